@@ -1,0 +1,141 @@
+"""ORACLE tooling -- runs ONLY in the build container (needs /root/reference).
+
+Generates tests/golden/*.npz by running the *imported reference* (through
+oracle/ref_shim.py) on seeded synthetic inputs/weights defined in
+tests/golden_util.py.  Only outputs are stored; inputs are regenerated from
+seeds on whichever machine runs the tests.
+
+    python oracle/gen_golden.py            # (re)write every fixture + manifest
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+import golden_util as gu    # noqa: E402
+from oracle import cpu_ref, ref_shim   # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def main():
+    assert ref_shim.available(), 'reference tree not found'
+    torch.set_num_threads(8)
+    os.makedirs(gu.GOLDEN_DIR, exist_ok=True)
+    manifest = dict(reference='ZeldaM1/PnP-VCVE @ /root/reference (imported on CPU via oracle/ref_shim.py)',
+                    torch=torch.__version__, cases={})
+    Ref = ref_shim.reference_generator_class()
+    sbu, da, bvn = ref_shim.reference_modules()
+    ref_flow_warp = ref_shim.reference_flow_warp()
+
+    # ---- full generator -------------------------------------------------
+    for case in gu.GEN_CASES:
+        cfg, sd_np, clip = gu.gen_case_inputs(case)
+        m = Ref(**cfg).eval()
+        sd = cpu_ref.to_torch_state(sd_np)
+        m.load_state_dict(sd, strict=True)
+        a = {k: T(v) for k, v in clip.items()}
+        with torch.no_grad():
+            ref = m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
+            mine = cpu_ref.generator_forward(sd, cfg, a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'],
+                                             a['partitions'])
+            # how much each ingredient matters in this case (so a parity gate of 1e-3 can see it)
+            sens = {}
+            sens['par->0'] = float((cpu_ref.generator_forward(sd, cfg, a['lq'], a['QPs'], a['slices'], a['mvs'],
+                                                              a['base_QPs'], a['partitions'] * 0) - ref).abs().max())
+            sens['mvs->0'] = float((cpu_ref.generator_forward(sd, cfg, a['lq'], a['QPs'], a['slices'], a['mvs'] * 0,
+                                                              a['base_QPs'], a['partitions']) - ref).abs().max())
+            sens['QPs*2'] = float((cpu_ref.generator_forward(sd, cfg, a['lq'], a['QPs'] * 2, a['slices'], a['mvs'],
+                                                             a['base_QPs'], a['partitions']) - ref).abs().max())
+            sens['base*2'] = float((cpu_ref.generator_forward(sd, cfg, a['lq'], a['QPs'], a['slices'], a['mvs'],
+                                                              a['base_QPs'] * 2, a['partitions']) - ref).abs().max())
+            sens['allkey'] = float((cpu_ref.generator_forward(sd, cfg, a['lq'], a['QPs'], a['slices'] * 0 + 80,
+                                                              a['mvs'], a['base_QPs'], a['partitions']) - ref).abs().max())
+        d = float((ref - mine).abs().max())
+        np.savez(os.path.join(gu.GOLDEN_DIR, case['name'] + '.npz'), out=ref.numpy())
+        manifest['cases'][case['name']] = dict(kind='generator', shape=list(ref.shape),
+                                               oracle_vs_reference_maxabs=d, sensitivity=sens,
+                                               out_minus_lq_maxabs=float((ref - (a['lq'] if not cfg['vsr'] else 0)).abs().max()))
+        print(case['name'], list(ref.shape), 'oracle-vs-ref', d, sens, flush=True)
+        assert d < 1e-5
+
+    # ---- flow_warp --------------------------------------------------------
+    for case in gu.WARP_CASES:
+        x, flow = gu.warp_case_inputs(case)
+        with torch.no_grad():
+            ref = ref_flow_warp(T(x), T(flow))
+            mine = cpu_ref.flow_warp(T(x), T(flow))
+        d = float((ref - mine).abs().max())
+        np.savez(os.path.join(gu.GOLDEN_DIR, case['name'] + '.npz'), out=ref.numpy())
+        manifest['cases'][case['name']] = dict(kind='flow_warp', shape=list(ref.shape), oracle_vs_reference_maxabs=d)
+        print(case['name'], d, flush=True)
+        assert d < 1e-5
+
+    # ---- CAA predictors ---------------------------------------------------
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=41)
+    sd = cpu_ref.to_torch_state(sd_np)
+    q = T(np.array(gu.CAA_QPS, np.float32).reshape(1, -1, 1, 1, 1))
+    bp = da.Base_Predictor(nf=64, num_experts=6, softmax=True).eval()
+    bp.load_state_dict({k[len('BasePredictor.'):]: v for k, v in sd.items() if k.startswith('BasePredictor.')})
+    se = da.SEModule(64).eval()
+    se.load_state_dict({k[len('BiasePredictor.'):]: v for k, v in sd.items() if k.startswith('BiasePredictor.')})
+    with torch.no_grad():
+        ew_ref = bp(q)
+        g_ref, _ = se(q)
+        ew = cpu_ref.base_predictor(sd, q, True)
+        g, _ = cpu_ref.bias_predictor(sd, cfg, q)
+    d = max(float((ew_ref - ew).abs().max()), float((g_ref - g).abs().max()))
+    np.savez(os.path.join(gu.GOLDEN_DIR, 'caa_predictors.npz'), ew=ew_ref.numpy(), gamma=g_ref.numpy())
+    manifest['cases']['caa_predictors'] = dict(kind='caa', oracle_vs_reference_maxabs=d, wseed=41)
+    print('caa', d, flush=True)
+    assert d < 1e-6
+
+    # ---- one BAE block / one branch ----------------------------------------
+    for case in gu.BLOCK_CASES:
+        cfg, sd_np, x, par, ew, gamma = gu.block_case_inputs(case)
+        sd = cpu_ref.to_torch_state(sd_np)
+        pre = 'backward_resblocks.main.0.'
+        blk = sbu.ResidualBlockNoBNDynamic_drt(mid_channels=64, num_experts=6, with_se=True, init_weight=True,
+                                               one_layer=True, channel_first=True, sparse_val=False).eval()
+        blk.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+        h, w = x.shape[-2:]
+        with torch.no_grad():
+            inp = {'x': T(x), 'par': T(par).view(1, 3, 1, h, w), 'weights': T(ew), 'gamma': T(gamma), 'beta': None}
+            ref = blk(inp)['x']
+            mine = cpu_ref.bae_block(sd, cfg, pre, T(x), T(par).view(1, 3, 1, h, w), T(ew), T(gamma))
+        d = float((ref - mine).abs().max())
+        out = dict(block=ref.numpy())
+        # whole forward branch (input conv + 8 blocks) on a 195-channel input
+        br = bvn.ResidualBlocksWithInputConvDynamic_drt(195, 64, 8, 6, True, with_se=True, init_weight=True,
+                                                        num_group=1, one_layer=True, blocktype='drt',
+                                                        channel_first=True, sparse_val=False).eval()
+        pb = 'forward_resblocks.'
+        br.load_state_dict({k[len(pb):]: v for k, v in sd.items() if k.startswith(pb)})
+        xin = gu.syn.uniform(case['seed'], 'xin', (1, 195, h, w), -1.0, 1.0)
+        with torch.no_grad():
+            inp = {'x': T(xin), 'par': T(par), 'weights': T(ew), 'gamma': T(gamma), 'beta': None}
+            ref_b = br(inp)['x']
+            mine_b = cpu_ref.resblocks(sd, cfg, 'forward_resblocks', T(xin), T(par), T(ew), T(gamma))
+        d2 = float((ref_b - mine_b).abs().max())
+        out['branch'] = ref_b.numpy()
+        np.savez(os.path.join(gu.GOLDEN_DIR, case['name'] + '.npz'), **out)
+        manifest['cases'][case['name']] = dict(kind='block+branch', oracle_vs_reference_maxabs=max(d, d2))
+        print(case['name'], d, d2, flush=True)
+        assert max(d, d2) < 1e-5
+
+    with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json'), 'w') as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print('wrote', gu.GOLDEN_DIR)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,135 @@
+"""Shared definitions of the golden-vector cases.
+
+Inputs and weights are regenerated from integer seeds (pnp_vcve_amd.synthetic);
+only the *reference outputs* are stored under tests/golden/ (written by
+oracle/gen_golden.py, which runs the imported reference in the build
+container).  Used by tests/ and by the generator script.
+"""
+import os
+
+import numpy as np
+
+from pnp_vcve_amd import synthetic as syn
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+# ---------------------------------------------------------------- generator
+# name, cfg overrides, weight seed, clip kwargs.  par_gain / par_scale are
+# chosen so that the partition branch is visible (see 'sensitivity' in the
+# manifest written by gen_golden.py).
+GEN_CASES = [
+    dict(name='gen_t7_ibbbp_64x96', cfg={}, wseed=11, par_gain=10.0,
+         clip=dict(seed=101, n=1, t=7, h=64, w=96, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_t7_allB_64x64', cfg={}, wseed=12, par_gain=10.0,
+         clip=dict(seed=102, n=1, t=7, h=64, w=64, slices='allB', qp_mode='ipb', crf=35)),
+    dict(name='gen_t7_allP_64x64', cfg={}, wseed=13, par_gain=10.0,
+         clip=dict(seed=103, n=1, t=7, h=64, w=64, slices='allP', qp_mode='ipb', crf=15)),
+    dict(name='gen_t8_64x64', cfg={}, wseed=14, par_gain=10.0,
+         clip=dict(seed=104, n=1, t=8, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_t8_mirror_64x64', cfg={}, wseed=14, par_gain=10.0, mirror=True,
+         clip=dict(seed=105, n=1, t=8, h=64, w=64, slices=[73, 66, 80, 66, 66, 80, 66, 73], qp_mode='qp', crf=25)),
+    dict(name='gen_n2_mixed_64x64', cfg={}, wseed=15, par_gain=10.0,
+         clip=dict(seed=106, n=2, t=5, h=64, w=64, slices=[[73, 66, 66, 80, 66], [73, 80, 66, 66, 66]],
+                   qp_mode='qp', crf=[15, 35])),
+    dict(name='gen_nocat_64x64', cfg=dict(with_cat=False), wseed=16, par_gain=10.0,
+         clip=dict(seed=107, n=1, t=5, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_noalignkey_64x64', cfg=dict(align_key=False), wseed=17, par_gain=10.0,
+         clip=dict(seed=108, n=1, t=5, h=64, w=64, slices='allP', qp_mode='qp', crf=25)),
+    dict(name='gen_vsr_64x64', cfg=dict(vsr=True), wseed=18, par_gain=10.0,
+         clip=dict(seed=109, n=1, t=2, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_t7_128x128', cfg={}, wseed=19, par_gain=1.0,
+         clip=dict(seed=110, n=1, t=7, h=128, w=128, slices='IBBBP', qp_mode='ipb', crf=25)),
+    dict(name='gen_parfloat_72x88', cfg={}, wseed=20, par_gain=1.0,
+         clip=dict(seed=111, n=1, t=4, h=72, w=88, slices='IBBBP', qp_mode='qp', crf=25, par_scale=1.0)),
+    dict(name='gen_two_layer_64x64', cfg=dict(one_layer=False), wseed=21, par_gain=10.0,
+         clip=dict(seed=112, n=1, t=3, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_channel_last_64x64', cfg=dict(channel_first=False), wseed=22, par_gain=10.0,
+         clip=dict(seed=113, n=1, t=3, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_nose_64x64', cfg=dict(with_se=False), wseed=23, par_gain=10.0,
+         clip=dict(seed=114, n=1, t=3, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_nobias_nosoftmax_qp_64x64',
+         cfg=dict(with_bias=False, with_se=False, expert_softmax=False, use_base_qp=False, num_experts=4,
+                  num_blocks=3),
+         wseed=24, par_gain=10.0,
+         clip=dict(seed=115, n=1, t=3, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+]
+
+
+def gen_case_inputs(case):
+    """-> (cfg, state-dict (numpy), clip dict (numpy))."""
+    cfg = dict(syn.DEFAULT_GENERATOR_CFG)
+    cfg.update(case['cfg'])
+    sd = syn.make_state_dict(cfg, seed=case['wseed'], par_gain=case.get('par_gain', 1.0))
+    clip = syn.make_clip(**case['clip'])
+    if case.get('mirror'):
+        # mirror-extended sequence: frame i == frame t-1-i (iconvsr.py:396-410)
+        t = clip['lq'].shape[1]
+        for i in range(t // 2):
+            clip['lq'][:, t - 1 - i] = clip['lq'][:, i]
+    return cfg, sd, clip
+
+
+# ---------------------------------------------------------------- flow_warp
+WARP_CASES = [
+    dict(name='warp_int_1x16x64x96', seed=201, shape=(1, 16, 64, 96), kind='int'),
+    dict(name='warp_frac_1x16x64x96', seed=202, shape=(1, 16, 64, 96), kind='frac'),
+    dict(name='warp_oob_2x8x64x64', seed=203, shape=(2, 8, 64, 64), kind='oob'),
+    dict(name='warp_block_1x64x40x56', seed=204, shape=(1, 64, 40, 56), kind='block'),
+    dict(name='warp_zero_1x4x64x64', seed=205, shape=(1, 4, 64, 64), kind='zero'),
+]
+
+
+def warp_case_inputs(case):
+    n, c, h, w = case['shape']
+    s = case['seed']
+    x = syn.uniform(s, 'x', (n, c, h, w), -1.0, 1.0)
+    kind = case['kind']
+    if kind == 'int':
+        flow = syn.randint(s, 'flow', (n, h, w, 2), -6, 6).astype(np.float32)
+    elif kind == 'frac':
+        flow = syn.uniform(s, 'flow', (n, h, w, 2), -8.0, 8.0)
+    elif kind == 'oob':
+        flow = syn.uniform(s, 'flow', (n, h, w, 2), -1.5 * w, 1.5 * w)
+    elif kind == 'block':
+        blk = syn.randint(s, 'flow', (n, h // 8, w // 8, 2), -32, 32).astype(np.float32) / 4.0
+        flow = np.repeat(np.repeat(blk, 8, axis=1), 8, axis=2)
+    elif kind == 'zero':
+        flow = np.zeros((n, h, w, 2), np.float32)
+    else:
+        raise ValueError(kind)
+    return x, np.ascontiguousarray(flow)
+
+
+# ---------------------------------------------------------------- CAA predictors
+CAA_QPS = [0.0, 15 / 255.0, 25 / 255.0, 35 / 255.0, 51 / 255.0, 66 / 255.0, 73 / 255.0, 80 / 255.0, 1.0]
+
+
+# ---------------------------------------------------------------- block / branch
+BLOCK_CASES = [
+    dict(name='block_par255', wseed=31, par_gain=10.0, seed=301, h=32, w=32, par='onehot255'),
+    dict(name='block_parzero', wseed=31, par_gain=10.0, seed=302, h=32, w=32, par='zero'),
+    dict(name='block_parfloat', wseed=32, par_gain=1.0, seed=303, h=24, w=40, par='float'),
+]
+
+
+def block_case_inputs(case):
+    cfg = dict(syn.DEFAULT_GENERATOR_CFG)
+    sd = syn.make_state_dict(cfg, seed=case['wseed'], par_gain=case['par_gain'])
+    s, h, w = case['seed'], case['h'], case['w']
+    x = syn.uniform(s, 'x', (1, 64, h, w), -1.0, 1.0)
+    if case['par'] == 'zero':
+        par = np.zeros((1, 3, h, w), np.float32)
+    elif case['par'] == 'float':
+        par = syn.uniform(s, 'par', (1, 3, h, w), 0.0, 1.0)
+    else:
+        cls = syn.randint(s, 'par', (1, h // 8, w // 8), 0, 3)
+        blk = np.stack([(cls == j) for j in range(3)], axis=1).astype(np.float32) / np.float32(255.0)
+        par = np.repeat(np.repeat(blk, 8, axis=2), 8, axis=3)
+    ew = syn.uniform(s, 'ew', (1, 6), 0.0, 1.0)
+    ew = (ew / ew.sum(axis=1, keepdims=True)).astype(np.float32)
+    gamma = syn.uniform(s, 'gamma', (1, 64), 0.0, 2.0)
+    return cfg, sd, x, np.ascontiguousarray(par), ew, gamma
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
