@@ -1,0 +1,117 @@
+/* libpnpvcve_hip.so -- C ABI of the MI355X-native PnP-VCVE BAE/CAA forward hot path.
+ *
+ * The reference (ZeldaM1/PnP-VCVE) is pure Python on PyTorch/mmcv and has no FFI of its own;
+ * each entry point below names the reference function it replaces (paths relative to
+ * /root/reference).  All pointers named *_dev are device (HBM) addresses owned by the
+ * caller; the library allocates no device memory, launches asynchronously on the supplied
+ * stream (a hipStream_t passed as void*) and returns 0 on success, a hipError_t value, or
+ * one of the PNP_ERR_* codes.  fp32 throughout.  No global state: every call is re-entrant.
+ */
+#ifndef PNPVCVE_H
+#define PNPVCVE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNP_ERR_BAD_ARG 1001
+#define PNP_ERR_UNSUPPORTED 1002
+#define PNP_ERR_WORKSPACE 1003
+#define PNP_ERR_SIZE_ASSERT 1004 /* reference: AssertionError, h/w < 64 (iconvsr_ipb_par.py:51) */
+#define PNP_ERR_SIZE_VALUE 1005  /* reference: ValueError from flow_warp.py:27-29 (h/w % 4 != 0) */
+
+int pnp_abi_version(void);
+
+/* ------------------------------------------------------------------ generator (a1/a2)
+ * Constructor kwargs of IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par
+ * (mmedit/models/backbones/sr_backbones/iconvsr_ipb_par.py:18-41 and parents
+ *  iconvsr_ipb.py:16-31, iconvsr.py:346-369).  Booleans are 0/1. */
+typedef struct pnp_generator_cfg {
+    int mid_channels; /* only 64 */
+    int num_blocks;
+    int num_experts;
+    int with_cat, use_base_qp, expert_softmax, with_bias, with_se;
+    int one_layer, channel_first, align_key, vsr;
+    int deform; /* 0 'vos' (MV bilinear warp); 1 'basic', 2 'fvc' reserved */
+} pnp_generator_cfg;
+
+typedef struct pnp_generator pnp_generator;
+
+int pnp_generator_create(const pnp_generator_cfg* cfg, pnp_generator** out);
+void pnp_generator_destroy(pnp_generator* g);
+
+/* Parameter schema = the reference state-dict: name, shape and the
+ * float offset of each tensor inside the flat parameter buffer the caller fills. */
+int pnp_generator_num_params(const pnp_generator* g);
+const char* pnp_generator_param_name(const pnp_generator* g, int i);
+int pnp_generator_param_ndim(const pnp_generator* g, int i);
+int64_t pnp_generator_param_dim(const pnp_generator* g, int i, int d);
+int64_t pnp_generator_param_offset(const pnp_generator* g, int i);
+int64_t pnp_generator_flat_floats(const pnp_generator* g);
+int64_t pnp_generator_packed_floats(const pnp_generator* g);
+
+/* flat (reference layouts) -> packed (MFMA B images); replaces nothing in the reference,
+ * it is the checkpoint-load-time half of mmcv load_checkpoint (iconvsr.py:510-523). */
+int pnp_generator_pack(const pnp_generator* g, const float* flat_dev, float* packed_dev, void* stream);
+
+int64_t pnp_generator_workspace_bytes(const pnp_generator* g, int t, int h, int w);
+
+/* generator.forward(lrs, QPs, slices, mvs, base_QPs, par_map)  iconvsr_ipb_par.py:44-149.
+ *   lrs_dev (n,t,3,h,w)  mvs_dev (n,t,4,h,w)  par_dev (n,t,3,h,w)      NCHW, contiguous
+ *   slices/qps/base_qps: HOST arrays of n*t floats (the (n,t,1,1,1) tensors, flattened);
+ *   the reference reads the same values host-side (int(torch.where(...)), :81,:116).
+ *   out_dev (n,t,3,h,w), or (n,t,3,4h,4w) when cfg.vsr. */
+int pnp_generator_forward(const pnp_generator* g, const float* flat_dev, const float* packed_dev,
+                          const float* lrs_dev, const float* mvs_dev, const float* par_dev,
+                          const float* slices_host, const float* qps_host, const float* base_qps_host,
+                          float* out_dev, void* workspace_dev, int64_t workspace_bytes,
+                          int n, int t, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------ single ops
+ * flow_warp(x, flow, 'bilinear', 'zeros', align_corners=True)  mmedit/models/common/flow_warp.py:6-50
+ *   x (n,c,h,w) NCHW ; flow (n,h,w,2) pixels (dx,dy) ; out (n,c,h,w). */
+int pnp_flow_warp_nchw_f32(const float* x_dev, const float* flow_dev, float* out_dev,
+                           int n, int c, int h, int w, void* stream);
+/* The same gather in the pixel-major layout the fused path uses (VOSAlignment.forward,
+ * iconvsr_mv.py:17-18): feat/out (h,w,c) ; flow_x/flow_y (h,w) planes. */
+int pnp_mv_warp_nhwc_f32(const float* feat_dev, const float* flow_x_dev, const float* flow_y_dev,
+                         float* out_dev, int h, int w, int c, void* stream);
+
+int pnp_nchw_to_nhwc_f32(const float* in_dev, float* out_dev, int n, int c, int h, int w, void* stream);
+int pnp_nhwc_to_nchw_f32(const float* in_dev, float* out_dev, int n, int c, int h, int w, void* stream);
+
+/* Base_Predictor / SEModule  (domain_aware.py:172-183, 210-222); host QP values in,
+ * ew_dev (count, E) and gamma_dev (count, 64) out.  v1/v2 may be NULL (gamma = 1). */
+int pnp_caa_predict_f32(const float* q_ew_host, const float* q_gamma_host, int count, int num_experts,
+                        int softmax, const float* w1_dev, const float* b1_dev, const float* w2_dev,
+                        const float* b2_dev, const float* v1_dev, const float* v2_dev,
+                        float* ew_dev, float* gamma_dev, void* stream);
+
+/* Weight packing for pnp_conv3x3_f32: OIHW (cout, cin_total, 3, 3) -> B image of input
+ * channels [cbase, cbase+csrc) (csrc = 64 -> 9 chunks, csrc = 3 -> 1 chunk); with
+ * num_experts > 1, w is (E, cout, cin_total, 3, 3) and ew_dev (E) mixes the experts first
+ * (Dynamic_conv2d_se.forward, sr_backbone_utils.py:198-199).  cout <= 64. */
+int64_t pnp_packed_conv_floats(int csrc);
+int pnp_pack_conv3x3_f32(const float* w_dev, const float* ew_dev, int num_experts, int cout, int cin_total,
+                         int cbase, int csrc, float* dst_dev, void* stream);
+/* 1x1 (64,64,1,1) -> 1 chunk */
+int pnp_pack_conv1x1_f32(const float* w_dev, float* dst_dev, void* stream);
+
+/* Generic fused 3x3 conv over a virtual concat of up to 4 pixel-major sources
+ * (64 channels each, or the 4-channel RGB0 frame):
+ *   v = conv3x3(cat(srcs)) ; v = (v + bias) * gamma ; v += sum_j par_j * conv1x1_j(src0)
+ *   v = act(v) ; v += residual ; out (h,w,64)
+ * This one op covers input_conv+LeakyReLU (basicvsr_net.py:484,515), both halves of
+ * ResidualBlockNoBNDynamic_drt.forward (sr_backbone_utils.py:304-333) and conv_hr
+ * (iconvsr.py:365).  NULL for unused bias/gamma/par/w1x1/residual.  act: 0 none, 1 relu,
+ * 2 leaky-relu(0.1).  par_dev: 3 NCHW planes (3,h,w). */
+int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_channels,
+                    const float* const* packed_w_dev, const float* bias_dev, const float* gamma_dev,
+                    const float* packed_w1x1_dev, const float* par_dev, const float* residual_dev,
+                    int act, float* out_dev, int h, int w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

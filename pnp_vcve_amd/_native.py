@@ -1,0 +1,82 @@
+"""ctypes binding of libpnpvcve_hip.so (the C ABI declared in include/pnpvcve.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpnpvcve_hip.so')
+
+PNP_ERR = {1001: 'bad argument', 1002: 'unsupported configuration', 1003: 'workspace too small or misaligned',
+           1004: 'size assert', 1005: 'size value'}
+
+
+class GeneratorCfg(ctypes.Structure):
+    _fields_ = [(k, c_int) for k in (
+        'mid_channels', 'num_blocks', 'num_experts', 'with_cat', 'use_base_qp', 'expert_softmax', 'with_bias',
+        'with_se', 'one_layer', 'channel_first', 'align_key', 'vsr', 'deform')]
+
+
+# name -> (restype, argtypes); every symbol include/pnpvcve.h declares
+SIGNATURES = {
+    'pnp_abi_version': (c_int, []),
+    'pnp_generator_create': (c_int, [POINTER(GeneratorCfg), POINTER(c_void_p)]),
+    'pnp_generator_destroy': (None, [c_void_p]),
+    'pnp_generator_num_params': (c_int, [c_void_p]),
+    'pnp_generator_param_name': (c_char_p, [c_void_p, c_int]),
+    'pnp_generator_param_ndim': (c_int, [c_void_p, c_int]),
+    'pnp_generator_param_dim': (c_int64, [c_void_p, c_int, c_int]),
+    'pnp_generator_param_offset': (c_int64, [c_void_p, c_int]),
+    'pnp_generator_flat_floats': (c_int64, [c_void_p]),
+    'pnp_generator_packed_floats': (c_int64, [c_void_p]),
+    'pnp_generator_pack': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'pnp_generator_workspace_bytes': (c_int64, [c_void_p, c_int, c_int, c_int]),
+    'pnp_generator_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      POINTER(c_float), POINTER(c_float), POINTER(c_float),
+                                      c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'pnp_flow_warp_nchw_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'pnp_mv_warp_nhwc_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'pnp_nchw_to_nhwc_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'pnp_nhwc_to_nchw_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'pnp_caa_predict_f32': (c_int, [POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'pnp_packed_conv_floats': (c_int64, [c_int]),
+    'pnp_pack_conv3x3_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'pnp_pack_conv1x1_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'pnp_conv3x3_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -m pnp_vcve_amd.build_native` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == 1004:
+        raise AssertionError(f'{what}: the height and width of inputs should be at least 64')
+    if rc == 1005:
+        raise ValueError(f'{what}: the spatial sizes of input and flow are not the same '
+                         '(frame size must be a multiple of 4)')
+    if rc in PNP_ERR:
+        raise RuntimeError(f'{what}: {PNP_ERR[rc]} (pnp error {rc})')
+    raise RuntimeError(f'{what}: HIP error {rc}')

@@ -1,0 +1,46 @@
+"""Builds libpnpvcve_hip.so (gfx950) in-tree with hipcc.  No torch involved."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'lib', 'libpnpvcve_hip.so')
+SOURCES = ['conv_mfma.hip', 'warp.hip', 'prep.hip', 'generator.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    mt = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > mt for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    objdir = os.path.join(HERE, 'lib', 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers.append(os.path.join(HERE, '..', 'include', 'pnpvcve.h'))
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

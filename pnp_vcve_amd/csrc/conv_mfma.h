@@ -1,0 +1,34 @@
+// 3x3 (+ fused 1x1 partition branches) implicit-GEMM convolution on the fp32
+// MFMA pipe of gfx950.  See conv_mfma.hip for the design notes.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const float* src[4];    // NHWC sources (virtual concat, never materialised)
+    const float* wsrc[4];   // packed chunk images per source (9 chunks for C=64, 1 for C=4)
+    int src_c[4];           // 64 or 4
+    int nsrc;
+    const float* wpar;      // 3 chunks (conv16x16, conv16x8, conv8x8) or nullptr
+    const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
+    long par_plane;         // floats between planes
+    const float* bias;      // [N] or nullptr
+    const float* gamma;     // [N] channel gain applied to (conv + bias) BEFORE the 1x1 branches, or nullptr
+    const float* residual;  // NHWC64, added after the activation, or nullptr
+    float* out;
+    const float* lr;        // out_mode 2/3: RGB frame, 3 NCHW planes
+    long lr_plane;
+    long w_ystride;         // floats between the weight images of consecutive blockIdx.y
+    int bias_ystride;
+    int H, W;               // spatial size of the sources
+    int act;                // 0 none, 1 relu, 2 leaky-relu(0.1)
+    int out_mode;           // 0 NHWC64 | 1 NHWC64 pixel-shuffle(2), sub-pixel = blockIdx.y
+                            // 2 RGB NCHW + lr | 3 RGB NCHW + bilinear x4 upsample of lr (H/4 x W/4)
+};
+
+enum { CONV_CFG_BIG = 0,    // 8x16 pixel tile, 64 output channels per block
+       CONV_CFG_SMALL = 1,  // 4x16 pixel tile, 64 output channels per block (fills the chip on small frames)
+       CONV_CFG_RGB = 2 };  // 8x16 pixel tile, <=32 output channels (conv_last)
+
+// grid_y > 1 only for out_mode 1 (4 sub-pixel images).
+int launch_conv3x3(const ConvArgs& a, int cfg, int grid_y, hipStream_t stream);
+int conv_pick_cfg(int H, int W);

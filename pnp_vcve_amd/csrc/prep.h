@@ -1,0 +1,41 @@
+// Layout, weight-packing, expert-mixing and CAA hyper-network kernels.
+#pragma once
+#include "common.h"
+
+// (T,3,H,W) NCHW frames -> (T,H,W,4) pixel-major, 4th channel zero
+int launch_pack_lr(const float* lrs, float* lr4, int T, int H, int W, hipStream_t stream);
+// generic layout converters (op-level tests / boundary glue)
+int launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, hipStream_t stream);
+int launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, hipStream_t stream);
+
+enum { PACK_WIDE = 0, PACK_RGB4 = 1, PACK_1X1 = 2 };
+struct PackArgs {
+    const float* w;     // [E][cout_total][cin_total][ktaps]
+    const float* ew;    // [E] mixing weights (nullptr: E must be 1)
+    int E;
+    long e_stride;      // floats between experts
+    int cin_total, ktaps;
+    int co_mul, co_add; // reference output channel = co * co_mul + co_add
+    int n_valid;        // packed output channels >= n_valid are zero
+    int kind;           // PACK_*
+    int cbase;          // first input channel of this source inside the virtual concat
+    int ntb;            // N tiles of 32 in the image (2 -> 64 channels, 1 -> 32)
+    float* dst;         // 9 chunks (PACK_WIDE) or 1 chunk
+    long w_ystride;     // blockIdx.y batching: floats between consecutive convs in w / dst
+    long dst_ystride;
+};
+int launch_pack_weights(const PackArgs& a, int grid_y, hipStream_t stream);
+// bias_out[y][c] = sum_e ew[e] * b[y][e][c]   (Dynamic_conv2d_se aggregate_bias)
+int launch_mix_bias(const float* b, const float* ew, float* out, int E, int C, int nconv, hipStream_t stream);
+
+// CAA hyper-network (Base_Predictor + SEModule) for up to 32 frames per launch.
+struct CaaArgs {
+    float q_ew[32];     // base_QPs (or QPs) per frame
+    float q_g[32];      // QPs per frame
+    int count, t0, E, softmax, with_se;
+    const float *w1, *b1, *w2, *b2;   // BasePredictor.BaseNet.{0,2}
+    const float *v1, *v2;             // BiasePredictor.fc.{0,2} (with_se)
+    float* ew;          // [T][E]
+    float* gamma;       // [T][64]
+};
+int launch_caa_predict(const CaaArgs& a, hipStream_t stream);

@@ -1,0 +1,115 @@
+// MV-guided bilinear alignment (the reference's VOSAlignment = flow_warp:
+// mmedit/models/backbones/sr_backbones/iconvsr_mv.py:12-18,
+// mmedit/models/common/flow_warp.py:6-50 -> F.grid_sample(bilinear, zeros, align_corners=True)).
+//
+// HBM-bound gather.  Algorithmic bytes per output pixel (C = 64, fp32):
+//   8 (flow) + 256 (each source byte once) + 256 (write) = 520 B.
+//
+// Pixel-major layout: one pixel's 64 channels are 256 contiguous bytes, so every bilinear
+// tap is one fully-used 256-B segment; 16 lanes x float4 cover a pixel, a wave covers 4
+// pixels per instruction, and since codec MVs are constant over >= 8x8 blocks neighbouring
+// pixels' taps are neighbouring segments (L2/TA friendly).  No LDS is needed: there is no
+// reuse beyond what a 4-tap footprint shares through L1/L2.
+#include "warp.h"
+
+namespace {
+
+// Coordinate arithmetic kept in the reference's order (normalise to [-1,1], flow_warp.py:41-42,
+// then ATen's align_corners=True un-normalise) so results track the CPU path to ~1e-7.
+__device__ __forceinline__ void tap_setup(float x, float y, float fx, float fy, int H, int W,
+                                          int& x0, int& y0, float& wx1, float& wy1) {
+    const float px = x + fx, py = y + fy;
+    const float wm1 = (float)(W - 1 > 1 ? W - 1 : 1), hm1 = (float)(H - 1 > 1 ? H - 1 : 1);
+    const float nx = 2.0f * px / wm1 - 1.0f, ny = 2.0f * py / hm1 - 1.0f;
+    float ix = ((nx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((ny + 1.0f) / 2.0f) * (float)(H - 1);
+    // keep the int conversion defined for wild vectors; anything beyond [-1, size] has no valid tap
+    ix = fminf(fmaxf(ix, -2.0f), (float)W + 1.0f);
+    iy = fminf(fmaxf(iy, -2.0f), (float)H + 1.0f);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    x0 = (int)fx0;
+    y0 = (int)fy0;
+    wx1 = ix - fx0;
+    wy1 = iy - fy0;
+}
+
+// feat/out: [H][W][C4*4] ; fxp/fyp: [H][W] planes (two channel planes of the NCHW mvs tensor)
+__global__ __launch_bounds__(256) void mv_warp_nhwc_kernel(const float* __restrict__ feat,
+                                                           const float* __restrict__ fxp,
+                                                           const float* __restrict__ fyp,
+                                                           float* __restrict__ out, int H, int W, int C4,
+                                                           long total) {
+    const f32x4* f4 = reinterpret_cast<const f32x4*>(feat);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C4;
+        const int c4 = (int)(i - pix * C4);
+        const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
+        int x0, y0;
+        float wx1, wy1;
+        tap_setup((float)x, (float)y, fxp[pix], fyp[pix], H, W, x0, y0, wx1, wy1);
+        const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;   // == (x0+1) - ix
+        const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x0 + 1 >= 0) & (x0 + 1 < W);
+        const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y0 + 1 >= 0) & (y0 + 1 < H);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const long r0 = ((long)y0 * W + x0) * C4 + c4, r1 = r0 + (long)W * C4;
+        const f32x4 v00 = (vx0 & vy0) ? f4[r0] : z;
+        const f32x4 v01 = (vx1 & vy0) ? f4[r0 + C4] : z;
+        const f32x4 v10 = (vx0 & vy1) ? f4[r1] : z;
+        const f32x4 v11 = (vx1 & vy1) ? f4[r1 + C4] : z;
+        o4[i] = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+    }
+}
+
+// Drop-in for flow_warp(x, flow): x (n,c,h,w) NCHW, flow (n,h,w,2) = (dx,dy) pixels.
+__global__ __launch_bounds__(256) void flow_warp_nchw_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ flow,
+                                                             float* __restrict__ out, int N, int C, int H, int W) {
+    const long hw = (long)H * W;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)N * hw) return;
+    const int n = (int)(p / hw);
+    const long pix = p - (long)n * hw;
+    const int yy = (int)(pix / W), xx = (int)(pix - (long)yy * W);
+    int x0, y0;
+    float wx1, wy1;
+    tap_setup((float)xx, (float)yy, flow[p * 2], flow[p * 2 + 1], H, W, x0, y0, wx1, wy1);
+    const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x0 + 1 >= 0) & (x0 + 1 < W);
+    const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y0 + 1 >= 0) & (y0 + 1 < H);
+    const float w00 = (vx0 & vy0) ? wx0 * wy0 : 0.f, w01 = (vx1 & vy0) ? wx1 * wy0 : 0.f;
+    const float w10 = (vx0 & vy1) ? wx0 * wy1 : 0.f, w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+    const long o00 = (long)cy0 * W + cx0, o01 = (long)cy0 * W + cx1;
+    const long o10 = (long)cy1 * W + cx0, o11 = (long)cy1 * W + cx1;
+    const float* xb = x + (long)n * C * hw;
+    float* ob = out + (long)n * C * hw + pix;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float* xc = xb + (long)c * hw;
+        ob[(long)c * hw] = xc[o00] * w00 + xc[o01] * w01 + xc[o10] * w10 + xc[o11] * w11;
+    }
+}
+
+}  // namespace
+
+int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, float* out, int H, int W, int C,
+                        hipStream_t stream) {
+    if (C % 4) return PNP_ERR_BAD_ARG;
+    const long total = (long)H * W * (C / 4);
+    long blocks = (total + 255) / 256;
+    const long cap = 256L * 32;            // 32 blocks per CU worth of grid, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(mv_warp_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, feat, fx, fy, out, H, W,
+                       C / 4, total);
+    return (int)hipGetLastError();
+}
+
+int launch_flow_warp_nchw(const float* x, const float* flow, float* out, int N, int C, int H, int W,
+                          hipStream_t stream) {
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(flow_warp_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, flow,
+                       out, N, C, H, W);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,196 @@
+"""The generator behind the reference's registry name.
+
+Same constructor kwargs, forward signature, state-dict keys and error behaviour as
+/root/reference/mmedit/models/backbones/sr_backbones/iconvsr_ipb_par.py:16-149
+(class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par), but the forward is a
+single call into libpnpvcve_hip.so (pnp_generator_forward), which schedules the whole clip
+as hand-written HIP kernels.  The nn.Module only holds the parameters in the reference's
+layout so that released checkpoints load unchanged.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _native
+from .registry import BACKBONES
+
+_DEFORM = {'vos': 0, 'basic': 1, 'fvc': 2}
+
+
+def _kaiming_normal_fan_in(t, scale):
+    nn.init.kaiming_normal_(t, a=0, mode='fan_in', nonlinearity='relu')
+    t.data.mul_(scale)
+
+
+@BACKBONES.register_module()
+class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
+    def __init__(self, mid_channels=64, num_blocks=30, num_experts=10, num_group=1, expert_softmax=False,
+                 use_base_qp=False, with_bias=False, with_se=False, with_par=False, init_weight=False,
+                 one_layer=False, small_sft=False, blocktype='default', channel_first=False, drconv=False,
+                 sparse_val=False, vsr=False, align_key=False,
+                 # parents: iconvsr_ipb.py:16, iconvsr.py:346-351
+                 with_cat=False, deform='vos', max_residue_magnitude=10, flow_inter='bilinear',
+                 keyframe_stride=5, padding=2):
+        super().__init__()
+        if deform == 'stdf':
+            raise TypeError('Not implemented yet')          # iconvsr_ipb.py:25-26
+        if deform not in _DEFORM:
+            raise TypeError('Not such DCN type')            # iconvsr_ipb.py:27-28
+        if blocktype not in ('drt',):
+            raise NotImplementedError(f"blocktype={blocktype!r}: only 'drt' (the shipped configs) is built")
+        if num_group != 1 or mid_channels != 64:
+            raise NotImplementedError('only mid_channels=64, num_group=1 (the shipped configs) are built')
+        if flow_inter != 'bilinear':
+            raise NotImplementedError("only flow_inter='bilinear'")
+        if with_bias:
+            assert use_base_qp is True or use_base_qp == 1     # iconvsr_ipb_par.py:27
+        self.mid_channels = mid_channels
+        self.padding = padding
+        self.keyframe_stride = keyframe_stride
+        self.flow_inter = flow_inter
+        self.with_cat, self.use_base_qp, self.with_bias = with_cat, use_base_qp, with_bias
+        self.with_par, self.vsr, self.align_key = with_par, vsr, align_key
+        self.is_mirror_extended = False
+        self._cfg = _native.GeneratorCfg(
+            mid_channels=mid_channels, num_blocks=num_blocks, num_experts=num_experts, with_cat=int(with_cat),
+            use_base_qp=int(use_base_qp), expert_softmax=int(expert_softmax), with_bias=int(with_bias),
+            with_se=int(with_se), one_layer=int(one_layer), channel_first=int(channel_first),
+            align_key=int(align_key), vsr=int(vsr), deform=_DEFORM[deform])
+        self._handle = ctypes.c_void_p()
+        L = _native.lib()
+        _native.check(L.pnp_generator_create(ctypes.byref(self._cfg), ctypes.byref(self._handle)),
+                      'pnp_generator_create')
+        # parameters, named and shaped as the native library's schema says (== reference state-dict)
+        self._schema = []
+        for i in range(L.pnp_generator_num_params(self._handle)):
+            name = L.pnp_generator_param_name(self._handle, i).decode()
+            shape = tuple(int(L.pnp_generator_param_dim(self._handle, i, d))
+                          for d in range(L.pnp_generator_param_ndim(self._handle, i)))
+            off = int(L.pnp_generator_param_offset(self._handle, i))
+            self._schema.append((name, shape, off))
+            self._register(name, nn.Parameter(torch.zeros(shape)))
+        self._flat_floats = int(L.pnp_generator_flat_floats(self._handle))
+        self._packed_floats = int(L.pnp_generator_packed_floats(self._handle))
+        self._init_like_reference(init_weight)
+        self._flat = self._packed = None
+        self._pack_key = None
+        self._workspace = {}
+
+    # ---------------------------------------------------------------- parameters
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split('.')
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.register_parameter(parts[-1], param)
+
+    def _init_like_reference(self, init_weight):
+        """SURVEY.md Appendix B (sr_backbone_utils.py:41-57,152-164,291-292; torch defaults)."""
+        for name, p in self.named_parameters():
+            with torch.no_grad():
+                in_block = '.main.' in name
+                if p.dim() == 5:                                        # Dynamic_conv2d experts (E,64,64,3,3)
+                    if init_weight:
+                        for k in range(p.shape[0]):
+                            nn.init.kaiming_uniform_(p[k])
+                    else:
+                        p.normal_()
+                elif in_block and name.endswith('.bias'):               # expert biases (E,64) and conv1.bias
+                    p.zero_()
+                elif in_block:                                          # conv1 / 1x1: default_init_weights(m, 0.1)
+                    _kaiming_normal_fan_in(p, 0.1)
+                elif 'upsample' in name:                                # PixelShufflePack: default_init_weights(self, 1)
+                    p.zero_() if name.endswith('.bias') else _kaiming_normal_fan_in(p, 1.0)
+                elif name.endswith('.bias'):                            # torch default conv / linear bias
+                    ref = dict(self.named_parameters())[name[:-4] + 'weight']
+                    bound = 1.0 / math.sqrt(ref[0].numel())
+                    p.uniform_(-bound, bound)
+                else:                                                   # torch default conv / linear weight
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+
+    def init_weights(self, pretrained=None, strict=True):
+        """iconvsr.py:510-523."""
+        if isinstance(pretrained, str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=strict)
+        elif pretrained is not None:
+            raise TypeError(f'"pretrained" must be a str or None. But received {type(pretrained)}.')
+
+    def _ensure_packed(self, device):
+        params = dict(self.named_parameters())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params.values())
+        if self._pack_key == key:
+            return
+        flat = torch.zeros(self._flat_floats, device=device, dtype=torch.float32)
+        for name, shape, off in self._schema:
+            p = params[name]
+            if not p.is_cuda:
+                raise RuntimeError('generator parameters must be on the GPU: call .cuda() first '
+                                   '(no CPU fallback exists for this path)')
+            flat[off:off + p.numel()].copy_(p.detach().reshape(-1))
+        packed = torch.zeros(self._packed_floats, device=device, dtype=torch.float32)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _native.check(_native.lib().pnp_generator_pack(self._handle, ctypes.c_void_p(flat.data_ptr()),
+                                                       ctypes.c_void_p(packed.data_ptr()), st), 'pnp_generator_pack')
+        self._flat, self._packed, self._pack_key = flat, packed, key
+
+    def _get_workspace(self, t, h, w, device):
+        k = (t, h, w, str(device))
+        ws = self._workspace.get(k)
+        if ws is None:
+            nbytes = int(_native.lib().pnp_generator_workspace_bytes(self._handle, t, h, w))
+            self._workspace.clear()        # keep one shape resident
+            ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            self._workspace[k] = ws
+        return ws
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, lrs, QPs=None, slices=None, mvs=None, base_QPs=None, par_map=None):
+        """iconvsr_ipb_par.py:44-149.  lrs (n,t,3,h,w); QPs/slices/base_QPs (n,t,1,1,1);
+        mvs (n,t,4,h,w); par_map (n,t,3,h,w).  Returns (n,t,3,h,w) (x4 spatial when vsr)."""
+        if not lrs.is_cuda:
+            raise RuntimeError('PnP-VCVE generator: inputs must be CUDA/HIP tensors; this build has no CPU path '
+                               '(the CPU restatement under oracle/ is test infrastructure only)')
+        n, t, c, h, w = lrs.size()
+        assert h >= 64 and w >= 64, (
+            f'The height and width of inputs should be at least 64, but got {h} and {w}.')
+        dev = lrs.device
+        with torch.cuda.device(dev):
+            self._ensure_packed(dev)
+            lrs_c = lrs.detach().float().contiguous()
+            mvs_c = mvs.detach().float().contiguous()
+            par_c = par_map.detach().float().contiguous()
+            if mvs_c.shape != (n, t, 4, h, w) or par_c.shape != (n, t, 3, h, w):
+                raise ValueError(f'The spatial sizes of input ({(h, w)}) and flow/partition maps '
+                                 f'({tuple(mvs_c.shape)}, {tuple(par_c.shape)}) are not the same.')
+            # the three (n,t,1,1,1) side-info tensors drive host control flow (key frames, expert dedup)
+            side = torch.stack([slices.reshape(n, t).float(), QPs.reshape(n, t).float(),
+                                base_QPs.reshape(n, t).float()]).cpu().contiguous()
+            fp = ctypes.POINTER(ctypes.c_float)
+            base = side.data_ptr()
+            sl_p = ctypes.cast(base, fp)
+            qp_p = ctypes.cast(base + 4 * n * t, fp)
+            bq_p = ctypes.cast(base + 8 * n * t, fp)
+            s = 4 if self.vsr else 1
+            out = torch.empty((n, t, 3, h * s, w * s), device=dev, dtype=torch.float32)
+            ws = self._get_workspace(t, h, w, dev)
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = _native.lib().pnp_generator_forward(
+                self._handle, ctypes.c_void_p(self._flat.data_ptr()), ctypes.c_void_p(self._packed.data_ptr()),
+                ctypes.c_void_p(lrs_c.data_ptr()), ctypes.c_void_p(mvs_c.data_ptr()),
+                ctypes.c_void_p(par_c.data_ptr()), sl_p, qp_p, bq_p, ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(ws.data_ptr()), ws.numel(), n, t, h, w, st)
+            _native.check(rc, 'pnp_generator_forward')
+        return out
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _native.lib().pnp_generator_destroy(self._handle)
+                self._handle = ctypes.c_void_p()
+        except Exception:
+            pass

@@ -1,0 +1,131 @@
+"""Tensor-level wrappers over the C ABI (device pointers + the current HIP stream).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation
+runs in libpnpvcve_hip.so.  All functions require CUDA(HIP) fp32 contiguous tensors and
+raise otherwise -- there is deliberately no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDA/HIP tensor: the PnP-VCVE hot path has no CPU fallback')
+    if t.dtype != torch.float32:
+        raise TypeError(f'{name} must be float32, got {t.dtype}')
+    return t.contiguous()
+
+
+def flow_warp(x, flow, interpolation='bilinear', padding_mode='zeros', align_corners=True):
+    """Drop-in for mmedit.models.common.flow_warp (flow_warp.py:6-50).
+    x (n,c,h,w), flow (n,h,w,2) in pixels."""
+    if x.size()[-2:] != flow.size()[1:3]:
+        raise ValueError(f'The spatial sizes of input ({x.size()[-2:]}) and '
+                         f'flow ({flow.size()[1:3]}) are not the same.')
+    if interpolation != 'bilinear' or padding_mode != 'zeros' or not align_corners:
+        raise NotImplementedError('only bilinear / zeros / align_corners=True (what the hot path uses)')
+    x, flow = _chk(x, 'x'), _chk(flow, 'flow')
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    _native.check(_native.lib().pnp_flow_warp_nchw_f32(_ptr(x), _ptr(flow), _ptr(out), n, c, h, w, _stream()),
+                  'pnp_flow_warp_nchw_f32')
+    return out
+
+
+def mv_warp_nhwc(feat, flow_x, flow_y):
+    """feat (h,w,c) pixel-major; flow_x/flow_y (h,w)."""
+    feat, flow_x, flow_y = _chk(feat, 'feat'), _chk(flow_x, 'flow_x'), _chk(flow_y, 'flow_y')
+    h, w, c = feat.shape
+    out = torch.empty_like(feat)
+    _native.check(_native.lib().pnp_mv_warp_nhwc_f32(_ptr(feat), _ptr(flow_x), _ptr(flow_y), _ptr(out), h, w, c,
+                                                     _stream()), 'pnp_mv_warp_nhwc_f32')
+    return out
+
+
+def nchw_to_nhwc(x):
+    x = _chk(x, 'x')
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), device=x.device, dtype=x.dtype)
+    _native.check(_native.lib().pnp_nchw_to_nhwc_f32(_ptr(x), _ptr(out), n, c, h, w, _stream()), 'nchw_to_nhwc')
+    return out
+
+
+def nhwc_to_nchw(x):
+    x = _chk(x, 'x')
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), device=x.device, dtype=x.dtype)
+    _native.check(_native.lib().pnp_nhwc_to_nchw_f32(_ptr(x), _ptr(out), n, c, h, w, _stream()), 'nhwc_to_nchw')
+    return out
+
+
+def caa_predict(q_ew, q_gamma, w1, b1, w2, b2, v1=None, v2=None, softmax=True):
+    """Base_Predictor + SEModule (domain_aware.py:172-183, 210-222).
+    q_ew/q_gamma: python sequences of floats (host).  Returns (ew (count,E), gamma (count,64))."""
+    count = len(q_ew)
+    E = w2.shape[0]
+    dev = w1.device
+    ew = torch.empty((count, E), device=dev, dtype=torch.float32)
+    gamma = torch.empty((count, 64), device=dev, dtype=torch.float32)
+    qa = (ctypes.c_float * count)(*[float(v) for v in q_ew])
+    qg = (ctypes.c_float * count)(*[float(v) for v in q_gamma])
+    ts = [_chk(t, 'param') for t in (w1, b1, w2, b2)]
+    vs = [(_chk(v, 'param') if v is not None else None) for v in (v1, v2)]
+    _native.check(_native.lib().pnp_caa_predict_f32(qa, qg, count, E, int(bool(softmax)), _ptr(ts[0]), _ptr(ts[1]),
+                                                    _ptr(ts[2]), _ptr(ts[3]), _ptr(vs[0]), _ptr(vs[1]), _ptr(ew),
+                                                    _ptr(gamma), _stream()), 'pnp_caa_predict_f32')
+    return ew, gamma
+
+
+def pack_conv3x3(weight, cbase=0, csrc=64, ew=None):
+    """OIHW (cout,cin,3,3) [or (E,cout,cin,3,3) with ew (E,)] -> packed image for input
+    channels [cbase, cbase+csrc)."""
+    weight = _chk(weight, 'weight')
+    E = 1
+    if weight.dim() == 5:
+        E = weight.shape[0]
+        ew = _chk(ew, 'ew')
+    cout, cin = weight.shape[-4], weight.shape[-3]
+    L = _native.lib()
+    dst = torch.empty(int(L.pnp_packed_conv_floats(64 if csrc == 64 else 4)), device=weight.device, dtype=torch.float32)
+    _native.check(L.pnp_pack_conv3x3_f32(_ptr(weight), _ptr(ew), E, cout, cin, cbase, csrc, _ptr(dst), _stream()),
+                  'pnp_pack_conv3x3_f32')
+    return dst
+
+
+def pack_conv1x1(weights):
+    """three (64,64,1,1) weights -> one tensor of 3 chunks (conv16x16, conv16x8, conv8x8)."""
+    L = _native.lib()
+    n = int(L.pnp_packed_conv_floats(4))
+    dst = torch.empty(3 * n, device=weights[0].device, dtype=torch.float32)
+    for j, w in enumerate(weights):
+        w = _chk(w, 'w1x1')
+        _native.check(L.pnp_pack_conv1x1_f32(_ptr(w), ctypes.c_void_p(dst.data_ptr() + 4 * n * j), _stream()),
+                      'pnp_pack_conv1x1_f32')
+    return dst
+
+
+def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, residual=None, act=0):
+    """Fused conv over pixel-major sources [(h,w,64) or (h,w,4)].  See include/pnpvcve.h."""
+    srcs = [_chk(s, 'src') for s in srcs]
+    h, w = srcs[0].shape[:2]
+    n = len(srcs)
+    out = torch.empty((h, w, 64), device=srcs[0].device, dtype=torch.float32)
+    sp = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    sc = (ctypes.c_int * n)(*[s.shape[2] for s in srcs])
+    wp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in packed_w])
+    keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, packed_w1x1, par, residual)]
+    _native.check(_native.lib().pnp_conv3x3_f32(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]),
+                                                _ptr(keep[3]), _ptr(keep[4]), act, _ptr(out), h, w, _stream()),
+                  'pnp_conv3x3_f32')
+    return out

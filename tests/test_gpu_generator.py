@@ -1,0 +1,117 @@
+"""GPU parity of the whole BAE/CAA forward (pnp_generator_forward through the registry class)
+against the golden vectors produced by the imported reference."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # north_star gate is 1e-3 on enhanced frames; the fp32 MFMA path is held to 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def build(cfg, sd_np):
+    from pnp_vcve_amd.registry import build_backbone
+    m = build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    return m.to(dev()).eval()
+
+
+def run(m, clip):
+    a = {k: torch.from_numpy(v).to(dev()) for k, v in clip.items()}
+    with torch.no_grad():
+        return m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
+
+
+@pytest.mark.parametrize('case', gu.GEN_CASES, ids=[c['name'] for c in gu.GEN_CASES])
+def test_generator_vs_reference_golden(case):
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    out = run(build(cfg, sd_np), clip).cpu().numpy()
+    ref = gu.load_golden(case['name'])['out']
+    assert out.shape == ref.shape
+    d = float(np.abs(out - ref).max())
+    print(case['name'], 'max|hip - reference| =', d)
+    assert d < TOL
+
+
+def test_psnr_delta_vs_reference_is_negligible():
+    case = gu.GEN_CASES[0]
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    out = run(build(cfg, sd_np), clip).cpu()
+    ref = torch.from_numpy(gu.load_golden(case['name'])['out'])
+    gt = torch.from_numpy(clip['gt'])
+    assert abs(cpu_ref.clip_psnr(out, gt) - cpu_ref.clip_psnr(ref, gt)) < 0.01
+
+
+def test_reference_error_behaviour():
+    case = gu.GEN_CASES[0]
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    m = build(cfg, sd_np)
+    small = {k: (v[..., :32, :32] if v.shape[-1] > 1 else v) for k, v in clip.items()}
+    with pytest.raises(AssertionError):                 # iconvsr_ipb_par.py:51
+        run(m, {k: np.ascontiguousarray(v) for k, v in small.items()})
+    odd = {k: (v[..., :, :66] if v.shape[-1] > 1 else v) for k, v in clip.items()}
+    with pytest.raises(ValueError):                     # flow_warp.py:27-29
+        run(m, {k: np.ascontiguousarray(v) for k, v in odd.items()})
+    with pytest.raises(RuntimeError):                   # CPU tensors: loud failure, no fallback
+        a = {k: torch.from_numpy(v) for k, v in clip.items()}
+        m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
+
+
+def test_repack_after_weight_update():
+    case = gu.GEN_CASES[1]
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    m = build(cfg, sd_np)
+    a = run(m, clip)
+    with torch.no_grad():
+        m.conv_last.bias.add_(0.25)
+    b = run(m, clip)
+    assert float((b - a - 0.25).abs().max()) < 1e-6
+
+
+def test_deterministic_and_batch_order_independent():
+    case = gu.GEN_CASES[5]          # n = 2, different key patterns
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    m = build(cfg, sd_np)
+    a = run(m, clip)
+    b = run(m, clip)
+    assert torch.equal(a, b)
+    swapped = {k: np.ascontiguousarray(v[::-1]) for k, v in clip.items()}
+    c = run(m, swapped)
+    assert torch.equal(c[0], a[1]) and torch.equal(c[1], a[0])
+
+
+def test_720p_clip_crop_consistency_and_oracle_spot_check():
+    """BASELINE configs[2] shape (T shortened to 3): the 720p result must agree, far from the crop
+    border, with the same network run on a crop -- on the GPU and on the oracle."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=77, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=770, n=1, t=3, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, mv_range=8)
+    m = build(cfg, sd_np)
+    full = run(m, clip)
+    assert full.shape == (1, 3, 3, 720, 1280)
+    assert torch.isfinite(full).all()
+    cy, cx, ch, cw = 200, 480, 320, 320
+    crop = {k: (np.ascontiguousarray(v[..., cy:cy + ch, cx:cx + cw]) if v.shape[-1] > 1 else v) for k, v in clip.items()}
+    part = run(m, crop)
+    # receptive field: (17 convs + |mv| <= 2 px) per recurrent step, <= 2*3 steps + 2 head convs
+    mrg = 128
+    d = float((part[..., mrg:-mrg, mrg:-mrg] - full[..., cy + mrg:cy + ch - mrg, cx + mrg:cx + cw - mrg]).abs().max())
+    print('720p crop consistency', d)
+    assert d < 1e-5
+    # oracle on a smaller crop (CPU, seconds)
+    oy, ox, oh, ow = 296, 576, 128, 128
+    oc = {k: (np.ascontiguousarray(v[..., oy:oy + oh, ox:ox + ow]) if v.shape[-1] > 1 else v) for k, v in clip.items()}
+    t = {k: torch.from_numpy(v) for k, v in oc.items()}
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, t['lq'], t['QPs'], t['slices'], t['mvs'],
+                                        t['base_QPs'], t['partitions'])
+    got = run(m, oc).cpu()
+    assert float((got - ref).abs().max()) < TOL

@@ -1,0 +1,215 @@
+"""GPU parity tests of the single ops, through the C ABI (pnp_vcve_amd.ops -> libpnpvcve_hip.so),
+against the golden vectors of the imported reference and against the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as gu
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+TOL_WARP = 1e-5      # fp32 bilinear gather; SURVEY.md section 7 step 3 gate
+TOL_CONV = 2e-5      # exact-fp32 MFMA, K <= 1764, |activations| ~ 1
+TOL_BLOCK = 5e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+def test_native_library_is_loaded():
+    from pnp_vcve_amd import _native
+    assert _native.lib().pnp_abi_version() == 1
+
+
+@pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])
+def test_flow_warp_nchw_vs_reference(case):
+    from pnp_vcve_amd import ops
+    x, flow = gu.warp_case_inputs(case)
+    out = ops.flow_warp(G(x), G(flow))
+    ref = gu.load_golden(case['name'])['out']
+    assert maxdiff(out, ref) < TOL_WARP
+
+
+@pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])
+def test_mv_warp_nhwc_vs_reference(case):
+    from pnp_vcve_amd import ops
+    x, flow = gu.warp_case_inputs(case)
+    ref = gu.load_golden(case['name'])['out']
+    for n in range(x.shape[0]):
+        feat = ops.nchw_to_nhwc(G(x[n:n + 1]))[0]
+        out = ops.mv_warp_nhwc(feat, G(flow[n, :, :, 0]), G(flow[n, :, :, 1]))
+        back = ops.nhwc_to_nchw(out.unsqueeze(0))
+        assert maxdiff(back, ref[n:n + 1]) < TOL_WARP
+
+
+def test_flow_warp_errors_like_reference():
+    from pnp_vcve_amd import ops
+    with pytest.raises(ValueError):
+        ops.flow_warp(torch.zeros(1, 4, 8, 8, device=dev()), torch.zeros(1, 8, 9, 2, device=dev()))
+    with pytest.raises(RuntimeError):
+        ops.flow_warp(torch.zeros(1, 4, 8, 8), torch.zeros(1, 8, 8, 2))     # CPU tensors: no fallback
+
+
+def test_layout_round_trip():
+    from pnp_vcve_amd import ops
+    x = torch.randn(2, 12, 9, 20, device=dev())
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(y), x)
+
+
+def test_caa_predictors_vs_reference():
+    from pnp_vcve_amd import ops
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd = gu.syn.make_state_dict(cfg, seed=41)
+    g = gu.load_golden('caa_predictors')
+    ew, gamma = ops.caa_predict(gu.CAA_QPS, gu.CAA_QPS,
+                                G(sd['BasePredictor.BaseNet.0.weight']), G(sd['BasePredictor.BaseNet.0.bias']),
+                                G(sd['BasePredictor.BaseNet.2.weight']), G(sd['BasePredictor.BaseNet.2.bias']),
+                                G(sd['BiasePredictor.fc.0.weight']), G(sd['BiasePredictor.fc.2.weight']), softmax=True)
+    assert maxdiff(ew, g['ew'][0]) < 1e-6
+    assert maxdiff(gamma, g['gamma'][0]) < 1e-6
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (24, 40), (37, 53), (64, 64), (128, 256)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_conv3x3_single_source(hw, act):
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x = gu.syn.uniform(7, f'x{h}x{w}', (1, 64, h, w), -1, 1)
+    wt = gu.syn.uniform(7, 'w', (64, 64, 3, 3), -0.06, 0.06)
+    b = gu.syn.uniform(7, 'b', (64,), -0.1, 0.1)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(b), padding=1)
+    ref = [ref, F.relu(ref), F.leaky_relu(ref, 0.1)][act]
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    out = ops.conv3x3([xs], [ops.pack_conv3x3(G(wt))], bias=G(b), act=act)
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < TOL_CONV
+
+
+def test_conv3x3_identity_weights_localise_layout_bugs():
+    """centre-tap identity: out == in exactly; then a one-tap shift."""
+    from pnp_vcve_amd import ops
+    h, w = 24, 40
+    x = gu.syn.uniform(8, 'x', (1, 64, h, w), -1, 1)
+    for (ky, kx) in [(1, 1), (0, 0), (2, 1), (1, 2)]:
+        wt = np.zeros((64, 64, 3, 3), np.float32)
+        wt[np.arange(64), np.arange(64), ky, kx] = 1.0
+        ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), padding=1)
+        out = ops.conv3x3([ops.nchw_to_nhwc(G(x))[0]], [ops.pack_conv3x3(G(wt))])
+        assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) == 0.0, (ky, kx)
+    # asymmetric channel permutation (catches transposed B images)
+    perm = np.roll(np.arange(64), 5)
+    wt = np.zeros((64, 64, 3, 3), np.float32)
+    wt[np.arange(64), perm, 1, 1] = 1.0
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(wt), padding=1)
+    out = ops.conv3x3([ops.nchw_to_nhwc(G(x))[0]], [ops.pack_conv3x3(G(wt))])
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) == 0.0
+
+
+@pytest.mark.parametrize('nwide', [0, 1, 2, 3])
+def test_conv3x3_virtual_concat(nwide):
+    """input_conv over [lr(3), wide sources...] == conv2d over the materialised cat."""
+    from pnp_vcve_amd import ops
+    h, w = 40, 56
+    cin = 3 + 64 * nwide
+    lr = gu.syn.uniform(9, 'lr', (1, 3, h, w), 0, 1)
+    wides = [gu.syn.uniform(9, f's{j}', (1, 64, h, w), -1, 1) for j in range(nwide)]
+    wt = gu.syn.uniform(9, f'w{nwide}', (64, cin, 3, 3), -0.05, 0.05)
+    b = gu.syn.uniform(9, 'b', (64,), -0.1, 0.1)
+    cat = np.concatenate([lr] + wides, axis=1)
+    ref = F.leaky_relu(F.conv2d(torch.from_numpy(cat), torch.from_numpy(wt), torch.from_numpy(b), padding=1), 0.1)
+    lr4 = np.concatenate([lr, np.zeros((1, 1, h, w), np.float32)], axis=1)
+    srcs = [ops.nchw_to_nhwc(G(lr4))[0]] + [ops.nchw_to_nhwc(G(s))[0] for s in wides]
+    wg = G(wt)
+    packed = [ops.pack_conv3x3(wg, 0, 3)] + [ops.pack_conv3x3(wg, 3 + 64 * j, 64) for j in range(nwide)]
+    out = ops.conv3x3(srcs, packed, bias=G(b), act=2)
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < TOL_CONV
+
+
+def _block_via_ops(sd, prefix, x, par, ew, gamma):
+    """ResidualBlockNoBNDynamic_drt (channel_first, one_layer) out of two fused conv launches."""
+    from pnp_vcve_amd import ops
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    ewg = G(ew[0])
+    w2 = ops.pack_conv3x3(G(sd[prefix + 'conv2.weight']), ew=ewg)
+    b2 = (G(sd[prefix + 'conv2.bias']) * ewg[:, None]).sum(0)
+    w1x1 = ops.pack_conv1x1([G(sd[prefix + k + '.weight']) for k in ('conv16x16', 'conv16x8', 'conv8x8')])
+    o = ops.conv3x3([xs], [w2], bias=b2, gamma=G(gamma[0]), packed_w1x1=w1x1, par=G(par[0]), act=1)
+    w1 = ops.pack_conv3x3(G(sd[prefix + 'conv1.weight']))
+    y = ops.conv3x3([o], [w1], bias=G(sd[prefix + 'conv1.bias']), residual=xs, act=0)
+    return ops.nhwc_to_nchw(y.unsqueeze(0))
+
+
+@pytest.mark.parametrize('case', gu.BLOCK_CASES, ids=[c['name'] for c in gu.BLOCK_CASES])
+def test_bae_block_vs_reference(case):
+    cfg, sd, x, par, ew, gamma = gu.block_case_inputs(case)
+    out = _block_via_ops(sd, 'backward_resblocks.main.0.', x, par, ew, gamma)
+    ref = gu.load_golden(case['name'])['block']
+    assert maxdiff(out, ref) < TOL_BLOCK
+
+
+def test_bae_block_partition_branch_is_live():
+    """zeroing par must change the result by what the oracle says (guards a silently dead 1x1 branch)."""
+    case = gu.BLOCK_CASES[2]
+    cfg, sd, x, par, ew, gamma = gu.block_case_inputs(case)
+    a = _block_via_ops(sd, 'backward_resblocks.main.0.', x, par, ew, gamma)
+    b = _block_via_ops(sd, 'backward_resblocks.main.0.', x, par * 0, ew, gamma)
+    t = cpu_ref.to_torch_state(sd)
+    h, w = x.shape[-2:]
+    ra = cpu_ref.bae_block(t, cfg, 'backward_resblocks.main.0.', torch.from_numpy(x),
+                           torch.from_numpy(par).view(1, 3, 1, h, w), torch.from_numpy(ew), torch.from_numpy(gamma))
+    rb = cpu_ref.bae_block(t, cfg, 'backward_resblocks.main.0.', torch.from_numpy(x),
+                           torch.zeros(1, 3, 1, h, w), torch.from_numpy(ew), torch.from_numpy(gamma))
+    assert float((ra - rb).abs().max()) > 1e-2
+    assert maxdiff(a - b, ra - rb) < TOL_BLOCK
+
+
+# ---------------------------------------------------------------- full-size properties (720p)
+def test_warp_720p_zero_and_integer_motion_exact():
+    from pnp_vcve_amd import ops
+    h, w = 720, 1280
+    feat = torch.rand(h, w, 64, device=dev())
+    z = torch.zeros(h, w, device=dev())
+    assert torch.equal(ops.mv_warp_nhwc(feat, z, z), feat)
+    out = ops.mv_warp_nhwc(feat, z + 3.0, z - 2.0)      # sample (x+3, y-2)
+    exp = torch.zeros_like(feat)
+    exp[2:, :w - 3] = feat[:h - 2, 3:]
+    # the reference's normalise/un-normalise round trip costs ~3 ulp of 1280 (1.2e-4 px) in the
+    # sample position, for the CPU path and for this kernel alike
+    assert float((out - exp).abs().max()) < 5e-4
+    # fractional, block-constant motion against the NCHW drop-in (two independent kernels)
+    blk = (torch.randint(-32, 33, (2, h // 8, w // 8), device=dev()).float() / 4.0)
+    fl = blk.repeat_interleave(8, 1).repeat_interleave(8, 2)
+    a = ops.mv_warp_nhwc(feat, fl[0].contiguous(), fl[1].contiguous())
+    b = ops.flow_warp(feat.permute(2, 0, 1).unsqueeze(0).contiguous(), fl.permute(1, 2, 0).unsqueeze(0).contiguous())
+    assert float((a.permute(2, 0, 1).unsqueeze(0) - b).abs().max()) < 1e-6
+
+
+def test_conv_720p_scaling_linearity_and_crop_consistency():
+    from pnp_vcve_amd import ops
+    h, w = 720, 1280
+    x = torch.randn(h, w, 64, device=dev())
+    wt = (torch.randn(64, 64, 3, 3, device=dev()) * 0.05)
+    pw = ops.pack_conv3x3(wt)
+    y = ops.conv3x3([x], [pw])
+    y2 = ops.conv3x3([x * 2.0], [pw])
+    assert torch.equal(y2, y * 2.0)                      # power-of-two scaling is exact in fp32
+    # a 96x112 crop, away from the crop border, sees the same pixels
+    cy, cx = 301, 517
+    yc = ops.conv3x3([x[cy:cy + 96, cx:cx + 112].contiguous()], [pw])
+    assert float((yc[1:-1, 1:-1] - y[cy + 1:cy + 95, cx + 1:cx + 111]).abs().max()) < 1e-5
+    # and against ATen on the host for that crop
+    ref = F.conv2d(x[cy:cy + 96, cx:cx + 112].permute(2, 0, 1).unsqueeze(0).cpu(), wt.cpu(), padding=1)
+    assert maxdiff(yc.permute(2, 0, 1).unsqueeze(0), ref) < TOL_CONV * 4

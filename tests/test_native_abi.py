@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/pnpvcve.h declares;
+host-side schema logic (no GPU compute)."""
+import os
+import re
+
+import pytest
+import torch
+
+from pnp_vcve_amd import _native, synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(_native.LIB_PATH):
+        from pnp_vcve_amd import build_native
+        build_native.build()
+    return _native.lib()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'pnpvcve.h')).read()
+    declared = set(re.findall(r'\b(pnp_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations found'
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pnp_abi_version() == 1
+
+
+def test_schema_equals_reference_state_dict():
+    from pnp_vcve_amd.generator import IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par as Gen
+    for over in ({}, dict(vsr=True), dict(with_cat=False), dict(one_layer=False), dict(with_se=False),
+                 dict(with_bias=False, with_se=False, num_experts=4, num_blocks=3)):
+        cfg = dict(syn.DEFAULT_GENERATOR_CFG)
+        cfg.update(over)
+        m = Gen(**cfg)
+        sd = m.state_dict()
+        sch = syn.state_dict_schema(cfg)
+        assert set(sd) == set(sch), (over, set(sd) ^ set(sch))
+        for k, shp in sch.items():
+            assert tuple(sd[k].shape) == tuple(shp), k
+    m = Gen(**syn.DEFAULT_GENERATOR_CFG)
+    assert sum(p.numel() for p in m.parameters()) == 4559885
+
+
+def test_constructor_errors_like_reference():
+    from pnp_vcve_amd.generator import IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par as Gen
+    cfg = dict(syn.DEFAULT_GENERATOR_CFG)
+    with pytest.raises(TypeError):
+        Gen(**dict(cfg, deform='nope'))
+    with pytest.raises(TypeError):
+        Gen(**dict(cfg, deform='stdf'))
+    with pytest.raises(AssertionError):
+        Gen(**dict(cfg, use_base_qp=False))      # with_bias requires use_base_qp (iconvsr_ipb_par.py:27)
+
+
+def test_no_cpu_fallback():
+    from pnp_vcve_amd.generator import IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par as Gen
+    m = Gen(**syn.DEFAULT_GENERATOR_CFG)
+    z = torch.zeros(1, 2, 3, 64, 64)
+    s = torch.zeros(1, 2, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        m(z, s, s, torch.zeros(1, 2, 4, 64, 64), s, z)
