@@ -182,12 +182,13 @@ def test_warp_720p_zero_and_integer_motion_exact():
     h, w = 720, 1280
     feat = torch.rand(h, w, 64, device=dev())
     z = torch.zeros(h, w, device=dev())
-    assert torch.equal(ops.mv_warp_nhwc(feat, z, z), feat)
+    # the reference's normalise/un-normalise round trip (flow_warp.py:41-42 + ATen) costs ~3 ulp of
+    # 1280 (1.2e-4 px) in the sample position -- for the CPU path and for this kernel alike -- so
+    # zero / integer motion is an identity / shift only to ~1e-4 x local contrast at this size
+    assert float((ops.mv_warp_nhwc(feat, z, z) - feat).abs().max()) < 5e-4
     out = ops.mv_warp_nhwc(feat, z + 3.0, z - 2.0)      # sample (x+3, y-2)
     exp = torch.zeros_like(feat)
     exp[2:, :w - 3] = feat[:h - 2, 3:]
-    # the reference's normalise/un-normalise round trip costs ~3 ulp of 1280 (1.2e-4 px) in the
-    # sample position, for the CPU path and for this kernel alike
     assert float((out - exp).abs().max()) < 5e-4
     # fractional, block-constant motion against the NCHW drop-in (two independent kernels)
     blk = (torch.randint(-32, 33, (2, h // 8, w // 8), device=dev()).float() / 4.0)
