@@ -68,6 +68,18 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat_dev, const f
                           float* out_dev, void* workspace_dev, int64_t workspace_bytes,
                           int n, int t, int h, int w, void* stream);
 
+/* Optional per-launch timing with HIP events recorded on the caller's stream around every
+ * kernel of pnp_generator_forward (measurement aid for bench.py; replaces the reference's
+ * wall-clock print, mmedit/models/restorers/basicvsr.py:176-182).  Enable, run forwards,
+ * then read per kind: total device ms, launch count and algorithmic work (FLOPs for the
+ * conv kinds, bytes for PNP_PROF_WARP).  Reading waits for the recorded events. */
+#define PNP_PROF_CONV_BLOCK 0 /* the 64->64 BAE convs (K = 576 or 768) */
+#define PNP_PROF_CONV_INPUT 1 /* input convs over the virtual concat */
+#define PNP_PROF_CONV_HEAD 2  /* conv_hr is BLOCK-shaped but conv_last / upsample convs land here */
+#define PNP_PROF_WARP 3       /* MV-guided bilinear alignment, 520 B per pixel */
+int pnp_generator_profile(pnp_generator* g, int enable);
+int pnp_generator_profile_read(pnp_generator* g, int kind, double* total_ms, int64_t* launches, double* work);
+
 /* ------------------------------------------------------------------ single ops
  * flow_warp(x, flow, 'bilinear', 'zeros', align_corners=True)  mmedit/models/common/flow_warp.py:6-50
  *   x (n,c,h,w) NCHW ; flow (n,h,w,2) pixels (dx,dy) ; out (n,c,h,w). */

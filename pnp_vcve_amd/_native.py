@@ -36,6 +36,9 @@ SIGNATURES = {
     'pnp_generator_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       POINTER(c_float), POINTER(c_float), POINTER(c_float),
                                       c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'pnp_generator_profile': (c_int, [c_void_p, c_int]),
+    'pnp_generator_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),
+                                           POINTER(ctypes.c_double)]),
     'pnp_flow_warp_nchw_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_mv_warp_nhwc_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'pnp_nchw_to_nhwc_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

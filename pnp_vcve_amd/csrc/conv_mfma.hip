@@ -76,6 +76,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    // ---- epilogue operands are fetched NOW so that their HBM/L2 latency hides under the K loop
+    //      (the residual may alias `out` element-for-element, which would otherwise serialise
+    //      every load behind the previous store).
+    const int n0 = lane & 31;
+    float bco[NT], gco[NT], pv[3] = {0.f, 0.f, 0.f};
+    float res[NT][16];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = (wn * NT + j) * 32 + n0;
+        bco[j] = a.bias ? a.bias[yimg * a.bias_ystride + co] : 0.f;
+        gco[j] = a.gamma ? a.gamma[co] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int gy = ty0 + 2 * wm + (mm >> 4), gx = tx0 + (mm & 15);
+            res[j][r] = (a.residual && gy < H && gx < W) ? a.residual[((long)gy * W + gx) * 64 + co] : 0.f;
+        }
+    }
+    if (a.wpar) {
+        const int gy = ty0 + 2 * wm + my, gx = tx0 + mx;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+            pv[jj] = (gy < H && gx < W) ? a.par[jj * a.par_plane + (long)gy * W + gx] : 0.f;
+    }
+
     // chunk bookkeeping: chunks of source s are wsrc[s] + tap*CH4*4 floats
     int nchunks = 0;
     for (int s = 0; s < a.nsrc; ++s) nchunks += (a.src_c[s] == 64) ? 9 : 1;
@@ -155,16 +180,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
                 const int dy = tap / 3, dx = tap - dy * 3;
                 const int apix = (2 * wm + my + dy) * PW + mx + dx;
                 const int sw = (mx + dx) & 15;
+                // fragments of q-step q+1 are read while the MFMAs of q-step q issue
+                f32x4 av = sA[apix * 16 + (h ^ sw)];
+                f32x4 bv[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = bb[j * 64];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const f32x4 av = sA[apix * 16 + ((2 * q + h) ^ sw)];
-                    f32x4 bv[NT];
+                    f32x4 an = av;
+                    f32x4 bn[NT];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bv[j] = bb[(q * NTB + j) * 64];
+                    for (int j = 0; j < NT; ++j) bn[j] = bv[j];
+                    if (q < 7) {
+                        an = sA[apix * 16 + ((2 * (q + 1) + h) ^ sw)];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) bn[j] = bb[((q + 1) * NTB + j) * 64];
+                    }
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                         for (int j = 0; j < NT; ++j) acc[j] = mfma32(av[kk], bv[j][kk], acc[j]);
+                    av = an;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[j] = bn[j];
                 }
             } else {
 #pragma unroll
@@ -192,15 +230,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
         }
     }
 
-    // ---- output coordinates of this lane's accumulator entries
-    const int n0 = lane & 31;
-    float bco[NT], gco[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = (wn * NT + j) * 32 + n0;
-        bco[j] = a.bias ? a.bias[yimg * a.bias_ystride + co] : 0.f;
-        gco[j] = a.gamma ? a.gamma[co] : 1.f;
-    }
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -208,11 +237,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 
     // ---- fused 1x1 partition branches: K-extension with A scaled by par_j(pixel)
     if (a.wpar) {
-        const int gy = ty0 + 2 * wm + my, gx = tx0 + mx;
-        float pv[3];
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
-            pv[jj] = (gy < H && gx < W) ? a.par[jj * a.par_plane + (long)gy * W + gx] : 0.f;
         const int apix = (2 * wm + my + 1) * PW + mx + 1;
         const int sw = (mx + 1) & 15;
 #pragma unroll
@@ -225,17 +249,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             }
             const f32x4* bb = sB + (c & 1) * CH4 + (wn * NT) * 64 + lane;
             const float ps = pv[jj];
+            f32x4 av = sA[apix * 16 + (h ^ sw)];
+            f32x4 bv[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = bb[j * 64];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                f32x4 av = sA[apix * 16 + ((2 * q + h) ^ sw)];
-                av *= ps;
-                f32x4 bv[NT];
+                f32x4 an = av;
+                f32x4 bn[NT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bv[j] = bb[(q * NTB + j) * 64];
+                for (int j = 0; j < NT; ++j) bn[j] = bv[j];
+                if (q < 7) {
+                    an = sA[apix * 16 + ((2 * (q + 1) + h) ^ sw)];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bn[j] = bb[((q + 1) * NTB + j) * 64];
+                }
+                av *= ps;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[j] = mfma32(av[kk], bv[j][kk], acc[j]);
+                av = an;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = bn[j];
             }
             if (more) {
                 f32x4* d = sB + ((c + 1) & 1) * CH4;
@@ -262,9 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
             if (a.out_mode == 0) {
-                const long o = ((long)gy * W + gx) * 64 + co;
-                if (a.residual) v += a.residual[o];
-                a.out[o] = v;
+                a.out[((long)gy * W + gx) * 64 + co] = v + res[j][r];
             } else if (a.out_mode == 1) {
                 const int oy = 2 * gy + (yimg >> 1), ox = 2 * gx + (yimg & 1);
                 a.out[((long)oy * (2 * W) + ox) * 64 + co] = v;

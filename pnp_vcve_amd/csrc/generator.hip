@@ -52,8 +52,19 @@ struct BranchPk {
 
 }  // namespace
 
+struct ProfRec {
+    hipEvent_t a, b;
+    int kind;
+    double work;
+};
+
 struct pnp_generator {
     pnp_generator_cfg cfg;
+    // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
+    mutable bool prof_on = false;
+    mutable std::vector<hipEvent_t> prof_pool;
+    mutable size_t prof_used = 0;
+    mutable std::vector<ProfRec> prof_recs;
     std::vector<ParamInfo> params;
     int64_t flat_floats = 0, packed_floats = 0;
     int ndyn = 0;
@@ -208,6 +219,31 @@ PackArgs plain_pack(const float* w, int cin_total, int ktaps, int kind, int cbas
     return a;
 }
 
+struct ProfScope {
+    const pnp_generator* g;
+    hipStream_t st;
+    bool on;
+    hipEvent_t b;
+    ProfScope(const pnp_generator* g_, hipStream_t st_, int kind, double work) : g(g_), st(st_), on(g_->prof_on) {
+        if (!on) return;
+        while (g->prof_pool.size() < g->prof_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) {
+                on = false;
+                return;
+            }
+            g->prof_pool.push_back(e);
+        }
+        hipEvent_t a = g->prof_pool[g->prof_used++];
+        b = g->prof_pool[g->prof_used++];
+        (void)hipEventRecord(a, st);
+        g->prof_recs.push_back(ProfRec{a, b, kind, work});
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(b, st);
+    }
+};
+
 struct Workspace {
     float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb;
     int64_t bytes;
@@ -263,7 +299,11 @@ int pnp_generator_create(const pnp_generator_cfg* cfg, pnp_generator** out) {
     return PNP_OK;
 }
 
-void pnp_generator_destroy(pnp_generator* g) { delete g; }
+void pnp_generator_destroy(pnp_generator* g) {
+    if (!g) return;
+    for (hipEvent_t e : g->prof_pool) (void)hipEventDestroy(e);
+    delete g;
+}
 
 int pnp_generator_num_params(const pnp_generator* g) { return (int)g->params.size(); }
 const char* pnp_generator_param_name(const pnp_generator* g, int i) { return g->params[i].name.c_str(); }
@@ -372,6 +412,14 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
         a.W = Wd;
         a.act = act;
         a.out_mode = mode;
+        // algorithmic FLOPs of this launch (reference channel counts, not padded ones)
+        double kreal = 0;
+        for (int s = 0; s < nsrc; ++s) kreal += 9.0 * (sc[s] == 64 ? 64 : 3);
+        if (wpar) kreal += 3 * 64;
+        const double nreal = (mode >= 2) ? 3 : 64;
+        const int kind = (mode != 0) ? PNP_PROF_CONV_HEAD : (nsrc > 1 || sc[0] != 64) ? PNP_PROF_CONV_INPUT
+                                                                                     : PNP_PROF_CONV_BLOCK;
+        ProfScope ps(g, st, kind, 2.0 * kreal * nreal * (double)H * Wd * gy);
         return launch_conv3x3(a, cfgsel, gy, st);
     };
     auto conv1src = [&](const float* src, const float* wimg, const float* bias, const float* gamma, const float* wpar,
@@ -510,8 +558,11 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
             if (i < t - 1) {
                 int k = i + 1;
                 while (!key[k]) ++k;
-                rc = launch_mv_warp_nhwc(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw,
-                                         mv_b + ((int64_t)i * 4 + 3) * hw, W.kw, h, w, 64, st);
+                {
+                    ProfScope ps(g, st, PNP_PROF_WARP, 520.0 * (double)hw);
+                    rc = launch_mv_warp_nhwc(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw,
+                                             mv_b + ((int64_t)i * 4 + 3) * hw, W.kw, h, w, 64, st);
+                }
                 if (rc) return rc;
                 srcs[ns] = W.kw;
                 sc[ns] = 64;
@@ -538,8 +589,11 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
             if (i > 0) {
                 int k = i - 1;
                 while (!key[k]) --k;
-                rc = launch_mv_warp_nhwc(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw,
-                                         mv_b + ((int64_t)i * 4 + 1) * hw, W.kw, h, w, 64, st);
+                {
+                    ProfScope ps(g, st, PNP_PROF_WARP, 520.0 * (double)hw);
+                    rc = launch_mv_warp_nhwc(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw,
+                                             mv_b + ((int64_t)i * 4 + 1) * hw, W.kw, h, w, 64, st);
+                }
                 if (rc) return rc;
                 srcs[ns] = W.kw;
                 sc[ns] = 64;
@@ -594,6 +648,35 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
             }
         }
     }
+    return PNP_OK;
+}
+
+int pnp_generator_profile(pnp_generator* g, int enable) {
+    if (!g) return PNP_ERR_BAD_ARG;
+    g->prof_on = enable != 0;
+    g->prof_used = 0;
+    g->prof_recs.clear();
+    return PNP_OK;
+}
+
+int pnp_generator_profile_read(pnp_generator* g, int kind, double* total_ms, int64_t* launches, double* work) {
+    if (!g || !total_ms || !launches || !work) return PNP_ERR_BAD_ARG;
+    double ms = 0, wk = 0;
+    int64_t n = 0;
+    for (const ProfRec& r : g->prof_recs) {
+        if (r.kind != kind) continue;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return (int)e;
+        float f = 0.f;
+        e = hipEventElapsedTime(&f, r.a, r.b);
+        if (e != hipSuccess) return (int)e;
+        ms += f;
+        wk += r.work;
+        ++n;
+    }
+    *total_ms = ms;
+    *launches = n;
+    *work = wk;
     return PNP_OK;
 }
 

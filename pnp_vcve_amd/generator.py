@@ -187,6 +187,23 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             _native.check(rc, 'pnp_generator_forward')
         return out
 
+    # ---------------------------------------------------------------- measurement aid
+    PROF_KINDS = {'conv_block': 0, 'conv_input': 1, 'conv_head': 2, 'mv_warp': 3}
+
+    def profile(self, enable=True):
+        """Bracket every kernel launch of forward() with HIP events (pnp_generator_profile)."""
+        _native.check(_native.lib().pnp_generator_profile(self._handle, int(bool(enable))), 'pnp_generator_profile')
+
+    def profile_read(self):
+        """-> {kind: dict(ms=total device ms, launches=n, work=FLOPs or bytes)} since profile(True)."""
+        res = {}
+        for name, k in self.PROF_KINDS.items():
+            ms, n, wk = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _native.check(_native.lib().pnp_generator_profile_read(self._handle, k, ctypes.byref(ms), ctypes.byref(n),
+                                                                   ctypes.byref(wk)), 'pnp_generator_profile_read')
+            res[name] = dict(ms=ms.value, launches=n.value, work=wk.value)
+        return res
+
     def __del__(self):
         try:
             if self._handle:

@@ -1,0 +1,54 @@
+"""Condense rocprofv3 csv output (kernel trace + PMC passes) into a per-kernel summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for k in ('conv3x3_mfma_kernel', 'mv_warp_nhwc_kernel', 'flow_warp_nchw_kernel', 'pack_weights_kernel',
+              'pack_lr_kernel', 'caa_predict_kernel', 'mix_bias_kernel'):
+        if k in name:
+            if k == 'conv3x3_mfma_kernel':
+                cfg = name.split('conv3x3_mfma_kernelI')[-1][:24]
+                return k + '<' + cfg.replace('Li', '').replace('E', ',').strip(',') + '>'
+            return k
+    return name[:60]
+
+
+def main(root):
+    tr = glob.glob(os.path.join(root, 'trace', '**', '*kernel_trace.csv'), recursive=True)
+    if tr:
+        agg = defaultdict(lambda: [0, 0.0])
+        for f in tr:
+            for r in csv.DictReader(open(f)):
+                d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+                a = agg[short(r['Kernel_Name'])]
+                a[0] += 1
+                a[1] += d
+        tot = sum(v[1] for v in agg.values())
+        print('== kernel trace (all dispatches of the profiled command)')
+        print(f'{"kernel":70s} {"calls":>7s} {"total_us":>12s} {"avg_us":>10s} {"%":>6s}')
+        for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f'{k:70s} {n:7d} {us:12.1f} {us / n:10.2f} {100 * us / tot:6.2f}')
+    for pas in ('pmc_sq', 'pmc_fetch', 'pmc_write', 'pmc_lds'):
+        fs = glob.glob(os.path.join(root, pas, '**', '*counter_collection.csv'), recursive=True)
+        if not fs:
+            continue
+        agg = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(int)
+        for f in fs:
+            for r in csv.DictReader(open(f)):
+                k = short(r['Kernel_Name'])
+                agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+                cnt[(k, r['Counter_Name'])] += 1
+        print(f'== {pas}: per-kernel counter AVERAGE per dispatch')
+        for k in sorted(agg):
+            parts = [f'{c}={v / cnt[(k, c)]:.4g}' for c, v in sorted(agg[k].items())]
+            n = max(cnt[(k, c)] for c in agg[k])
+            print(f'{k:70s} n={n:<6d} ' + ' '.join(parts))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
