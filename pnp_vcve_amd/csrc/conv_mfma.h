@@ -21,6 +21,7 @@ struct ConvArgs {
     int bias_ystride;
     int H, W;               // spatial size of the sources
     int act;                // 0 none, 1 relu, 2 leaky-relu(0.1)
+    unsigned long long* dbg; // diagnostic timeline buffer (8 u64 per block) or nullptr
     int out_mode;           // 0 NHWC64 | 1 NHWC64 pixel-shuffle(2), sub-pixel = blockIdx.y
                             // 2 RGB NCHW + lr | 3 RGB NCHW + bilinear x4 upsample of lr (H/4 x W/4)
 };

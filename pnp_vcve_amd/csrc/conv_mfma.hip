@@ -19,20 +19,35 @@
 // channels of its pixel) and NT float4 of B and issues 4*NT MFMAs: the K order inside a
 // q-step is permuted identically for A and B (common.h) so no shuffles are needed.
 //
-// LDS:  A tile  (TH+2) x 18 pixels x 256 B, 16-byte slots XOR-swizzled with the tile column
-//       (conflict-free ds_read_b128 across 16 consecutive columns);
-//       B chunks 2 x (8 q-steps x NTB x 1 KiB), double-buffered through registers
-//       (global_load early, ds_write after the chunk's MFMAs, one barrier per chunk).
+// LDS:  A tile  (TH+2) x 18 pixels x (256 + 16) B: the 16-byte pad makes 16 consecutive columns hit
+//       16 disjoint 4-bank groups (conflict-free ds_read_b128) AND keeps every fragment address of
+//       the K loop a per-lane base + compile-time immediate (no address VALU between MFMAs);
+//       B chunks 2 x (8 q-steps x NTB x 1 KiB), double-buffered through registers.
 //       8x16 tile: 46080 + 32768 = 78848 B  -> two blocks per CU (2 waves per SIMD), so one
 //       block's halo fill / epilogue overlaps the other's MFMA stream.
+//
+// What the r01 timeline (tools/trace_conv.py) showed and this structure answers:
+//   * a CU retires roughly one wave-level VMEM instruction per ~130 cycles whatever its
+//     width, so every global access here is 16 B per lane: the accumulator tile is
+//     transposed through the (by then free) A region of LDS and stored / residual-added as
+//     whole 256-B pixel rows (8 instead of 32 stores per wave);
+//   * fragment reads run one q-step ahead of the MFMAs and continue ACROSS the per-chunk
+//     barrier: chunk c+1's B image is written to the other buffer mid-chunk, the single
+//     barrier sits at the top of the last q-step (after this chunk's last LDS read, before
+//     the first read of the next buffer), so no LDS latency is exposed at chunk seams.
 #include "conv_mfma.h"
 #include <mutex>
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+template <int N>
+using T = std::integral_constant<int, N>;
 
 template <int WM, int WN, int NT, int NTB>
 struct ConvCfg {
@@ -41,18 +56,20 @@ struct ConvCfg {
     static constexpr int PW = TW + 2;
     static constexpr int PIX = (TH + 2) * PW;
     static constexpr int CH4 = PNP_CHUNK_Q * NTB * 64;      // float4 per chunk
-    static constexpr int LDS_BYTES = (PIX * 16 + 2 * CH4) * 16;
+    static constexpr int PSTR = 17;                         // float4 per LDS pixel: 256 B + 16 B pad
+    static constexpr int LDS_BYTES = (PIX * PSTR + 2 * CH4) * 16;
 };
 
 template <int WM, int WN, int NT, int NTB>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<WM, WN, NT, NTB>;
-    constexpr int TH = C::TH, TW = C::TW, PW = C::PW, PIX = C::PIX, CH4 = C::CH4;
+    constexpr int TH = C::TH, TW = C::TW, PW = C::PW, PIX = C::PIX, CH4 = C::CH4, PSTR = C::PSTR;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(NT * WN == NTB, "N tiles");
+    static_assert(4 * 32 * NT * 32 * 4 <= PIX * 256, "transpose region must fit the A tile");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f32x4* sA = reinterpret_cast<f32x4*>(smem_raw);
-    f32x4* sB = sA + PIX * 16;
+    f32x4* sB = sA + PIX * PSTR;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -69,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     }
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const int yimg = blockIdx.y;
+    const long yoff = (long)yimg * a.w_ystride;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -76,233 +94,293 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // ---- epilogue operands are fetched NOW so that their HBM/L2 latency hides under the K loop
-    //      (the residual may alias `out` element-for-element, which would otherwise serialise
-    //      every load behind the previous store).
+    // diagnostic timeline (a.dbg != nullptr only from tools/trace_conv.py): shader-clock stamps
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_e1 = 0, dbg_r0 = 0;
+    if (a.dbg) {
+        dbg_t0 = __builtin_amdgcn_s_memtime();
+        dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    // memory phases (halo fill, epilogue) outrank the co-resident block's MFMA stream for issue slots
+    __builtin_amdgcn_s_setprio(3);
+
+    // ---- row-wise epilogue geometry: a lane owns 16 B (4 channels) of one pixel per iteration
+    constexpr int CW = NT * 8;        // float4 per pixel inside this wave's N range
+    constexpr int PPI = 64 / CW;      // pixels per wave instruction
+    constexpr int EIT = 32 / PPI;     // iterations to cover the wave's 32 pixels
+    const int ec = lane % CW, ep = lane / CW;
     const int n0 = lane & 31;
+    const bool rowwise = a.out_mode < 2;
+
+    // ---- epilogue operands are fetched EARLY (right behind the first halo-tile loads) so their
+    //      latency hides under the K loop; the residual may alias `out` element-for-element.
     float bco[NT], gco[NT], pv[3] = {0.f, 0.f, 0.f};
-    float res[NT][16];
+    f32x4 res4[EIT];
+    auto prefetch_epilogue_operands = [&]() {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = (wn * NT + j) * 32 + n0;
-        bco[j] = a.bias ? a.bias[yimg * a.bias_ystride + co] : 0.f;
-        gco[j] = a.gamma ? a.gamma[co] : 1.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int gy = ty0 + 2 * wm + (mm >> 4), gx = tx0 + (mm & 15);
-            res[j][r] = (a.residual && gy < H && gx < W) ? a.residual[((long)gy * W + gx) * 64 + co] : 0.f;
+        for (int j = 0; j < NT; ++j) {
+            const int co = (wn * NT + j) * 32 + n0;
+            bco[j] = a.bias ? a.bias[yimg * a.bias_ystride + co] : 0.f;
+            gco[j] = a.gamma ? a.gamma[co] : 1.f;
         }
-    }
-    if (a.wpar) {
-        const int gy = ty0 + 2 * wm + my, gx = tx0 + mx;
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
-            pv[jj] = (gy < H && gx < W) ? a.par[jj * a.par_plane + (long)gy * W + gx] : 0.f;
-    }
-
-    // chunk bookkeeping: chunks of source s are wsrc[s] + tap*CH4*4 floats
-    int nchunks = 0;
-    for (int s = 0; s < a.nsrc; ++s) nchunks += (a.src_c[s] == 64) ? 9 : 1;
-    const int nmain = nchunks;
-    if (a.wpar) nchunks += 3;
-    const long yoff = (long)yimg * a.w_ystride;
-
-    auto chunk_ptr = [&](int c) -> const f32x4* {
-        // wave-uniform walk over at most 4 sources
-        int base = 0;
-        for (int s = 0; s < a.nsrc; ++s) {
-            const int n = (a.src_c[s] == 64) ? 9 : 1;
-            if (c < base + n) return reinterpret_cast<const f32x4*>(a.wsrc[s] + yoff) + (long)(c - base) * CH4;
-            base += n;
+        for (int i = 0; i < EIT; ++i) {
+            const int p = ep + i * PPI;
+            const int gy = ty0 + 2 * wm + (p >> 4), gx = tx0 + (p & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a.residual && gy < H && gx < W)
+                v = *reinterpret_cast<const f32x4*>(a.residual + ((long)gy * W + gx) * 64 + wn * NT * 32 + ec * 4);
+            res4[i] = v;
         }
-        return reinterpret_cast<const f32x4*>(a.wpar + yoff) + (long)(c - base) * CH4;
+        if (a.wpar) {
+            const int gy = ty0 + 2 * wm + my, gx = tx0 + mx;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                pv[jj] = (gy < H && gx < W) ? a.par[jj * a.par_plane + (long)gy * W + gx] : 0.f;
+        }
     };
 
     constexpr int BPT = CH4 / 256;
     f32x4 breg[BPT];
-    {   // chunk 0 -> sB[0]
-        const f32x4* g = chunk_ptr(0);
+    auto load_b = [&](const f32x4* g) {
 #pragma unroll
         for (int i = 0; i < BPT; ++i) breg[i] = g[t + 256 * i];
+    };
+    auto store_b = [&](int buf) {
+        f32x4* d = sB + buf * CH4;
 #pragma unroll
-        for (int i = 0; i < BPT; ++i) sB[t + 256 * i] = breg[i];
-    }
+        for (int i = 0; i < BPT; ++i) d[t + 256 * i] = breg[i];
+    };
+    const int bofs = (wn * NT) * 64 + lane;     // this lane's float4 inside a q-step of a B chunk
 
-    int c = 0;   // global chunk counter
-    for (int s = 0; s < a.nsrc; ++s) {
-        const float* sp = a.src[s];
-        const bool wide = (a.src_c[s] == 64);
-        // ------------------------------------------------------------ stage the halo tile
-        if (wide) {
-            constexpr int AIT = (PIX * 16 + 255) / 256;
-            f32x4 areg[AIT];
+    // ---- halo tile staging (global -> registers -> swizzled LDS), split so that the loads of the
+    //      first tile, of weight chunk 0 and of the epilogue operands are all in flight together
+    constexpr int AIT = (PIX * 16 + 255) / 256;
+    f32x4 areg[AIT];
+    auto stage_wide_load = [&](const float* sp) {
 #pragma unroll
-            for (int k = 0; k < AIT; ++k) {
-                const int i = t + 256 * k;
-                const int pix = i >> 4, c16 = i & 15;
-                const int ry = pix / PW, rx = pix - ry * PW;
-                const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (i < PIX * 16 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v = *reinterpret_cast<const f32x4*>(sp + ((long)gy * W + gx) * 64 + c16 * 4);
-                areg[k] = v;
-            }
-#pragma unroll
-            for (int k = 0; k < AIT; ++k) {
-                const int i = t + 256 * k;
-                const int pix = i >> 4, c16 = i & 15;
-                const int ry = pix / PW, rx = pix - ry * PW;
-                if (i < PIX * 16) sA[pix * 16 + (c16 ^ (rx & 15))] = areg[k];
-            }
-        } else {
-            for (int i = t; i < PIX; i += 256) {
-                const int ry = i / PW, rx = i - ry * PW;
-                const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v = *reinterpret_cast<const f32x4*>(sp + ((long)gy * W + gx) * 4);
-                sA[i] = v;
-            }
+        for (int k = 0; k < AIT; ++k) {
+            const int i = t + 256 * k;
+            const int pix = i >> 4, c16 = i & 15;
+            const int ry = pix / PW, rx = pix - ry * PW;
+            const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < PIX * 16 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const f32x4*>(sp + ((long)gy * W + gx) * 64 + c16 * 4);
+            areg[k] = v;
         }
-        __syncthreads();
+    };
+    auto stage_wide_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int i = t + 256 * k;
+            const int pix = i >> 4, c16 = i & 15;
+            if (i < PIX * 16) sA[pix * PSTR + c16] = areg[k];
+        }
+    };
+    auto stage_rgb = [&](const float* sp) {
+        for (int i = t; i < PIX; i += 256) {
+            const int ry = i / PW, rx = i - ry * PW;
+            const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(sp + ((long)gy * W + gx) * 4);
+            sA[i] = v;
+        }
+    };
 
-        const int ntap = wide ? 9 : 1;
-        for (int tap = 0; tap < ntap; ++tap) {
-            const bool more = (c + 1 < nchunks);
-            if (more) {
-                const f32x4* g = chunk_ptr(c + 1);
+    // A-fragment addresses: lane base + immediates (tap and q are compile-time everywhere)
+    const f32x4* a_lane = sA + ((2 * wm + my) * PW + mx) * PSTR + h;
+    const f32x4* r_lane = sA + (2 * wm + my) * PW + mx;          // 4-channel frame: one float4 per pixel
+    auto a_wide = [&](int tap, int q) -> f32x4 {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        return a_lane[(dy * PW + dx) * PSTR + 2 * q];
+    };
+    auto a_rgb = [&](int q) -> f32x4 {
+        const int tp0 = 2 * q, tp1 = (2 * q + 1 > 8) ? 8 : 2 * q + 1;
+        const int o0 = (tp0 / 3) * PW + tp0 % 3, o1 = (tp1 / 3) * PW + tp1 % 3;
+        return r_lane[h ? o1 : o0];
+    };
+
+    // ---- one chunk: NQ q-steps of buffer `cbuf`; the fragments (av,bv) of its first q-step are
+    //      live on entry, those of the NEXT chunk's first q-step on exit (when there is one).
+    //      `next` = global image of the following chunk (nullptr: none).
+    //      KIND 0: wide source, tap TAP; 1: rgb source; 2: 1x1 branch (centre tap, A scaled by ps)
+    //      NEXT_TAP: tap whose first A fragment is prefetched after the barrier (-1: sA will be
+    //      restaged first / nothing follows)
+    // Scheduling: sched_barrier(0) fences each q-step (otherwise hipcc sinks every prefetch back to
+    // its first use); inside, sched_group_barrier deals ONE non-MFMA instruction into each of the
+    // first MFMA gaps -- measured (tools/ubench/ub_kloop.hip): bunching the ds_reads / address VALU
+    // between two q-steps costs +6..12 cycles per 64-cycle MFMA for a wave alone on its SIMD.
+    int cbuf = 0;
+    f32x4 av, bv[NT];
+    auto run_chunk = [&](auto kind_c, auto nq_c, auto tap_c, auto ntap_c, float ps, const f32x4* next) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr int NQ = decltype(nq_c)::value;
+        constexpr int TAP = decltype(tap_c)::value;
+        constexpr int NEXT_TAP = decltype(ntap_c)::value;
+        const f32x4* bb = sB + cbuf * CH4 + bofs;
+        const f32x4* bn_base = sB + (cbuf ^ 1) * CH4 + bofs;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < BPT; ++i) breg[i] = g[t + 256 * i];
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 an = av, bn[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bn[j] = bv[j];
+            if (q == NQ - 1) __syncthreads();   // after this chunk's last LDS read, before the next buffer's first
+            if (q == 0 && next) load_b(next);
+            if (q < NQ - 1) {
+                an = (KIND == 1) ? a_rgb(q + 1) : a_wide(TAP, q + 1);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bn[j] = bb[((q + 1) * NTB + j) * 64];
+            } else if (next) {
+                if (NEXT_TAP >= 0) an = a_wide(NEXT_TAP, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bn[j] = bn_base[j * 64];
             }
-            const f32x4* bb = sB + (c & 1) * CH4 + (wn * NT) * 64 + lane;
-            if (wide) {
-                const int dy = tap / 3, dx = tap - dy * 3;
-                const int apix = (2 * wm + my + dy) * PW + mx + dx;
-                const int sw = (mx + dx) & 15;
-                // fragments of q-step q+1 are read while the MFMAs of q-step q issue
-                f32x4 av = sA[apix * 16 + (h ^ sw)];
-                f32x4 bv[NT];
+            f32x4 ax = av;
+            if (KIND == 2) ax *= ps;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bv[j] = bb[j * 64];
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    f32x4 an = av;
-                    f32x4 bn[NT];
+                for (int j = 0; j < NT; ++j) acc[j] = mfma32(ax[kk], bv[j][kk], acc[j]);
+            if (q == NQ - 2 && next) store_b(cbuf ^ 1);
+            // interleave: MFMA, ds_read, MFMA, ds_read, ... then the rest
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bn[j] = bv[j];
-                    if (q < 7) {
-                        an = sA[apix * 16 + ((2 * (q + 1) + h) ^ sw)];
+            for (int g = 0; g < 1 + NT; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            }
+            if (q == 0) {
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) bn[j] = bb[((q + 1) * NTB + j) * 64];
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[j] = mfma32(av[kk], bv[j][kk], acc[j]);
-                    av = an;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bv[j] = bn[j];
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    const int tp0 = 2 * q, tp1 = (2 * q + 1 > 8) ? 8 : 2 * q + 1;
-                    const int tp = h ? tp1 : tp0;
-                    const int dy = tp / 3, dx = tp - dy * 3;
-                    const f32x4 av = sA[(2 * wm + my + dy) * PW + mx + dx];
-                    f32x4 bv[NT];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bv[j] = bb[(q * NTB + j) * 64];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[j] = mfma32(av[kk], bv[j][kk], acc[j]);
+                for (int g = 0; g < BPT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
                 }
             }
-            if (more) {
-                f32x4* d = sB + ((c + 1) & 1) * CH4;
+            if (q == NQ - 2) {
 #pragma unroll
-                for (int i = 0; i < BPT; ++i) d[t + 256 * i] = breg[i];
+                for (int g = 0; g < BPT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            av = an;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = bn[j];
+        }
+        cbuf ^= 1;
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using Q8 = std::integral_constant<int, 8>;
+    using Q5 = std::integral_constant<int, 5>;
+    // (tap constants are T<n>)
+
+    // ---- prologue: halo tile of source 0, weight chunk 0 and the epilogue operands are requested
+    //      back to back (one memory latency instead of three), then written to LDS in that order
+    const bool rgb0 = (a.src_c[0] != 64);
+    if (rgb0) stage_rgb(a.src[0]);
+    else stage_wide_load(a.src[0]);
+    load_b(reinterpret_cast<const f32x4*>(a.wsrc[0] + yoff));
+    prefetch_epilogue_operands();
+    if (!rgb0) stage_wide_store();
+    store_b(0);
+
+    // ---- sources (only source 0 may be the 4-channel frame); chunk images are 9 (wide) or 1 (rgb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < a.nsrc) {
+            const bool is_rgb = (s == 0) && rgb0;
+            const f32x4* wb = reinterpret_cast<const f32x4*>(a.wsrc[s] + yoff);
+            const f32x4* after = nullptr;      // first chunk after this source
+            if (s + 1 < a.nsrc) after = reinterpret_cast<const f32x4*>(a.wsrc[s + 1 < 4 ? s + 1 : 3] + yoff);
+            else if (a.wpar) after = reinterpret_cast<const f32x4*>(a.wpar + yoff);
+            // sA is free here: every wave passed the last chunk's barrier after its final A read
+            if (s > 0) {
+                __builtin_amdgcn_s_setprio(3);
+                stage_wide_load(a.src[s]);
+                stage_wide_store();
             }
             __syncthreads();
-            ++c;
+            __builtin_amdgcn_s_setprio(0);
+            if (a.dbg && s == 0) dbg_t1 = __builtin_amdgcn_s_memtime();
+            av = is_rgb ? a_rgb(0) : a_wide(0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = sB[cbuf * CH4 + bofs + j * 64];
+            if (is_rgb) {
+                run_chunk(K1{}, Q5{}, T<0>{}, T<-1>{}, 1.f, after);
+            } else {
+                const bool par_next = (s + 1 >= a.nsrc) && a.wpar;
+                run_chunk(K0{}, Q8{}, T<0>{}, T<1>{}, 1.f, wb + 1L * CH4);
+                run_chunk(K0{}, Q8{}, T<1>{}, T<2>{}, 1.f, wb + 2L * CH4);
+                run_chunk(K0{}, Q8{}, T<2>{}, T<3>{}, 1.f, wb + 3L * CH4);
+                run_chunk(K0{}, Q8{}, T<3>{}, T<4>{}, 1.f, wb + 4L * CH4);
+                run_chunk(K0{}, Q8{}, T<4>{}, T<5>{}, 1.f, wb + 5L * CH4);
+                run_chunk(K0{}, Q8{}, T<5>{}, T<6>{}, 1.f, wb + 6L * CH4);
+                run_chunk(K0{}, Q8{}, T<6>{}, T<7>{}, 1.f, wb + 7L * CH4);
+                run_chunk(K0{}, Q8{}, T<7>{}, T<8>{}, 1.f, wb + 8L * CH4);
+                if (par_next) run_chunk(K0{}, Q8{}, T<8>{}, T<4>{}, 1.f, after);
+                else run_chunk(K0{}, Q8{}, T<8>{}, T<-1>{}, 1.f, after);
+            }
         }
     }
 
+    // ---- (conv + bias) * gamma, then the fused 1x1 partition branches as a K extension
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
-
-    // ---- fused 1x1 partition branches: K-extension with A scaled by par_j(pixel)
     if (a.wpar) {
-        const int apix = (2 * wm + my + 1) * PW + mx + 1;
-        const int sw = (mx + 1) & 15;
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            const bool more = (c + 1 < nchunks);
-            if (more) {
-                const f32x4* g = chunk_ptr(c + 1);
-#pragma unroll
-                for (int i = 0; i < BPT; ++i) breg[i] = g[t + 256 * i];
-            }
-            const f32x4* bb = sB + (c & 1) * CH4 + (wn * NT) * 64 + lane;
-            const float ps = pv[jj];
-            f32x4 av = sA[apix * 16 + (h ^ sw)];
-            f32x4 bv[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = bb[j * 64];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f32x4 an = av;
-                f32x4 bn[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bn[j] = bv[j];
-                if (q < 7) {
-                    an = sA[apix * 16 + ((2 * (q + 1) + h) ^ sw)];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bn[j] = bb[((q + 1) * NTB + j) * 64];
-                }
-                av *= ps;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[j] = mfma32(av[kk], bv[j][kk], acc[j]);
-                av = an;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bv[j] = bn[j];
-            }
-            if (more) {
-                f32x4* d = sB + ((c + 1) & 1) * CH4;
-#pragma unroll
-                for (int i = 0; i < BPT; ++i) d[t + 256 * i] = breg[i];
-            }
-            __syncthreads();
-            ++c;
-        }
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpar + yoff);
+        run_chunk(K2{}, Q8{}, T<4>{}, T<4>{}, pv[0], wp + 1L * CH4);
+        run_chunk(K2{}, Q8{}, T<4>{}, T<4>{}, pv[1], wp + 2L * CH4);
+        run_chunk(K2{}, Q8{}, T<4>{}, T<-1>{}, pv[2], nullptr);
     }
-    (void)nmain;
+    if (a.dbg) dbg_t2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_setprio(3);
 
-    // ---- epilogue: activation, residual, store.  Accumulator register r of lane (n0,h)
-    //      is pixel m = (r&3) + 8*(r>>2) + 4*h of the wave's M tile, channel n0 of N tile j.
+    // ---- epilogue.  Accumulator register r of lane (n0,h) is pixel m = (r&3) + 8*(r>>2) + 4*h of the
+    //      wave's M tile, channel n0 of N tile j.
+    if (rowwise) {
+        // transpose through the wave's private 32 px x (NT*32) ch slice of the (now free) A region:
+        // every wave passed the last chunk's barrier after its final read of sA
+        float* sT = reinterpret_cast<float*>(sA) + wave * (32 * NT * 32);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = (wn * NT + j) * 32 + n0;
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int gy = ty0 + 2 * wm + (mm >> 4), gx = tx0 + (mm & 15);
-            if (gy >= H || gx >= W) continue;
-            float v = acc[j][r];
-            if (a.act == 1) v = fmaxf(v, 0.f);
-            else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
-            if (a.out_mode == 0) {
-                a.out[((long)gy * W + gx) * 64 + co] = v + res[j][r];
-            } else if (a.out_mode == 1) {
-                const int oy = 2 * gy + (yimg >> 1), ox = 2 * gx + (yimg & 1);
-                a.out[((long)oy * (2 * W) + ox) * 64 + co] = v;
-            } else if (co < 3) {
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[j][r];
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
+                sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (NT * 32) + j * 32 + n0] = v;
+            }
+        asm volatile("" ::: "memory");      // keep the row reads below behind the column writes above
+        const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            const int p = ep + i * PPI;
+            const int gy = ty0 + 2 * wm + (p >> 4), gx = tx0 + (p & 15);
+            const f32x4 v = sT4[p * CW + ec] + res4[i];
+            if (gy < H && gx < W) {
+                long o;
+                if (a.out_mode == 0) o = ((long)gy * W + gx) * 64;
+                else o = ((long)(2 * gy + (yimg >> 1)) * (2 * W) + 2 * gx + (yimg & 1)) * 64;
+                *reinterpret_cast<f32x4*>(a.out + o + wn * NT * 32 + ec * 4) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = (wn * NT + j) * 32 + n0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gy = ty0 + 2 * wm + (mm >> 4), gx = tx0 + (mm & 15);
+                if (gy >= H || gx >= W || co >= 3) continue;
+                float v = acc[j][r];
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
                 float base;
                 if (a.out_mode == 2) {
                     base = a.lr[co * a.lr_plane + (long)gy * W + gx];
@@ -324,6 +402,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
                 a.out[(long)co * H * W + (long)gy * W + gx] = v + base;
             }
         }
+    }
+    if (a.dbg) dbg_e1 = __builtin_amdgcn_s_memtime();
+    if (a.dbg && t == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* d = a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
+        d[0] = dbg_t0;
+        d[1] = dbg_t1;
+        d[2] = dbg_t2;
+        d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));     // HW_REG_HW_ID
+        d[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));    // HW_REG_XCC_ID
+        d[6] = __builtin_amdgcn_s_memrealtime();
+        d[7] = tile;
+        d[11] = dbg_e1;
+        d[12] = dbg_r0;
     }
 }
 
@@ -348,14 +441,17 @@ int launch_cfg(const ConvArgs& a, int grid_y, hipStream_t stream) {
 int conv_pick_cfg(int H, int W) {
     // 8x16 tiles need >= 2 blocks per CU (512 tiles) to fill the chip; below that use 4x16 tiles.
     const long tiles_big = (long)((W + 15) / 16) * ((H + 7) / 8);
+    if (getenv("PNP_FORCE_BIG")) return CONV_CFG_BIG;
     return tiles_big >= 1024 ? CONV_CFG_BIG : CONV_CFG_SMALL;
 }
 
 int launch_conv3x3(const ConvArgs& a, int cfg, int grid_y, hipStream_t stream) {
     if (a.nsrc < 1 || a.nsrc > 4) return PNP_ERR_BAD_ARG;
     if (a.wpar && (a.nsrc != 1 || a.src_c[0] != 64 || !a.par)) return PNP_ERR_BAD_ARG;
-    for (int s = 0; s < a.nsrc; ++s)
+    for (int s = 0; s < a.nsrc; ++s) {
         if (a.src_c[s] != 64 && a.src_c[s] != 4) return PNP_ERR_BAD_ARG;
+        if (s > 0 && a.src_c[s] != 64) return PNP_ERR_BAD_ARG;   // the RGB frame may only be source 0
+    }
     switch (cfg) {
         case CONV_CFG_BIG: return launch_cfg<4, 1, 2, 2>(a, grid_y, stream);
         case CONV_CFG_SMALL: return launch_cfg<2, 2, 1, 2>(a, grid_y, stream);

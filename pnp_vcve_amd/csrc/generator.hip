@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/pnpvcve.h"
 #include "conv_mfma.h"
@@ -746,6 +747,11 @@ int pnp_pack_conv1x1_f32(const float* w, float* dst, void* st) {
     return launch_pack_weights(plain_pack(w, 64, 1, PACK_1X1, 0, 2, 64, dst), 1, (hipStream_t)st);
 }
 
+// Diagnostic only (not part of include/pnpvcve.h): per-block shader-clock timeline of the next
+// pnp_conv3x3_f32 launches, 8 u64 per block.  Used by tools/trace_conv.py.
+static unsigned long long* g_conv_dbg = nullptr;
+void pnp_debug_set_conv_trace(void* buf) { g_conv_dbg = (unsigned long long*)buf; }
+
 int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w,
                     const float* bias, const float* gamma, const float* packed_w1x1, const float* par,
                     const float* residual, int act, float* out, int h, int w, void* st) {
@@ -769,6 +775,7 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels,
     a.W = w;
     a.act = act;
     a.out_mode = 0;
+    a.dbg = g_conv_dbg;
     return launch_conv3x3(a, conv_pick_cfg(h, w), 1, (hipStream_t)st);
 }
 
