@@ -1,0 +1,64 @@
+"""Clip sharding and metric collection across the GPUs of a node (replicas only).
+
+The model never exchanges tensors between GPUs; frames of a clip are strictly sequential, clips
+are independent.  What crosses xGMI is one fixed-shape fp64 all-gather of per-clip metrics:
+
+  * sharding rule = the reference's DistributedSampler with shuffle=False
+    (mmedit/datasets/samplers/distributed_sampler.py:45-70): pad the index list by wrapping to a
+    multiple of the world size, rank r takes indices[r::world]; a dataset smaller than the world
+    size raises ValueError;
+  * collection = the reference's collect_results_gpu ordering (mmedit/apis/test.py:226-233):
+    interleave the per-rank parts with zip(*parts), then truncate the padding -- but as ONE
+    all_gather of a [clips_per_rank, K] float64 tensor instead of pickles over two collectives.
+
+Backend-agnostic: 'nccl' (= RCCL on ROCm) on GPUs, 'gloo' in the CPU tests.
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_dist(launcher='pytorch', backend='nccl', **kwargs):
+    """mmcv.runner.init_dist('pytorch', backend=...) as used by tools/test.py:85: env:// rendezvous
+    from the launcher's RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*."""
+    if launcher != 'pytorch':
+        raise ValueError(f'Invalid launcher type: {launcher} (only "pytorch" is built)')
+    rank = int(os.environ['RANK'])
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank % max(torch.cuda.device_count(), 1))))
+    dist.init_process_group(backend=backend, **kwargs)
+
+
+def shard_indices(n, rank, world, samples_per_gpu=1):
+    if n < world * samples_per_gpu:
+        raise ValueError('You may use too small dataset and our distributed sampler cannot pad your dataset '
+                         'correctly. We highly recommend you to use fewer GPUs to finish your work')
+    per = int(math.ceil(n * 1.0 / world / samples_per_gpu)) * samples_per_gpu
+    total = per * world
+    idx = list(range(n))
+    idx += idx[:total - n]
+    out = idx[rank:total:world]
+    assert len(out) == per
+    return out
+
+
+def gather_clip_metrics(local, n_total, device=None):
+    """local: list (this rank's clips, in shard order) of K-float lists.  Returns, on every rank,
+    the [n_total, K] float64 tensor in dataset order."""
+    rank, world = get_dist_info()
+    t = torch.tensor(local, dtype=torch.float64, device=device).reshape(len(local), -1)
+    if world == 1:
+        return t[:n_total].cpu()
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)                       # the only data-path-adjacent collective
+    stacked = torch.stack(parts, dim=1)             # [per, world, K]: zip(*parts) order
+    return stacked.reshape(-1, t.shape[1])[:n_total].cpu()

@@ -1,0 +1,131 @@
+"""`BasicVSR` -- the model wrapper the reference's configs name (model.type).
+
+Reproduces the test-time surface of mmedit/models/restorers/basicvsr.py:33-233 and
+basic_restorer.py:49-98: constructor keys, forward(test_mode=True, **data) plumbing of the
+side-information tensors into generator(lq, QPs, slices, mvs, base_QPs, partitions), per-frame
+PSNR/SSIM on uint8-rounded BGR frames averaged over the clip, optional PNG dump.
+Training (forward_train / train_step) is out of scope for this build and raises.
+"""
+import os.path as osp
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .metrics import ALLOWED_METRICS, tensor2img
+from .registry import LOSSES, MODELS, build_backbone, build_loss
+
+
+@LOSSES.register_module()
+class CharbonnierLoss(nn.Module):
+    """mmedit/models/losses/pixelwise_loss.py:139-184 -- accepted so that configs build; only
+    used by training, which this build does not provide."""
+
+    def __init__(self, loss_weight=1.0, reduction='mean', sample_wise=False, eps=1e-12):
+        super().__init__()
+        self.loss_weight, self.reduction, self.sample_wise, self.eps = loss_weight, reduction, sample_wise, eps
+
+    def forward(self, pred, target, weight=None, **kwargs):
+        loss = torch.sqrt((pred - target) ** 2 + self.eps)
+        if weight is not None:
+            loss = loss * weight
+        loss = loss.mean() if self.reduction == 'mean' else (loss.sum() if self.reduction == 'sum' else loss)
+        return self.loss_weight * loss
+
+
+@MODELS.register_module()
+class BasicVSR(nn.Module):
+    allowed_metrics = ALLOWED_METRICS
+
+    def __init__(self, generator, pixel_loss=None, ensemble=None, train_cfg=None, test_cfg=None, psnr_only=False,
+                 pretrained=None):
+        super().__init__()
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.psnr_only = psnr_only
+        self.generator = build_backbone(generator)
+        self.pixel_loss = build_loss(pixel_loss) if pixel_loss else None
+        if ensemble is not None:
+            raise NotImplementedError('spatial-temporal ensemble is not part of the hot path')
+        self.forward_ensemble = None
+        self.fix_iter = train_cfg.get('fix_iter', 0) if train_cfg else 0
+        self.is_weight_fixed = False
+        self.register_buffer('step_counter', torch.zeros(1))          # basicvsr.py:50
+        self.last_forward_seconds = None
+        if pretrained is not None:
+            self.generator.init_weights(pretrained)
+
+    def check_if_mirror_extended(self, lrs):
+        """basicvsr.py:52-68."""
+        is_mirror_extended = False
+        if lrs.size(1) % 2 == 0:
+            lrs_1, lrs_2 = torch.chunk(lrs, 2, dim=1)
+            if torch.norm(lrs_1 - lrs_2.flip(1)) == 0:
+                is_mirror_extended = True
+        return is_mirror_extended
+
+    def forward(self, lq, gt=None, QPs=None, slices=None, mvs=None, base_QPs=None, partitions=None, test_mode=False,
+                **kwargs):
+        """basic_restorer.py:64-98."""
+        if test_mode:
+            return self.forward_test(lq, gt, QPs, slices, mvs, base_QPs, partitions, **kwargs)
+        raise NotImplementedError('training is out of scope of the MI355X hot-path build')
+
+    def evaluate(self, output, gt):
+        """basicvsr.py:119-153."""
+        crop_border = self.test_cfg['crop_border']
+        convert_to = self.test_cfg.get('convert_to', None)
+        eval_result = dict()
+        for metric in self.test_cfg['metrics']:
+            if output.ndim == 5:
+                avg = []
+                for i in range(output.size(1)):
+                    avg.append(self.allowed_metrics[metric](tensor2img(output[:, i]), tensor2img(gt[:, i]), crop_border,
+                                                            convert_to=convert_to))
+                eval_result[metric] = np.mean(avg)
+            else:
+                eval_result[metric] = self.allowed_metrics[metric](tensor2img(output), tensor2img(gt), crop_border,
+                                                                   convert_to=convert_to)
+        return eval_result
+
+    def forward_test(self, lq, gt=None, QPs=None, slices=None, mvs=None, base_QPs=None, par_map=None, meta=None,
+                     save_image=False, save_path=None, iteration=None):
+        """basicvsr.py:155-233."""
+        if not self.psnr_only:
+            with torch.no_grad():
+                torch.cuda.synchronize()
+                begin = time.time()
+                output = self.generator(lq, QPs, slices, mvs, base_QPs, par_map)
+                torch.cuda.synchronize()
+                self.last_forward_seconds = time.time() - begin
+        else:
+            output = lq
+        if gt is not None and gt.ndim == 4:
+            t = output.size(1)
+            if self.check_if_mirror_extended(lq):
+                output = 0.5 * (output[:, t // 4] + output[:, -1 - t // 4])
+            else:
+                output = output[:, t // 2]
+        if self.test_cfg is not None and self.test_cfg.get('metrics', None):
+            assert gt is not None, 'evaluation with metrics must have gt images.'
+            results = dict(eval_result=self.evaluate(output, gt))
+        else:
+            results = dict(lq=lq.cpu(), output=output.cpu())
+            if gt is not None:
+                results['gt'] = gt.cpu()
+        if save_image:
+            from PIL import Image
+            import os
+            if output.ndim == 5:
+                folder_name = meta[0]['key'].split('/')[0]
+                for i in range(output.size(1)):
+                    name = f'{i:08d}.png' if iteration is None else f'{i:08d}-{iteration + 1:06d}.png'
+                    p = osp.join(save_path, folder_name, name)
+                    os.makedirs(osp.dirname(p), exist_ok=True)
+                    Image.fromarray(tensor2img(output[:, i])[..., ::-1]).save(p)
+            else:
+                img_name = meta[0]['key'].replace('/', '_')
+                p = osp.join(save_path, f'{img_name}.png' if iteration is None else f'{img_name}-{iteration + 1:06d}.png')
+                os.makedirs(osp.dirname(p), exist_ok=True)
+                Image.fromarray(tensor2img(output)[..., ::-1]).save(p)
+        return results

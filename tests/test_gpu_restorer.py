@@ -1,0 +1,54 @@
+"""GPU: the BasicVSR wrapper and the test driver, driven by the config keys of the reference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_basicvsr_forward_test_matches_oracle_metrics():
+    import pnp_vcve_amd  # noqa: F401
+    from pnp_vcve_amd import restorer, synthetic as syn  # noqa: F401
+    from pnp_vcve_amd.config import Config
+    from pnp_vcve_amd.registry import build_model
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128.py'))
+    model = build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    gcfg = dict(syn.DEFAULT_GENERATOR_CFG)
+    sd_np = syn.make_state_dict(gcfg, seed=9, par_gain=10.0)
+    model.generator.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    model = model.cuda().eval()
+    clip = syn.make_clip(seed=91, n=1, t=4, h=64, w=80)
+    data = {k: torch.from_numpy(v).cuda() for k, v in clip.items()}
+    res = model(test_mode=True, lq=data['lq'], gt=data['gt'], QPs=data['QPs'], slices=data['slices'], mvs=data['mvs'],
+                base_QPs=data['base_QPs'], partitions=data['partitions'])
+    assert set(res['eval_result']) == {'PSNR', 'SSIM'}
+    c = {k: torch.from_numpy(v) for k, v in clip.items()}
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), gcfg, c['lq'], c['QPs'], c['slices'], c['mvs'],
+                                        c['base_QPs'], c['partitions'])
+    assert abs(res['eval_result']['PSNR'] - cpu_ref.clip_psnr(ref, c['gt'])) < 0.01
+    # without metrics the wrapper returns CPU tensors (basicvsr.py:199-202)
+    model.test_cfg = None
+    res = model(test_mode=True, lq=data['lq'], gt=data['gt'], QPs=data['QPs'], slices=data['slices'], mvs=data['mvs'],
+                base_QPs=data['base_QPs'], partitions=data['partitions'])
+    assert not res['output'].is_cuda and float((res['output'] - ref).abs().max()) < 1e-4
+    with pytest.raises(NotImplementedError):
+        model(lq=data['lq'], gt=data['gt'])          # training path is out of scope
+
+
+def test_test_driver_cli(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'),
+                          os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128.py'), 'none',
+                          '--cfg-options', 'data.test.num_clips=2', 'data.test.num_input_frames=3',
+                          'data.test.height=64', 'data.test.width=64', '--save-path', str(tmp_path)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'Eval-PSNR' in out.stdout and 'Eval-SSIM' in out.stdout
+    assert os.path.exists(os.path.join(str(tmp_path), '000', '00000000.png'))

@@ -1,0 +1,142 @@
+"""CPU tests of the host-side boundary: config loader, registry, metrics, checkpoint schema,
+clip sharding and the world_size-2 metric all-gather (gloo)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_configs_carry_the_reference_keys():
+    from pnp_vcve_amd.config import Config
+    from pnp_vcve_amd import synthetic as syn
+    for name in ('HR_davis_LR_128x128.py', 'HR_davis_LR_128x128_IPB.py', 'HR_davis_LR_128x128_IPB_LR_test.py'):
+        cfg = Config.fromfile(os.path.join(ROOT, 'configs', name))
+        assert cfg.model.type == 'BasicVSR'
+        g = dict(cfg.model.generator)
+        assert g.pop('type') == 'IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par'
+        assert g == syn.DEFAULT_GENERATOR_CFG                 # kwargs of configs/HR_davis_LR_128x128.py:8-24
+        assert cfg.test_cfg.metrics == ['PSNR', 'SSIM'] and cfg.test_cfg.crop_border == 0
+        assert cfg.dist_params.backend == 'nccl'
+        assert cfg.data.test_dataloader.samples_per_gpu == 1
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128_IPB_LR_test.py'))
+    assert (cfg.data.test.height, cfg.data.test.width, cfg.data.test.qp_mode) == (180, 320, 'ipb')   # _base_ chain
+    cfg.merge_from_dict({'model.generator.vsr': True, 'data.test.num_clips': 2})
+    assert cfg.model.generator.vsr is True and cfg.data.test.num_clips == 2 and cfg.model.generator.num_blocks == 8
+
+
+def test_registry_builds_model_from_config():
+    import pnp_vcve_amd  # noqa: F401
+    from pnp_vcve_amd import restorer  # noqa: F401
+    from pnp_vcve_amd.config import Config
+    from pnp_vcve_amd.registry import MODELS, build_model
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128.py'))
+    m = build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    assert type(m).__name__ == 'BasicVSR'
+    assert 'step_counter' in m.state_dict()                  # basicvsr.py:50
+    assert any(k.startswith('generator.forward_resblocks.main.7.conv2.weight') for k in m.state_dict())
+    with pytest.raises(KeyError):
+        build_model(dict(type='NoSuchModel'))
+    assert 'CharbonnierLoss' in MODELS
+
+
+def test_checkpoint_round_trip_with_reference_prefixes(tmp_path):
+    import pnp_vcve_amd  # noqa: F401
+    from pnp_vcve_amd import restorer  # noqa: F401
+    from pnp_vcve_amd import synthetic as syn
+    from pnp_vcve_amd.checkpoint import load_checkpoint
+    from pnp_vcve_amd.registry import build_backbone
+    cfg = dict(syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    sd = {('generator.' + k): torch.from_numpy(v) for k, v in syn.make_state_dict(cfg, seed=3).items()}
+    sd['step_counter'] = torch.zeros(1)
+    f = str(tmp_path / 'ckpt.pth')
+    torch.save({'meta': {}, 'state_dict': {('module.' + k): v for k, v in sd.items()}}, f)
+    g = build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+    g.init_weights(pretrained=f, strict=True)
+    assert torch.equal(g.state_dict()['conv_last.weight'], sd['generator.conv_last.weight'])
+    with pytest.raises(TypeError):
+        g.init_weights(pretrained=123)
+    load_checkpoint(g, f, strict=False)
+
+
+def test_psnr_ssim_definitions():
+    from pnp_vcve_amd.metrics import psnr, ssim, tensor2img
+    from oracle import cpu_ref
+    a = torch.rand(1, 3, 40, 48)
+    b = (a + 0.03 * torch.randn_like(a)).clamp(0, 1)
+    ia, ib = tensor2img(a), tensor2img(b)
+    assert ia.dtype == np.uint8 and ia.shape == (40, 48, 3)
+    assert np.array_equal(ia, cpu_ref.tensor2img_uint8(a[0]))
+    assert abs(psnr(ia, ib) - cpu_ref.psnr_uint8(ia, ib)) < 1e-9
+    assert psnr(ia, ia) == float('inf')
+    s = ssim(ia, ib)
+    assert 0.5 < s < 1.0 and abs(ssim(ia, ia) - 1.0) < 1e-12
+    # brute-force check of the 'valid' Gaussian window on one channel
+    x, y = ia[..., 0].astype(np.float64), ib[..., 0].astype(np.float64)
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    g /= g.sum()
+    win = np.outer(g, g)
+    mu = sum(win[i, j] * x[i:i + 30, j:j + 38] for i in range(11) for j in range(11))
+    from pnp_vcve_amd.metrics import _gauss_valid
+    assert np.abs(_gauss_valid(x, g) - mu).max() < 1e-9
+
+
+def test_sharding_rule_matches_reference_sampler():
+    from pnp_vcve_amd.dist import shard_indices
+    # reference: indices += indices[:total-n]; indices[rank::world]  (distributed_sampler.py:62-70)
+    for n, world in ((8, 8), (10, 4), (4, 3), (100, 8)):
+        per = -(-n // world)
+        idx = list(range(n))
+        idx += idx[:per * world - n]
+        for r in range(world):
+            assert shard_indices(n, r, world) == idx[r::world]
+    with pytest.raises(ValueError):
+        shard_indices(4, 0, 8)                               # distributed_sampler.py:45-49
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from pnp_vcve_amd.apis import multi_gpu_test
+    from pnp_vcve_amd.datasets import SyntheticCompressedClipDataset
+    dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+
+    class Fake(torch.nn.Module):            # stands in for BasicVSR: the GPU path is covered by -m gpu tests
+        last_forward_seconds = 0.5
+        def forward(self, test_mode=False, lq=None, meta=None, **kw):
+            clip = int(meta[0]['key'].split('/')[0])
+            return dict(eval_result={'PSNR': 30.0 + clip, 'SSIM': 0.9 + clip / 1000.0})
+
+    ds = SyntheticCompressedClipDataset(num_clips=5, num_input_frames=2, height=64, width=64)
+    out = multi_gpu_test(Fake(), ds, device='cpu')
+    assert len(out) == 5
+    for i, o in enumerate(out):
+        assert abs(o['eval_result']['PSNR'] - (30.0 + i)) < 1e-12, (i, o)
+        assert abs(o['frames_per_s'] - 4.0) < 1e-12
+    stats = ds.evaluate(out)
+    assert abs(stats['PSNR'] - 32.0) < 1e-12
+    dist.barrier()
+    print('rank', dist.get_rank(), 'ok')
+''')
+
+
+def test_two_rank_clip_sharding_and_metric_all_gather_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    port = 29600 + os.getpid() % 300
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert 'ok' in o

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Evaluation driver with the reference's CLI (tools/test.py:18-61 of ZeldaM1/PnP-VCVE):
+    python tools/test.py CONFIG CHECKPOINT [--launcher pytorch] [--save-path DIR] [--cfg-options k=v ...]
+CHECKPOINT may be 'none' (seeded random weights: released checkpoints are not available offline)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import pnp_vcve_amd  # noqa: E402,F401
+from pnp_vcve_amd import restorer  # noqa: E402,F401
+from pnp_vcve_amd.apis import multi_gpu_test  # noqa: E402
+from pnp_vcve_amd.checkpoint import load_checkpoint  # noqa: E402
+from pnp_vcve_amd.config import Config, parse_cfg_options  # noqa: E402
+from pnp_vcve_amd.datasets import build_dataset  # noqa: E402
+from pnp_vcve_amd.dist import get_dist_info, init_dist  # noqa: E402
+from pnp_vcve_amd.registry import build_model  # noqa: E402
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description='PnP-VCVE hot-path tester (MI355X)')
+    p.add_argument('config')
+    p.add_argument('checkpoint')
+    p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--deterministic', action='store_true')
+    p.add_argument('--out')
+    p.add_argument('--gpu-collect', action='store_true', help='accepted for CLI parity; collection is always on-GPU')
+    p.add_argument('--testdir_lr', default=None)
+    p.add_argument('--testdir_gt', default=None)
+    p.add_argument('--save-path', default=None, type=str)
+    p.add_argument('--tmpdir')
+    p.add_argument('--cfg-options', nargs='+', default=None)
+    p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    p.add_argument('--local_rank', type=int, default=0)
+    a = p.parse_args()
+    if 'LOCAL_RANK' not in os.environ:
+        os.environ['LOCAL_RANK'] = str(a.local_rank)
+    return a
+
+
+def main():
+    args = parse_args()
+    cfg = Config.fromfile(args.config)
+    if args.cfg_options:
+        cfg.merge_from_dict(parse_cfg_options(args.cfg_options))
+    if args.launcher != 'none':
+        init_dist(args.launcher, **cfg.dist_params)
+    rank, world = get_dist_info()
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+    if args.testdir_lr is not None or args.testdir_gt is not None:
+        raise SystemExit('the on-disk REDS loader is outside this build (SURVEY.md section 8f-1); '
+                         'use the synthetic dataset of the config')
+    dataset = build_dataset(cfg.data.test)
+    model = build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    if args.checkpoint.lower() != 'none':
+        load_checkpoint(model, args.checkpoint, map_location='cpu')
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    model = model.to(dev)          # no DDP wrap: inference replicas share nothing
+    outputs = multi_gpu_test(model, dataset, save_image=args.save_path is not None, save_path=args.save_path,
+                             device=dev, metrics=tuple(cfg.test_cfg['metrics']))
+    if rank == 0:
+        stats = dataset.evaluate(outputs)
+        for k, v in stats.items():
+            print(f'Eval-{k}: {v}')
+        print('{:.4f}/{:.4f}'.format(float(stats.get('PSNR', float('nan'))), float(stats.get('SSIM', float('nan')))))
+        fps = [o['frames_per_s'] for o in outputs]
+        print(f'clips {len(outputs)}  world {world}  mean frames/s per clip {sum(fps) / len(fps):.2f}')
+        if args.out:
+            torch.save(outputs, args.out)
+
+
+if __name__ == '__main__':
+    main()
