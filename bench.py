@@ -26,6 +26,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s achievable)
 
 
+def committed_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json, written by
+    tools/profile_gpu.sh for this same command at 720p): (2 x FETCH_SIZE + WRITE_SIZE) KiB, the gfx950
+    correction of MI355X_MICROARCH.md.  None when no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+    if not files:
+        return {}, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], ROOT)
+
+
 def make_inputs(seed, t, h, w, dev):
     from pnp_vcve_amd import synthetic as syn
     clip = syn.make_clip(seed=seed, n=1, t=t, h=h, w=w, slices='IBBBP', qp_mode='qp', crf=25,
@@ -159,6 +171,7 @@ def main():
             'psnr_per_rank': [float(x) for x in allm[:, 0]],
             'frames_per_s_per_rank': [float(x) for x in allm[:, 1]],
         }
+        pmc, pmc_src = committed_pmc_traffic() if args.workload == '720p' else ({}, None)
         if prof is not None:
             cb = prof['conv_block']
             ci = prof['conv_input']
@@ -169,7 +182,9 @@ def main():
             ach = cb['work'] / (cb['ms'] * 1e-3) / 1e12 if cb['ms'] > 0 else 0.0
             res['roofline'] = {'kernel': 'conv3x3_mfma_kernel (64->64 BAE block convs, fp32 MFMA 32x32x2)',
                                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                               'traffic': pmc.get('conv3x3_mfma_kernel<4,1,2,2>', {}).get('hbm_bytes_per_launch'),
+                               'traffic_source': pmc_src,
                                'launches': cb['launches'], 'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
                                'all_convs_TFLOPs': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                                'device_ms_per_step': {'conv_block': cb['ms'] / args.steps, 'conv_input': ci['ms'] / args.steps,
@@ -178,7 +193,9 @@ def main():
                 gbs = wp['work'] / (wp['ms'] * 1e-3) / 1e9
                 res['roofline_mv_warp'] = {'kernel': 'mv_warp_nhwc_kernel (MV-guided bilinear alignment)', 'bound': 'hbm',
                                            'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                           'frac': gbs / PEAK_HBM_GBS, 'traffic': None, 'launches': wp['launches'],
+                                           'frac': gbs / PEAK_HBM_GBS,
+                                           'traffic': pmc.get('mv_warp_nhwc_kernel', {}).get('hbm_bytes_per_launch'),
+                                           'traffic_source': pmc_src, 'launches': wp['launches'],
                                            'avg_launch_us': 1e3 * wp['ms'] / wp['launches'],
                                            'algorithmic_bytes_per_launch': wp['work'] / wp['launches']}
         if world == 1 and not args.no_cpu_baseline:

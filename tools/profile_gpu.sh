@@ -15,5 +15,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 benc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_lds -- python3 bench.py $ARGS > $OUT/pmc_lds.log 2>&1
 find $OUT -name '*.csv' | head -50
-python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+python3 tools/summarize_profile.py $OUT $OUT/pmc.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

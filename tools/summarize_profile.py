@@ -11,8 +11,11 @@ def short(name):
               'pack_lr_kernel', 'caa_predict_kernel', 'mix_bias_kernel'):
         if k in name:
             if k == 'conv3x3_mfma_kernel':
-                cfg = name.split('conv3x3_mfma_kernelI')[-1][:24]
-                return k + '<' + cfg.replace('Li', '').replace('E', ',').strip(',') + '>'
+                import re
+                mm = re.search(r'conv3x3_mfma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)
+                if not mm:
+                    mm = re.search(r'conv3x3_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
+                return k + ('<%s,%s,%s,%s>' % mm.groups() if mm else '')
             return k
     return name[:60]
 
@@ -50,5 +53,30 @@ def main(root):
             print(f'{k:70s} n={n:<6d} ' + ' '.join(parts))
 
 
+def pmc_json(root, out):
+    """per-kernel HBM traffic per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE reads exactly half
+    of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section); separate passes per counter."""
+    import json
+    res = {}
+    for pas, cname in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+        for f in glob.glob(os.path.join(root, pas, '**', '*counter_collection.csv'), recursive=True):
+            acc = defaultdict(lambda: [0.0, 0])
+            for r in csv.DictReader(open(f)):
+                if r['Counter_Name'] != cname:
+                    continue
+                a = acc[short(r['Kernel_Name'])]
+                a[0] += float(r['Counter_Value'])
+                a[1] += 1
+            for k, (v, n) in acc.items():
+                res.setdefault(k, {})[cname + '_KiB_per_launch'] = v / n
+                res[k]['launches'] = n
+    for k, d in res.items():
+        if 'FETCH_SIZE_KiB_per_launch' in d and 'WRITE_SIZE_KiB_per_launch' in d:
+            d['hbm_bytes_per_launch'] = (2 * d['FETCH_SIZE_KiB_per_launch'] + d['WRITE_SIZE_KiB_per_launch']) * 1024
+    json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
     main(sys.argv[1])
+    if len(sys.argv) > 2:
+        pmc_json(sys.argv[1], sys.argv[2])
