@@ -115,3 +115,37 @@ def test_720p_clip_crop_consistency_and_oracle_spot_check():
                                         t['base_QPs'], t['partitions'])
     got = run(m, oc).cpu()
     assert float((got - ref).abs().max()) < TOL
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 64, 64), (1, 2, 64, 64), (1, 3, 68, 76), (3, 2, 64, 100), (1, 9, 64, 64)],
+                         ids=lambda s: 'n%d_t%d_%dx%d' % s)
+def test_edge_shapes_vs_oracle(shape):
+    """T = 1 (no alignment at all), T = 2, ragged tiles (sizes that are multiples of 4 but not of the
+    8x16 tile), n = 3, and a 9-frame clip with two interior key frames -- against the pinned oracle."""
+    n, t, h, w = shape
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=300 + t, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=3000 + h + w, n=n, t=t, h=h, w=w, slices='IBBBP', qp_mode='qp',
+                            crf=[15, 25, 35][:n] if n > 1 else 25, block=4)
+    out = run(build(cfg, sd_np), clip).cpu()
+    c = {k: torch.from_numpy(v) for k, v in clip.items()}
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, c['lq'], c['QPs'], c['slices'], c['mvs'],
+                                        c['base_QPs'], c['partitions'])
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) < TOL
+
+
+def test_per_frame_base_qp_values_are_honoured():
+    """base_QPs is an input tensor: distinct values per frame must select distinct expert mixtures
+    (the dedup on the host is by value, not by clip)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=55, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=555, n=1, t=4, h=64, w=64)
+    clip['base_QPs'] = (np.array([15, 35, 15, 51], np.float32) / 255.0).reshape(1, 4, 1, 1, 1)
+    out = run(build(cfg, sd_np), clip).cpu()
+    c = {k: torch.from_numpy(v) for k, v in clip.items()}
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, c['lq'], c['QPs'], c['slices'], c['mvs'],
+                                        c['base_QPs'], c['partitions'])
+    assert float((out - ref).abs().max()) < TOL
