@@ -123,6 +123,13 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_chann
                     const float* packed_w1x1_dev, const float* par_dev, const float* residual_dev,
                     int act, float* out_dev, int h, int w, void* stream);
 
+/* Per-frame sum of squared differences of the uint8-rounded frames (the statistic behind
+ * psnr(tensor2img(a), tensor2img(b)), mmedit/core/misc.py:51-71 + core/evaluation/metrics.py:200-215):
+ * a, b (frames, c, h, w) fp32 in HBM -> sse_dev (frames) uint64, exact.  PSNR = 20 log10(255 / sqrt(sse / N)),
+ * N = c * (h - 2 crop) * (w - 2 crop). */
+int pnp_psnr_sse_f32(const float* a_dev, const float* b_dev, unsigned long long* sse_dev, int frames,
+                     int c, int h, int w, int crop_border, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

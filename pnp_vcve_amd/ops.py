@@ -129,3 +129,21 @@ def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, r
                                                 _ptr(keep[3]), _ptr(keep[4]), act, _ptr(out), h, w, _stream()),
                   'pnp_conv3x3_f32')
     return out
+
+
+def psnr_frames(a, b, crop_border=0):
+    """Per-frame PSNR with the reference's definition (uint8-rounded frames), computed on the GPU.
+    a, b: (..., c, h, w) with any leading dims; returns a float64 CPU tensor of the leading shape."""
+    a, b = _chk(a, 'a'), _chk(b, 'b')
+    if a.shape != b.shape:
+        raise AssertionError(f'Image shapes are different: {tuple(a.shape)}, {tuple(b.shape)}.')
+    c, h, w = a.shape[-3:]
+    frames = a.numel() // (c * h * w)
+    sse = torch.empty(frames, dtype=torch.int64, device=a.device)
+    _native.check(_native.lib().pnp_psnr_sse_f32(_ptr(a), _ptr(b), _ptr(sse), frames, c, h, w, int(crop_border),
+                                                 _stream()), 'pnp_psnr_sse_f32')
+    n = c * (h - 2 * crop_border) * (w - 2 * crop_border)
+    mse = sse.cpu().double() / n
+    out = 20.0 * torch.log10(255.0 / mse.sqrt())
+    out[mse == 0] = float('inf')
+    return out.reshape(a.shape[:-3])

@@ -214,3 +214,27 @@ def test_conv_720p_scaling_linearity_and_crop_consistency():
     # and against ATen on the host for that crop
     ref = F.conv2d(x[cy:cy + 96, cx:cx + 112].permute(2, 0, 1).unsqueeze(0).cpu(), wt.cpu(), padding=1)
     assert maxdiff(yc.permute(2, 0, 1).unsqueeze(0), ref) < TOL_CONV * 4
+
+
+@pytest.mark.parametrize('crop', [0, 3])
+def test_psnr_on_device_matches_reference_definition(crop):
+    from pnp_vcve_amd import ops
+    from pnp_vcve_amd.metrics import psnr, tensor2img
+    a = torch.rand(5, 3, 70, 90)
+    b = (a + 0.05 * torch.randn_like(a))          # exceeds [0,1] on purpose: exercises the clamp
+    b[4] = a[4]
+    got = ops.psnr_frames(a.to(dev()), b.to(dev()), crop)
+    for i in range(5):
+        ref = psnr(tensor2img(a[i]), tensor2img(b[i]), crop)
+        if ref == float('inf'):
+            assert got[i] == float('inf')
+        else:
+            assert abs(float(got[i]) - ref) < 1e-4, (i, float(got[i]), ref)
+    # 720p frames, exact integer statistic vs the host
+    x = torch.rand(2, 3, 720, 1280, device=dev())
+    y = (x + 0.02 * torch.randn_like(x)).clamp(0, 1)
+    g = ops.psnr_frames(x, y)
+    xi = (x.clamp(0, 1) * 255).round()
+    yi = (y * 255).round()
+    ref = 20 * torch.log10(255.0 / ((xi - yi).double() ** 2).mean(dim=(1, 2, 3)).sqrt())
+    assert float((g - ref.cpu()).abs().max()) < 1e-9
