@@ -130,6 +130,15 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_chann
 int pnp_psnr_sse_f32(const float* a_dev, const float* b_dev, unsigned long long* sse_dev, int frames,
                      int c, int h, int w, int crop_border, void* stream);
 
+/* MV / partition records -> dense maps: the inner loop of LoadImageFromFileList_ipb.__call__
+ * (mmedit/datasets/pipelines/loading_ipb.py:328-369) + RescaleToZeroOne(partitions) + HWC->CHW.
+ *   records_dev (R,10) fp32 rows (direction, w, h, x_w, y_w, x, y, motion_x, motion_y, scale) in file
+ *   order over the whole clip; rec_frame_dev (R) int32 frame of each row; slices_host (t) = ord('I'|'P'|'B').
+ *   mvs_dev (t,4,h,w) and par_dev (t,3,h,w) are fully written; scratch_dev = t*2*h*w int32.  t <= 256. */
+int pnp_rasterise_side_info_f32(const float* records_dev, const int* rec_frame_dev, long num_records,
+                                const float* slices_host, int t, int h, int w, float* mvs_dev, float* par_dev,
+                                int* scratch_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

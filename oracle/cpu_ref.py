@@ -336,5 +336,54 @@ def clip_psnr(output, gt, crop_border=0):
     return sum(vals) / len(vals)
 
 
+# --------------------------------------------------------------------------
+# bitstream side-info rasteriser (the step right BEFORE the hot path)
+# --------------------------------------------------------------------------
+def rasterise_side_info(records, rec_frame, slices, h, w):
+    """datasets/pipelines/loading_ipb.py:328-369 (LoadImageFromFileList_ipb.__call__ inner loop) followed
+    by RescaleToZeroOne on `partitions` (normalization.py:93-99) and FramesToTensor's HWC->CHW
+    (formating.py:124-137).
+
+    records (R,10) float32 rows (direction, w, h, x_w, y_w, x, y, motion_x, motion_y, scale) in file order,
+    rec_frame (R,) frame index of each row, slices: sequence of 'I'/'P'/'B' per frame.
+    Returns mvs (T,4,h,w) float32 [pixels] and partitions (T,3,h,w) float32 in {0, 1/255}.
+    Python slice semantics are kept as they are (a block whose start index is negative wraps around and
+    usually selects nothing; the far side is clipped)."""
+    import numpy as np
+    T = len(slices)
+    mvs, parts = [], []
+    part_ch = {256: 0, 128: 1, 64: 2}
+    p_offset = None                                  # unassigned in the reference until the first frame ends
+    records = np.asarray(records, np.float32)
+    for f in range(T):
+        is_b = (slices[f] == 'B')
+        mv = np.zeros((h, w, 4), np.float32)
+        part = np.zeros((h, w, 3), np.float32)
+        for row in records[np.asarray(rec_frame) == f]:
+            direction, bw, bh, x_w, y_w, x, y, mx, my, scale = row
+            x, y, bw, bh, x_w, y_w = int(x), int(y), int(bw), int(bh), int(x_w), int(y_w)
+            mx = mx / scale
+            my = my / scale
+            ys, xs = slice(y - bh // 2, y + bh // 2), slice(x - bw // 2, x + bw // 2)
+            if direction < 0:
+                mv[ys, xs, 0] = mx
+                mv[ys, xs, 1] = my
+            elif direction > 0 and is_b:
+                mv[ys, xs, 2] = mx
+                mv[ys, xs, 3] = my
+            elif direction > 0 and not is_b:
+                tgt = mvs[-p_offset]
+                yw, xw = slice(y_w - bh // 2, y_w + bh // 2), slice(x_w - bw // 2, x_w + bw // 2)
+                tgt[yw, xw, 2] = -mx
+                tgt[yw, xw, 3] = -my
+            part[ys, xs, part_ch[bw * bh]] = 1
+        parts.append(part)
+        mvs.append(mv)
+        p_offset = (p_offset + 1) if is_b else 1
+    mvs = np.stack([m.transpose(2, 0, 1) for m in mvs]).astype(np.float32)
+    parts = np.stack([(p.astype(np.float32) / 255.).transpose(2, 0, 1) for p in parts]).astype(np.float32)
+    return mvs, parts
+
+
 def to_torch_state(sd_np):
     return {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}

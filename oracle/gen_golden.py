@@ -132,6 +132,43 @@ def main():
         print(case['name'], d, d2, flush=True)
         assert max(d, d2) < 1e-5
 
+    # ---- side-info rasteriser (row 8f-1): the reference loader run on a synthetic on-disk clip
+    import tempfile
+    from PIL import Image
+    Loader = ref_shim.reference_loader_class()
+    for case in gu.RASTER_CASES:
+        rec, rec_frame, slices, h, w = gu.raster_case_inputs(case)
+        with tempfile.TemporaryDirectory() as root:
+            png = os.path.join(root, 'crf25', 'png', '000')
+            mvd = os.path.join(root, 'crf25', 'mv', '000')
+            os.makedirs(png)
+            os.makedirs(mvd)
+            table = {'crf25': {'000': {}}}
+            paths = []
+            for f, sl in enumerate(slices):
+                Image.fromarray(np.zeros((h, w, 3), np.uint8)).save(os.path.join(png, f'{f:08d}.png'))
+                np.save(os.path.join(mvd, f'{f:08d}.npy'), rec[rec_frame == f].reshape(-1, 10))
+                table['crf25']['000'][str(f)] = {'slice': sl, 'QP': 20 + f}
+                paths.append(os.path.join(png, f'{f:08d}.png'))
+            qp_file = os.path.join(root, 'qp.json')
+            with open(qp_file, 'w') as fq:
+                json.dump(table, fq)
+            ld = Loader(io_backend='disk', key='lq', channel_order='rgb', random_compress=False, load_mv=True,
+                        load_qp_slice=True, load_base_qp=True, load_partition=True, drconv=True, qp_slice_file=qp_file)
+            res = ld(dict(lq_path=paths))
+        mvs_ref = np.stack([m.transpose(2, 0, 1) for m in res['mvs']]).astype(np.float32)
+        par_ref = np.stack([(p_.astype(np.float32) / 255.).transpose(2, 0, 1) for p_ in res['partitions']])
+        mine_mv, mine_par = cpu_ref.rasterise_side_info(rec, rec_frame, slices, h, w)
+        d = max(float(np.abs(mvs_ref - mine_mv).max()), float(np.abs(par_ref - mine_par).max()))
+        np.savez(os.path.join(gu.GOLDEN_DIR, case['name'] + '.npz'), mvs=mvs_ref, partitions=par_ref,
+                 slices=np.array([float(np.asarray(v).reshape(-1)[0]) for v in res['slices']], np.float32),
+                 QPs=np.array([float(np.asarray(v).reshape(-1)[0]) for v in res['QPs']], np.float32),
+                 base_QPs=np.array([float(np.asarray(v).reshape(-1)[0]) for v in res['base_QPs']], np.float32))
+        manifest['cases'][case['name']] = dict(kind='rasteriser', oracle_vs_reference_maxabs=d,
+                                               nonzero_mv_fraction=float((mvs_ref != 0).mean()))
+        print(case['name'], d, 'nonzero', float((mvs_ref != 0).mean()), flush=True)
+        assert d == 0.0
+
     with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json'), 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print('wrote', gu.GOLDEN_DIR)

@@ -159,5 +159,47 @@ def reference_modules():
             importlib.import_module('mmedit.models.backbones.sr_backbones.basicvsr_net'))
 
 
+def reference_loader_class():
+    """LoadImageFromFileList_ipb (mmedit/datasets/pipelines/loading_ipb.py:221-397), importable with
+    a disk FileClient and a PIL-backed imfrombytes standing in for mmcv's (file plumbing only; the
+    MV / partition rasterisation arithmetic is the reference's own numpy code)."""
+    install()
+    import io
+    import numpy as np
+    from PIL import Image
+    mmcv = sys.modules['mmcv']
+    if 'mmcv.fileio' not in sys.modules:
+        fileio = types.ModuleType('mmcv.fileio')
+
+        class FileClient:
+            def __init__(self, backend='disk', **kwargs):
+                assert backend == 'disk'
+
+            def get(self, filepath):
+                with open(filepath, 'rb') as f:
+                    return f.read()
+        fileio.FileClient = FileClient
+        mmcv.fileio = fileio
+        sys.modules['mmcv.fileio'] = fileio
+
+        def imfrombytes(content, flag='color', channel_order='bgr', backend=None):
+            img = np.array(Image.open(io.BytesIO(content)).convert('RGB'))
+            return img if channel_order == 'rgb' else img[..., ::-1].copy()
+        mmcv.imfrombytes = imfrombytes
+        core = types.ModuleType('mmedit.core')
+        core.__path__ = []
+        mask = types.ModuleType('mmedit.core.mask')
+        for n in ('bbox2mask', 'brush_stroke_mask', 'get_irregular_mask', 'random_bbox'):
+            setattr(mask, n, _absent)
+        sys.modules['mmedit.core'] = core
+        sys.modules['mmedit.core.mask'] = mask
+        for name, rel in (('mmedit.datasets', 'mmedit/datasets'), ('mmedit.datasets.pipelines', 'mmedit/datasets/pipelines')):
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REFERENCE_ROOT, rel)]
+            sys.modules[name] = m
+    mod = importlib.import_module('mmedit.datasets.pipelines.loading_ipb')
+    return mod.LoadImageFromFileList_ipb
+
+
 def available():
     return os.path.isdir(os.path.join(REFERENCE_ROOT, 'mmedit'))

@@ -147,3 +147,23 @@ def psnr_frames(a, b, crop_border=0):
     out = 20.0 * torch.log10(255.0 / mse.sqrt())
     out[mse == 0] = float('inf')
     return out.reshape(a.shape[:-3])
+
+
+def rasterise_side_info(records, rec_frame, slices, h, w):
+    """Decoder MV records -> (mvs (T,4,h,w), partitions (T,3,h,w)) on the GPU
+    (LoadImageFromFileList_ipb.__call__, loading_ipb.py:328-369, + RescaleToZeroOne + FramesToTensor).
+    records (R,10) fp32 CUDA, rec_frame (R,) int32 CUDA, slices: sequence of 'I'/'P'/'B' (or ord values)."""
+    records = _chk(records, 'records')
+    if not rec_frame.is_cuda or rec_frame.dtype != torch.int32:
+        raise TypeError('rec_frame must be a CUDA int32 tensor')
+    rec_frame = rec_frame.contiguous()
+    t = len(slices)
+    sl = (ctypes.c_float * t)(*[float(ord(s) if isinstance(s, str) else s) for s in slices])
+    dev = records.device
+    mvs = torch.empty((t, 4, h, w), device=dev, dtype=torch.float32)
+    par = torch.empty((t, 3, h, w), device=dev, dtype=torch.float32)
+    scratch = torch.empty((t, 2, h, w), device=dev, dtype=torch.int32)
+    _native.check(_native.lib().pnp_rasterise_side_info_f32(_ptr(records), _ptr(rec_frame), records.shape[0], sl, t, h, w,
+                                                            _ptr(mvs), _ptr(par), _ptr(scratch), _stream()),
+                  'pnp_rasterise_side_info_f32')
+    return mvs, par

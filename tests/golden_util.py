@@ -133,3 +133,36 @@ def block_case_inputs(case):
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+
+
+# ---------------------------------------------------------------- side-info rasteriser
+RASTER_CASES = [
+    dict(name='raster_ibbpbp_48x64', seed=401, h=48, w=64, slices='IBBPBP', per_frame=60),
+    dict(name='raster_ippp_64x64', seed=402, h=64, w=64, slices='IPPP', per_frame=90),
+]
+
+
+def raster_case_inputs(case):
+    """Synthetic per-frame MV records in the on-disk row format of the reference
+    (direction, w, h, x_w, y_w, x, y, motion_x, motion_y, scale), incl. blocks that stick out of the frame."""
+    s, h, w = case['seed'], case['h'], case['w']
+    slices = case['slices']
+    rows, frames = [], []
+    sizes = [(16, 16), (16, 8), (8, 16), (8, 8)]
+    for f, sl in enumerate(slices):
+        if sl == 'I':
+            continue
+        n = case['per_frame']
+        sz = syn.randint(s, f'sz{f}', (n,), 0, 3)
+        cx = syn.randint(s, f'cx{f}', (n,), -1, w // 4 + 1) * 4
+        cy = syn.randint(s, f'cy{f}', (n,), -1, h // 4 + 1) * 4
+        mx = syn.randint(s, f'mx{f}', (n,), -64, 64)
+        my = syn.randint(s, f'my{f}', (n,), -64, 64)
+        dr = syn.randint(s, f'dr{f}', (n,), 0, 1) * 2 - 1
+        for i in range(n):
+            bw, bh = sizes[int(sz[i])]
+            x, y = int(cx[i]), int(cy[i])
+            xw, yw = x + int(mx[i]) // 4, y + int(my[i]) // 4
+            rows.append([float(dr[i]), bw, bh, xw, yw, x, y, float(mx[i]), float(my[i]), 4.0])
+            frames.append(f)
+    return np.array(rows, np.float32), np.array(frames, np.int32), slices, h, w

@@ -238,3 +238,41 @@ def test_psnr_on_device_matches_reference_definition(crop):
     yi = (y * 255).round()
     ref = 20 * torch.log10(255.0 / ((xi - yi).double() ** 2).mean(dim=(1, 2, 3)).sqrt())
     assert float((g - ref.cpu()).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize('case', gu.RASTER_CASES, ids=[c['name'] for c in gu.RASTER_CASES])
+def test_rasteriser_vs_reference_loader(case):
+    """bit-exact against the maps the reference's LoadImageFromFileList_ipb produced (tests/golden)."""
+    from pnp_vcve_amd import ops
+    rec, rec_frame, slices, h, w = gu.raster_case_inputs(case)
+    mvs, par = ops.rasterise_side_info(G(rec), torch.from_numpy(rec_frame).to(dev()), slices, h, w)
+    g = gu.load_golden(case['name'])
+    assert np.array_equal(mvs.cpu().numpy(), g['mvs'])
+    assert np.array_equal(par.cpu().numpy(), g['partitions'])
+
+
+def test_rasteriser_720p_wraparound_and_overwrite_order_vs_oracle():
+    """a REDS-sized frame set with thousands of records, blocks hanging over every edge (incl. the python
+    wrap-around case y + h/2 < 0) and heavy overlap: the last record must win, as in the loader's loop."""
+    from pnp_vcve_amd import ops
+    h, w, slices = 720, 1280, 'IBBPBBP'
+    rng = np.random.RandomState(3)
+    rows, frames = [], []
+    for f, sl in enumerate(slices):
+        if sl == 'I':
+            continue
+        n = 6000
+        sz = np.array([(16, 16), (16, 8), (8, 16), (8, 8)])[rng.randint(0, 4, n)]
+        cx = rng.randint(-6, w // 4 + 6, n) * 4
+        cy = rng.randint(-6, h // 4 + 6, n) * 4
+        mx, my = rng.randint(-64, 65, n), rng.randint(-64, 65, n)
+        dr = rng.randint(0, 2, n) * 2 - 1
+        for i in range(n):
+            rows.append([dr[i], sz[i, 0], sz[i, 1], cx[i] + mx[i] // 4, cy[i] + my[i] // 4, cx[i], cy[i], mx[i], my[i], 4])
+            frames.append(f)
+    rec, rec_frame = np.array(rows, np.float32), np.array(frames, np.int32)
+    mvs, par = ops.rasterise_side_info(G(rec), torch.from_numpy(rec_frame).to(dev()), slices, h, w)
+    rm, rp = cpu_ref.rasterise_side_info(rec, rec_frame, slices, h, w)
+    assert np.array_equal(mvs.cpu().numpy(), rm)
+    assert np.array_equal(par.cpu().numpy(), rp)
+    assert (rm[3, 2:] != 0).any() and (rm[0, 2:] != 0).any()      # P frames painted the previous anchors

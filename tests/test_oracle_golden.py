@@ -95,3 +95,12 @@ def test_psnr_definition():
     v = cpu_ref.clip_psnr(a, b)
     assert 20 < v < 40
     assert cpu_ref.clip_psnr(a, a) == float('inf')
+
+
+@pytest.mark.parametrize('case', gu.RASTER_CASES, ids=[c['name'] for c in gu.RASTER_CASES])
+def test_rasteriser_matches_reference_loader(case):
+    rec, rec_frame, slices, h, w = gu.raster_case_inputs(case)
+    mvs, par = cpu_ref.rasterise_side_info(rec, rec_frame, slices, h, w)
+    g = gu.load_golden(case['name'])
+    assert np.array_equal(mvs, g['mvs']) and np.array_equal(par, g['partitions'])
+    assert [chr(int(v)) for v in g['slices']] == list(slices)
