@@ -7,7 +7,17 @@ from .dist import gather_clip_metrics, get_dist_info, shard_indices
 
 
 def _to_device(data, device):
-    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in data.items()}
+    """Host -> device; when the clip carries raw decoder MV records (CompressedClipFolderDataset) the dense
+    motion / partition maps are painted on the GPU (pnp_rasterise_side_info_f32) instead of on the host."""
+    out = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in data.items()}
+    if 'mv_records' in out:
+        from .ops import rasterise_side_info
+        rec, rf = out.pop('mv_records'), out.pop('rec_frame')
+        t, h, w = out['lq'].shape[1], out['lq'].shape[-2], out['lq'].shape[-1]
+        sl = [float(v) for v in data['slices'].reshape(-1)[:t]]
+        mvs, par = rasterise_side_info(rec.float(), rf.int(), sl, h, w)
+        out['mvs'], out['partitions'] = mvs.unsqueeze(0), par.unsqueeze(0)
+    return out
 
 
 def single_gpu_test(model, dataset, save_image=False, save_path=None, device='cuda'):

@@ -50,12 +50,103 @@ class SyntheticCompressedClipDataset(_EvalMixin, torch.utils.data.Dataset):
         return out
 
 
+@DATASETS.register_module(name='SRREDSMultipleGTCompressDataset')
+@DATASETS.register_module()
+class CompressedClipFolderDataset(_EvalMixin, torch.utils.data.Dataset):
+    """On-disk clips in the reference's layout (mmedit/datasets/sr_reds_multiple_gt_compress_dataset.py +
+    pipelines GenerateSegmentIndices_LR / LoadImageFromFileList_ipb / LoadImageFromFileList /
+    RescaleToZeroOne / FramesToTensor, configs/HR_davis_LR_128x128.py:109-131):
+
+        <lq_folder>/<clip>/<%08d>.png        e.g. dataset/REDS_test_HR/crf25/png/000/00000000.png
+        <lq_folder with 'png'->'mv'>/<clip>/<%08d>.npy   decoder MV records, rows
+              (direction, w, h, x_w, y_w, x, y, motion_x, motion_y, scale)
+        qp_slice_file: JSON  {crfXX: {clip: {frame: {'slice': 'I|P|B', 'QP': q}}}}
+        <gt_folder>/<clip>/<%08d>.png
+
+    Frames, QP / slice side info and the raw MV records are read on the host; the dense motion and
+    partition maps are NOT built here -- the records travel to the GPU and pnp_rasterise_side_info_f32
+    paints them there (apis.prepare_batch).  Clips are discovered on disk (REDS4 names if present)."""
+
+    REDS4 = ['000', '011', '015', '020']
+
+    def __init__(self, lq_folder, gt_folder, num_input_frames=100, pipeline=None, scale=1, val_partition='REDS4',
+                 repeat=1, cprs_folder=None, test_mode=True, qp_slice_file=None, replace_qp_withIPB=False, **unused):
+        import json
+        import os
+        if not isinstance(repeat, int):
+            raise TypeError(f'"repeat" must be an integer, but got {type(repeat)}.')
+        self.lq_folder, self.gt_folder = str(lq_folder), str(gt_folder)
+        self.num_input_frames = num_input_frames
+        # the loader options live inside the pipeline list in the reference configs
+        for step in (pipeline or []):
+            if isinstance(step, dict) and step.get('type', '').startswith('LoadImageFromFileList_ipb'):
+                qp_slice_file = step.get('qp_slice_file', qp_slice_file)
+                replace_qp_withIPB = step.get('replace_qp_withIPB', replace_qp_withIPB)
+        self.replace_qp = bool(replace_qp_withIPB)
+        self.table = None
+        if qp_slice_file is not None:
+            with open(qp_slice_file) as f:
+                self.table = json.load(f)
+        clips = sorted(d for d in os.listdir(self.lq_folder) if os.path.isdir(os.path.join(self.lq_folder, d)))
+        if val_partition == 'REDS4' and all(c in clips for c in self.REDS4):
+            clips = list(self.REDS4)
+        self.keys = clips * repeat
+
+    def __len__(self):
+        return len(self.keys)
+
+    @staticmethod
+    def _png(path):
+        import numpy as np
+        from PIL import Image
+        return np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8)
+
+    def __getitem__(self, idx):
+        import os
+        import numpy as np
+        key = self.keys[idx]
+        d = os.path.join(self.lq_folder, key)
+        names = sorted(f for f in os.listdir(d) if f.endswith('.png'))[:self.num_input_frames]
+        crf_dir = self.lq_folder.rstrip('/').split('/')[-2] if '/' in self.lq_folder.rstrip('/') else ''
+        base_qp = int(crf_dir.split('crf')[1]) if 'crf' in crf_dir else 0          # loading_ipb.py:239
+        lq, gt, slices, qps, recs, rec_frame = [], [], [], [], [], []
+        for t, name in enumerate(names):
+            lq.append(self._png(os.path.join(d, name)))
+            gt.append(self._png(os.path.join(self.gt_folder, key, name)))
+            frame = str(int(name.split('.')[0]))
+            if crf_dir.startswith('crf') and self.table is not None:                # loading_ipb.py:298-312
+                e = self.table[crf_dir][key][frame]
+                sl = e['slice']
+                qp = ord(sl) if self.replace_qp else e['QP']
+            else:
+                sl = 'I' if frame == '0' else 'P'
+                qp = ord(sl) if self.replace_qp else 0.0
+            slices.append(float(ord(sl)))
+            qps.append(float(qp) / 255.0)
+            mv_path = os.path.join(d, name).replace('.png', '.npy').replace('png', 'mv')   # loading_ipb.py:326
+            r = np.load(mv_path).astype(np.float32).reshape(-1, 10)
+            recs.append(r)
+            rec_frame.append(np.full((r.shape[0],), t, np.int32))
+        T = len(names)
+        f32 = lambda a: torch.from_numpy(np.stack(a).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous()
+        return dict(lq=f32(lq), gt=f32(gt),
+                    slices=torch.tensor(slices, dtype=torch.float32).view(T, 1, 1, 1),
+                    QPs=torch.tensor(qps, dtype=torch.float32).view(T, 1, 1, 1),
+                    base_QPs=torch.full((T, 1, 1, 1), base_qp / 255.0, dtype=torch.float32),
+                    mv_records=torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, 10), np.float32)),
+                    rec_frame=torch.from_numpy(np.concatenate(rec_frame) if rec_frame else np.zeros((0,), np.int32)),
+                    meta=dict(key=f'{key}/{0:08d}', lq_path=d, gt_path=os.path.join(self.gt_folder, key)))
+
+
 def collate(batch):
     """samples_per_gpu=1 (forced by the reference, tools/test.py:110): add the batch dim."""
     out = {}
     for k in batch[0]:
         if k == 'meta':
             out[k] = [b[k] for b in batch]
+        elif k in ('mv_records', 'rec_frame'):      # ragged per clip: samples_per_gpu is 1
+            assert len(batch) == 1
+            out[k] = batch[0][k]
         else:
             out[k] = torch.stack([b[k] for b in batch])
     return out

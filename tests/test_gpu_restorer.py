@@ -52,3 +52,33 @@ def test_test_driver_cli(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'Eval-PSNR' in out.stdout and 'Eval-SSIM' in out.stdout
     assert os.path.exists(os.path.join(str(tmp_path), '000', '00000000.png'))
+
+
+def test_folder_dataset_end_to_end_with_gpu_rasteriser(tmp_path):
+    """dist_test-style run on an on-disk clip tree in the reference's layout: frames + MV records from disk,
+    dense maps painted on the GPU, generator, on-device PSNR -- against the oracle fed with the oracle's maps."""
+    import pnp_vcve_amd  # noqa: F401
+    from pnp_vcve_amd import restorer, synthetic as syn  # noqa: F401
+    from pnp_vcve_amd.apis import multi_gpu_test
+    from pnp_vcve_amd.config import Config
+    from pnp_vcve_amd.datasets import build_dataset
+    from pnp_vcve_amd.registry import build_model
+    from test_host_logic import _write_clip_tree
+    lq, gt, qp, slices = _write_clip_tree(str(tmp_path), clips=('000',), t=4)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'REDS_folder_example.py'))
+    cfg.merge_from_dict({'data.test.lq_folder': lq, 'data.test.gt_folder': gt})
+    cfg.data.test.pipeline[1]['qp_slice_file'] = qp
+    ds = build_dataset(cfg.data.test)
+    model = build_model(cfg.model, train_cfg=None, test_cfg=dict(metrics=['PSNR'], crop_border=0))
+    gcfg = dict(syn.DEFAULT_GENERATOR_CFG)
+    sd_np = syn.make_state_dict(gcfg, seed=12, par_gain=10.0)
+    model.generator.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    model = model.cuda().eval()
+    out = multi_gpu_test(model, ds, device='cuda', metrics=('PSNR',))
+    item = ds[0]
+    mvs, par = cpu_ref.rasterise_side_info(item['mv_records'].numpy(), item['rec_frame'].numpy(), slices, 64, 64)
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), gcfg, item['lq'][None], item['QPs'][None],
+                                        item['slices'][None], torch.from_numpy(mvs)[None], item['base_QPs'][None],
+                                        torch.from_numpy(par)[None])
+    assert abs(out[0]['eval_result']['PSNR'] - cpu_ref.clip_psnr(ref, item['gt'][None])) < 0.01

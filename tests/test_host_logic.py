@@ -140,3 +140,50 @@ def test_two_rank_clip_sharding_and_metric_all_gather_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'ok' in o
+
+
+def _write_clip_tree(root, clips=('000', '011'), t=4, h=64, w=64, crf='crf25'):
+    """a tiny dataset in the reference's on-disk layout (PNG frames, .npy MV records, JSON QP/slice table)."""
+    import json
+    from PIL import Image
+    import golden_util as gu
+    table = {crf: {}}
+    slices = 'IBPB'[:t]
+    for ci, clip in enumerate(clips):
+        png = os.path.join(root, crf, 'png', clip)
+        mv = os.path.join(root, crf, 'mv', clip)
+        gt = os.path.join(root, 'X4', 'png', clip)
+        for d in (png, mv, gt):
+            os.makedirs(d)
+        rec, rf, _, _, _ = gu.raster_case_inputs(dict(seed=900 + ci, h=h, w=w, slices=slices, per_frame=30))
+        table[crf][clip] = {}
+        rng = np.random.RandomState(ci)
+        for f in range(t):
+            img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(png, f'{f:08d}.png'))
+            Image.fromarray(np.clip(img.astype(int) + rng.randint(-9, 10, img.shape), 0, 255).astype(np.uint8)).save(
+                os.path.join(gt, f'{f:08d}.png'))
+            np.save(os.path.join(mv, f'{f:08d}.npy'), rec[rf == f])
+            table[crf][clip][str(f)] = {'slice': slices[f], 'QP': 22 + f}
+    qp = os.path.join(root, 'qp.json')
+    with open(qp, 'w') as fq:
+        json.dump(table, fq)
+    return os.path.join(root, crf, 'png'), os.path.join(root, 'X4', 'png'), qp, slices
+
+
+def test_folder_dataset_reads_the_reference_layout(tmp_path):
+    from pnp_vcve_amd.datasets import build_dataset
+    import golden_util as gu
+    lq, gt, qp, slices = _write_clip_tree(str(tmp_path))
+    ds = build_dataset(dict(type='SRREDSMultipleGTCompressDataset', lq_folder=lq, gt_folder=gt, num_input_frames=100,
+                            pipeline=[dict(type='LoadImageFromFileList_ipb', qp_slice_file=qp)], scale=1,
+                            val_partition='REDS4', test_mode=True))
+    assert len(ds) == 2
+    item = ds[1]
+    assert item['lq'].shape == (4, 3, 64, 64) and item['gt'].shape == (4, 3, 64, 64)
+    assert [chr(int(v)) for v in item['slices'].reshape(-1)] == list(slices)
+    assert torch.allclose(item['QPs'].reshape(-1), torch.tensor([22., 23., 24., 25.]) / 255.0)
+    assert torch.allclose(item['base_QPs'].reshape(-1), torch.full((4,), 25 / 255.0))
+    rec, rf, _, _, _ = gu.raster_case_inputs(dict(seed=901, h=64, w=64, slices=slices, per_frame=30))
+    assert np.array_equal(item['mv_records'].numpy(), rec) and np.array_equal(item['rec_frame'].numpy(), rf)
+    assert item['meta']['key'].startswith('011/')

@@ -50,9 +50,12 @@ def main():
     rank, world = get_dist_info()
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    if args.testdir_lr is not None or args.testdir_gt is not None:
-        raise SystemExit('the on-disk REDS loader is outside this build (SURVEY.md section 8f-1); '
-                         'use the synthetic dataset of the config')
+    if args.testdir_lr is not None:                     # tools/test.py:98-103 of the reference
+        cfg.merge_from_dict({'data.test.lq_folder': args.testdir_lr})
+        print('-------------------- test LR dir :', args.testdir_lr)
+    if args.testdir_gt is not None:
+        cfg.merge_from_dict({'data.test.gt_folder': args.testdir_gt})
+        print('-------------------- test GT dir :', args.testdir_gt)
     dataset = build_dataset(cfg.data.test)
     model = build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     if args.checkpoint.lower() != 'none':
