@@ -33,7 +33,8 @@ typedef struct pnp_generator_cfg {
     int num_experts;
     int with_cat, use_base_qp, expert_softmax, with_bias, with_se;
     int one_layer, channel_first, align_key, vsr;
-    int deform; /* 0 'vos' (MV bilinear warp); 1 'basic', 2 'fvc' reserved */
+    int deform; /* 0 'vos' (MV bilinear warp, iconvsr_mv.py:12-18); 1 'basic' (:52-84), 2 'fvc' (:21-41):
+                   flow-guided modulated deformable conv, deform_groups 16 (mmcv semantics restated) */
 } pnp_generator_cfg;
 
 typedef struct pnp_generator pnp_generator;
@@ -77,6 +78,7 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat_dev, const f
 #define PNP_PROF_CONV_INPUT 1 /* input convs over the virtual concat */
 #define PNP_PROF_CONV_HEAD 2  /* conv_hr is BLOCK-shaped but conv_last / upsample convs land here */
 #define PNP_PROF_WARP 3       /* MV-guided bilinear alignment, 520 B per pixel */
+#define PNP_PROF_DCN 4        /* modulated deformable alignment (deform = basic|fvc), 2240 B per pixel */
 int pnp_generator_profile(pnp_generator* g, int enable);
 int pnp_generator_profile_read(pnp_generator* g, int kind, double* total_ms, int64_t* launches, double* work);
 
@@ -129,6 +131,15 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_chann
  * N = c * (h - 2 crop) * (w - 2 crop). */
 int pnp_psnr_sse_f32(const float* a_dev, const float* b_dev, unsigned long long* sse_dev, int frames,
                      int c, int h, int w, int crop_border, void* stream);
+
+/* Modulated deformable 3x3 conv, 64 -> 64 channels, deform_groups 16 (mmcv.ops.modulated_deform_conv2d as
+ * called at mmedit/models/backbones/sr_backbones/iconvsr_mv.py:38-41,81-84; semantics restated, mmcv is not
+ * vendored).  x_dev (h,w,64) pixel-major; om_dev (h,w,448): conv_offset[2] output (pre-sigmoid masks) in the
+ * channel order given by pnp_dcn_ref_channel (packed channel -> reference channel of the 432, -1 = padding);
+ * flow_x/flow_y (h,w) planes added to every (dx, dy) offset or NULL; w_packed = pnp_pack_conv3x3_f32 image. */
+int pnp_dcn_nhwc_f32(const float* x_dev, const float* om_dev, const float* flow_x_dev, const float* flow_y_dev,
+                     const float* w_packed_dev, const float* bias_dev, float* out_dev, int h, int w, void* stream);
+int pnp_dcn_ref_channel(int packed_channel);
 
 /* MV / partition records -> dense maps: the inner loop of LoadImageFromFileList_ipb.__call__
  * (mmedit/datasets/pipelines/loading_ipb.py:328-369) + RescaleToZeroOne(partitions) + HWC->CHW.

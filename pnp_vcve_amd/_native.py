@@ -51,6 +51,9 @@ SIGNATURES = {
     'pnp_psnr_sse_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_rasterise_side_info_f32': (c_int, [c_void_p, c_void_p, ctypes.c_long, POINTER(c_float), c_int, c_int, c_int,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    'pnp_dcn_nhwc_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_void_p]),
+    'pnp_dcn_ref_channel': (c_int, [c_int]),
     'pnp_conv3x3_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
 }

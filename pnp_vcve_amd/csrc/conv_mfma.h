@@ -22,8 +22,10 @@ struct ConvArgs {
     int H, W;               // spatial size of the sources
     int act;                // 0 none, 1 relu, 2 leaky-relu(0.1)
     unsigned long long* dbg; // diagnostic timeline buffer (8 u64 per block) or nullptr
+    int out_cstride;        // out_mode 4: channels per pixel of the output buffer
     int out_mode;           // 0 NHWC64 | 1 NHWC64 pixel-shuffle(2), sub-pixel = blockIdx.y
                             // 2 RGB NCHW + lr | 3 RGB NCHW + bilinear x4 upsample of lr (H/4 x W/4)
+                            // 4 NHWC with out_cstride channels per pixel, channel block 64*blockIdx.y
 };
 
 enum { CONV_CFG_BIG = 0,    // 8x16 pixel tile, 64 output channels per block

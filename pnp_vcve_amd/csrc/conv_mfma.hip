@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     constexpr int EIT = 32 / PPI;     // iterations to cover the wave's 32 pixels
     const int ec = lane % CW, ep = lane / CW;
     const int n0 = lane & 31;
-    const bool rowwise = a.out_mode < 2;
+    const bool rowwise = a.out_mode < 2 || a.out_mode == 4;
 
     // ---- epilogue operands are fetched EARLY (right behind the first halo-tile loads) so their
     //      latency hides under the K loop; the residual may alias `out` element-for-element.
@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             if (gy < H && gx < W) {
                 long o;
                 if (a.out_mode == 0) o = ((long)gy * W + gx) * 64;
+                else if (a.out_mode == 4) o = ((long)gy * W + gx) * a.out_cstride + 64 * yimg;
                 else o = ((long)(2 * gy + (yimg >> 1)) * (2 * W) + 2 * gx + (yimg & 1)) * 64;
                 *reinterpret_cast<f32x4*>(a.out + o + wn * NT * 32 + ec * 4) = v;
             }

@@ -23,6 +23,7 @@
 #include "conv_mfma.h"
 #include "prep.h"
 #include "warp.h"
+#include "dcn.h"
 
 namespace {
 
@@ -73,6 +74,9 @@ struct pnp_generator {
     BranchPk br[2];                   // 0 backward, 1 forward
     int64_t hr_img = -1, hr_bias = -1, last_img = -1, last_bias = -1;       // last_bias packed (32)
     int64_t up_img[2] = {-1, -1}, up_bias[2] = {-1, -1};                    // packed
+    // deform = 'basic' | 'fvc' (iconvsr_mv.py:21-84): flat offsets of the aligner's parameters, packed images
+    int64_t f_dcn_w = -1, f_dcn_b = -1, f_off0_w = -1, f_off0_b = -1, f_off2_w = -1, f_off2_b = -1;
+    int64_t dcn_img = -1, off0_flow_img = -1, off0_feat_img = -1, off2_img = -1, off2_bias = -1;
     int64_t p_w1 = -1, p_b1 = -1, p_w2 = -1, p_b2 = -1, p_v1 = -1, p_v2 = -1;  // flat
     // flat offsets needed by pack()
     int64_t f_in_w[2] = {-1, -1}, f_hr_w = -1, f_last_w = -1, f_last_b = -1, f_up_w[2] = {-1, -1},
@@ -105,7 +109,7 @@ int build_layout(pnp_generator* g) {
     if (c.num_blocks < 1 || c.num_experts < 1 || c.num_experts > 64) return PNP_ERR_BAD_ARG;
     if (c.with_se && !c.with_bias) return PNP_ERR_BAD_ARG;   // reference: gamma is None -> crash
     if (c.with_bias && !c.use_base_qp) return PNP_ERR_BAD_ARG;   // iconvsr_ipb_par.py:27 assert
-    if (c.deform != 0) return PNP_ERR_UNSUPPORTED;
+    if (c.deform < 0 || c.deform > 2) return PNP_ERR_BAD_ARG;
     const int nb = c.num_blocks, E = c.num_experts;
     const int dpb = c.one_layer ? 1 : 2;
     g->ndyn = 2 * nb * dpb;
@@ -171,6 +175,19 @@ int build_layout(pnp_generator* g) {
             B.blocks[i].w1x1 = g->add_packed(3 * IMG_CHUNK);
         }
     }
+    if (c.deform != 0) {
+        g->f_dcn_w = g->add_param("deform_align.weight", {64, 64, 3, 3});
+        g->f_dcn_b = g->add_param("deform_align.bias", {64});
+        g->f_off0_w = g->add_param("deform_align.conv_offset.0.weight", {64, 66, 3, 3});
+        g->f_off0_b = g->add_param("deform_align.conv_offset.0.bias", {64});
+        g->f_off2_w = g->add_param("deform_align.conv_offset.2.weight", {432, 64, 3, 3});
+        g->f_off2_b = g->add_param("deform_align.conv_offset.2.bias", {432});
+        g->dcn_img = g->add_packed(IMG_WIDE);
+        g->off0_flow_img = g->add_packed(IMG_CHUNK);
+        g->off0_feat_img = g->add_packed(IMG_WIDE);
+        g->off2_img = g->add_packed(7 * IMG_WIDE);
+        g->off2_bias = g->add_packed(448);
+    }
     g->f_hr_w = g->add_param("conv_hr.weight", {64, 64, 3, 3});
     g->hr_bias = g->add_param("conv_hr.bias", {64});
     g->hr_img = g->add_packed(IMG_WIDE);
@@ -196,8 +213,11 @@ __global__ void small_copy_kernel(const float* __restrict__ src, float* __restri
     if (i >= n_total) return;
     if (mode == 0) {            // zero-padded copy
         dst[i] = i < n_valid ? src[i] : 0.f;
-    } else {                    // pixel-shuffle bias permutation: dst[sub*64 + c] = src[c*4 + sub]
+    } else if (mode == 1) {     // pixel-shuffle bias permutation: dst[sub*64 + c] = src[c*4 + sub]
         dst[i] = src[(i & 63) * 4 + (i >> 6)];
+    } else {                    // DCN offset/mask channel order (prep.h)
+        const int r = pnp_dcn_ref_channel_impl(i);
+        dst[i] = r >= 0 ? src[r] : 0.f;
     }
 }
 
@@ -213,6 +233,8 @@ PackArgs plain_pack(const float* w, int cin_total, int ktaps, int kind, int cbas
     a.co_mul = 1;
     a.co_add = 0;
     a.n_valid = n_valid;
+    a.co_mode = 0;
+    a.cvalid = 3;
     a.kind = kind;
     a.cbase = cbase;
     a.ntb = ntb;
@@ -246,7 +268,7 @@ struct ProfScope {
 };
 
 struct Workspace {
-    float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb;
+    float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om;
     int64_t bytes;
 };
 
@@ -272,6 +294,12 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
         W.u3 = take(hw * 16 * 64);
     } else {
         W.u1 = W.u2 = W.u3 = nullptr;
+    }
+    if (g->cfg.deform != 0) {
+        W.flow4 = take(hw * 4);
+        W.om = take(hw * 448);
+    } else {
+        W.flow4 = W.om = nullptr;
     }
     W.ew = take((int64_t)t * g->cfg.num_experts);
     W.gamma = take((int64_t)t * 64);
@@ -343,6 +371,25 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
             }
         }
     }
+    if (c.deform != 0) {
+        rc = launch_pack_weights(plain_pack(flat + g->f_dcn_w, 64, 9, PACK_WIDE, 0, 2, 64, packed + g->dcn_img), 1, st);
+        if (rc) return rc;
+        // conv_offset[0] over cat([ref, flow]) (iconvsr_mv.py:33,70): the 2 flow channels are concat channels 64,65
+        PackArgs pf = plain_pack(flat + g->f_off0_w, 66, 9, PACK_RGB4, 64, 2, 64, packed + g->off0_flow_img);
+        pf.cvalid = 2;
+        rc = launch_pack_weights(pf, 1, st);
+        if (rc) return rc;
+        rc = launch_pack_weights(plain_pack(flat + g->f_off0_w, 66, 9, PACK_WIDE, 0, 2, 64, packed + g->off0_feat_img), 1, st);
+        if (rc) return rc;
+        PackArgs po = plain_pack(flat + g->f_off2_w, 64, 9, PACK_WIDE, 0, 2, 64, packed + g->off2_img);
+        po.co_mode = 1;            // 7 blocks of 64 permuted output channels (432 valid)
+        po.w_ystride = 0;
+        po.dst_ystride = IMG_WIDE;
+        rc = launch_pack_weights(po, 7, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(small_copy_kernel, dim3(2), dim3(256), 0, st, flat + g->f_off2_b, packed + g->off2_bias, 432,
+                           448, 2);
+    }
     rc = launch_pack_weights(plain_pack(flat + g->f_hr_w, 64, 9, PACK_WIDE, 0, 2, 64, packed + g->hr_img), 1, st);
     if (rc) return rc;
     rc = launch_pack_weights(plain_pack(flat + g->f_last_w, 64, 9, PACK_WIDE, 0, 1, 3, packed + g->last_img), 1, st);
@@ -413,6 +460,7 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
         a.W = Wd;
         a.act = act;
         a.out_mode = mode;
+        a.out_cstride = 448;
         // algorithmic FLOPs of this launch (reference channel counts, not padded ones)
         double kreal = 0;
         for (int s = 0; s < nsrc; ++s) kreal += 9.0 * (sc[s] == 64 ? 64 : 3);
@@ -429,6 +477,46 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
         const int sc[1] = {64};
         const float* ws[1] = {wimg};
         return conv(1, srcs, sc, ws, bias, gamma, wpar, parp, residual, act, dst, h, w, 0, cfg_lr, 1, nullptr, 0, 0, 0);
+    };
+
+    // deform_align(feat, flow) -> W.kw  (iconvsr_ipb.py:19-24 dispatch; iconvsr_mv.py:12-84)
+    auto align = [&](const float* feat, const float* fxp, const float* fyp) -> int {
+        int r;
+        if (c.deform == 0 || c.deform == 1) {   // 'vos', and the pre-warp of 'basic' (:69)
+            ProfScope ps(g, st, PNP_PROF_WARP, 520.0 * (double)hw);
+            r = launch_mv_warp_nhwc(feat, fxp, fyp, c.deform == 0 ? W.kw : W.tmp0, h, w, 64, st);
+            if (r || c.deform == 0) return r;
+        }
+        r = launch_pack_flow4(fxp, fyp, W.flow4, h, w, st);
+        if (r) return r;
+        {   // conv_offset[0] + LeakyReLU over cat([ref_warped | ref_unwarped, flow])
+            const float* srcs[2] = {W.flow4, c.deform == 1 ? W.tmp0 : feat};
+            const int sc[2] = {4, 64};
+            const float* ws[2] = {packed + g->off0_flow_img, packed + g->off0_feat_img};
+            r = conv(2, srcs, sc, ws, flat + g->f_off0_b, nullptr, nullptr, nullptr, nullptr, 2, W.tmp1, h, w, 0, cfg_lr, 1,
+                     nullptr, 0, 0, 0);
+            if (r) return r;
+        }
+        {   // conv_offset[2]: 64 -> 432 (7 blocks of 64 permuted channels), no activation
+            const float* srcs[1] = {W.tmp1};
+            const int sc[1] = {64};
+            const float* ws[1] = {packed + g->off2_img};
+            r = conv(1, srcs, sc, ws, packed + g->off2_bias, nullptr, nullptr, nullptr, nullptr, 0, W.om, h, w, 4, cfg_lr, 7,
+                     nullptr, 0, IMG_WIDE, 64);
+            if (r) return r;
+        }
+        DcnArgs d;
+        d.x = feat;
+        d.om = W.om;
+        d.fx = c.deform == 1 ? fxp : nullptr;
+        d.fy = c.deform == 1 ? fyp : nullptr;
+        d.w = packed + g->dcn_img;
+        d.bias = flat + g->f_dcn_b;
+        d.out = W.kw;
+        d.H = h;
+        d.W = w;
+        ProfScope ps(g, st, PNP_PROF_DCN, 2240.0 * (double)hw);
+        return launch_dcn(d, st);
     };
 
     for (int b = 0; b < n; ++b) {
@@ -491,6 +579,8 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
                 a.co_mul = 1;
                 a.co_add = 0;
                 a.n_valid = 64;
+                a.co_mode = 0;
+                a.cvalid = 3;
                 a.kind = PACK_WIDE;
                 a.cbase = 0;
                 a.ntb = 2;
@@ -559,11 +649,7 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
             if (i < t - 1) {
                 int k = i + 1;
                 while (!key[k]) ++k;
-                {
-                    ProfScope ps(g, st, PNP_PROF_WARP, 520.0 * (double)hw);
-                    rc = launch_mv_warp_nhwc(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw,
-                                             mv_b + ((int64_t)i * 4 + 3) * hw, W.kw, h, w, 64, st);
-                }
+                rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw, mv_b + ((int64_t)i * 4 + 3) * hw);
                 if (rc) return rc;
                 srcs[ns] = W.kw;
                 sc[ns] = 64;
@@ -590,11 +676,7 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
             if (i > 0) {
                 int k = i - 1;
                 while (!key[k]) --k;
-                {
-                    ProfScope ps(g, st, PNP_PROF_WARP, 520.0 * (double)hw);
-                    rc = launch_mv_warp_nhwc(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw,
-                                             mv_b + ((int64_t)i * 4 + 1) * hw, W.kw, h, w, 64, st);
-                }
+                rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw, mv_b + ((int64_t)i * 4 + 1) * hw);
                 if (rc) return rc;
                 srcs[ns] = W.kw;
                 sc[ns] = 64;
@@ -729,6 +811,24 @@ int pnp_caa_predict_f32(const float* q_ew, const float* q_g, int count, int E, i
     }
     return PNP_OK;
 }
+
+int pnp_dcn_nhwc_f32(const float* x, const float* om, const float* fx, const float* fy, const float* w_packed,
+                     const float* bias, float* out, int h, int w, void* st) {
+    if (h < 1 || w < 1) return PNP_ERR_BAD_ARG;
+    DcnArgs d;
+    d.x = x;
+    d.om = om;
+    d.fx = fx;
+    d.fy = fy;
+    d.w = w_packed;
+    d.bias = bias;
+    d.out = out;
+    d.H = h;
+    d.W = w;
+    return launch_dcn(d, (hipStream_t)st);
+}
+
+int pnp_dcn_ref_channel(int packed_channel) { return pnp_dcn_ref_channel_impl(packed_channel); }
 
 int64_t pnp_packed_conv_floats(int csrc) { return csrc == 64 ? IMG_WIDE : IMG_CHUNK; }
 

@@ -4,6 +4,15 @@
 
 // (T,3,H,W) NCHW frames -> (T,H,W,4) pixel-major, 4th channel zero
 int launch_pack_lr(const float* lrs, float* lr4, int T, int H, int W, hipStream_t stream);
+// DCN conv_offset output channel order used by this build (dcn.hip): packed channel c' ->
+// reference channel of conv_offset[2] (offsets (g*9+k)*2+{dy,dx} for c' < 288, masks 288+g*9+k), -1 = padding
+static inline __host__ __device__ int pnp_dcn_ref_channel_impl(int c) {
+    if (c < 288) return ((((c & 31) >> 1) * 9 + (c >> 5)) << 1) + (c & 1);
+    if (c < 432) return 288 + ((c - 288) & 15) * 9 + ((c - 288) >> 4);
+    return -1;
+}
+// two (H,W) planes -> (H,W,4) pixel-major (x, y, 0, 0): the flow as a conv source
+int launch_pack_flow4(const float* fx, const float* fy, float* out4, int H, int W, hipStream_t stream);
 // generic layout converters (op-level tests / boundary glue)
 int launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, hipStream_t stream);
 int launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, hipStream_t stream);
@@ -17,6 +26,8 @@ struct PackArgs {
     int cin_total, ktaps;
     int co_mul, co_add; // reference output channel = co * co_mul + co_add
     int n_valid;        // packed output channels >= n_valid are zero
+    int co_mode;        // 0: affine (co_mul, co_add); 1: DCN offset/mask permutation of packed channel 64*blockIdx.y + co
+    int cvalid;         // PACK_RGB4: valid channels of the 4-channel source (3 RGB frame, 2 flow)
     int kind;           // PACK_*
     int cbase;          // first input channel of this source inside the virtual concat
     int ntb;            // N tiles of 32 in the image (2 -> 64 channels, 1 -> 32)

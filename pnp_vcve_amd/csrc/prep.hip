@@ -21,6 +21,14 @@ __global__ __launch_bounds__(256) void pack_lr_kernel(const float* __restrict__ 
     reinterpret_cast<f32x4*>(lr4)[i] = v;
 }
 
+__global__ __launch_bounds__(256) void pack_flow4_kernel(const float* __restrict__ fx, const float* __restrict__ fy,
+                                                         float* __restrict__ out4, long hw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw) return;
+    f32x4 v = {fx[i], fy[i], 0.f, 0.f};
+    reinterpret_cast<f32x4*>(out4)[i] = v;
+}
+
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            int C, long hw, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over N*HW*C, c fastest
@@ -63,15 +71,19 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     } else if (a.kind == PACK_RGB4) {
         tap = 2 * q + h;
         ci = a.cbase + j;
-        valid = valid && (q < 5) && (tap <= 8) && (j < 3);
+        valid = valid && (q < 5) && (tap <= 8) && (j < a.cvalid);
     } else {
         tap = 0;
         ci = a.cbase + 8 * q + 4 * h + j;
     }
     float v = 0.f;
+    int co_ref = co * a.co_mul + a.co_add;
+    if (a.co_mode == 1) {
+        co_ref = pnp_dcn_ref_channel_impl(blockIdx.y * 64 + co);
+        valid = valid && co_ref >= 0;
+    }
     if (valid) {
-        const float* w = a.w + (long)blockIdx.y * a.w_ystride +
-                         ((long)(co * a.co_mul + a.co_add) * a.cin_total + ci) * a.ktaps + tap;
+        const float* w = a.w + (long)blockIdx.y * a.w_ystride + ((long)co_ref * a.cin_total + ci) * a.ktaps + tap;
         if (a.ew) {
             for (int e = 0; e < a.E; ++e) v += a.ew[e] * w[(long)e * a.e_stride];
         } else {
@@ -133,6 +145,12 @@ int launch_pack_lr(const float* lrs, float* lr4, int T, int H, int W, hipStream_
     const long hw = (long)H * W, total = hw * T;
     hipLaunchKernelGGL(pack_lr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, lrs, lr4, hw,
                        total);
+    return (int)hipGetLastError();
+}
+
+int launch_pack_flow4(const float* fx, const float* fy, float* out4, int H, int W, hipStream_t stream) {
+    const long hw = (long)H * W;
+    hipLaunchKernelGGL(pack_flow4_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, stream, fx, fy, out4, hw);
     return (int)hipGetLastError();
 }
 

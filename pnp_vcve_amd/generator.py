@@ -188,7 +188,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         return out
 
     # ---------------------------------------------------------------- measurement aid
-    PROF_KINDS = {'conv_block': 0, 'conv_input': 1, 'conv_head': 2, 'mv_warp': 3}
+    PROF_KINDS = {'conv_block': 0, 'conv_input': 1, 'conv_head': 2, 'mv_warp': 3, 'dcn': 4}
 
     def profile(self, enable=True):
         """Bracket every kernel launch of forward() with HIP events (pnp_generator_profile)."""

@@ -167,3 +167,24 @@ def rasterise_side_info(records, rec_frame, slices, h, w):
                                                             _ptr(mvs), _ptr(par), _ptr(scratch), _stream()),
                   'pnp_rasterise_side_info_f32')
     return mvs, par
+
+
+def modulated_deform_conv_nhwc(x, offset, mask_logits, weight, bias, flow=None):
+    """mmcv.ops.modulated_deform_conv2d(x, offset, sigmoid(mask_logits), weight, bias, 1, 1, 1, 1, 16) for the
+    hot path's shapes.  x (h,w,64) pixel-major; offset (288,h,w) and mask_logits (144,h,w) in mmcv's channel
+    order; weight (64,64,3,3); optional flow (2,h,w) = (dx,dy) added to every offset.  Returns (h,w,64)."""
+    x = _chk(x, 'x')
+    h, w, _ = x.shape
+    L = _native.lib()
+    ref = torch.tensor([L.pnp_dcn_ref_channel(c) for c in range(448)], device=x.device)
+    src = torch.cat([_chk(offset, 'offset'), _chk(mask_logits, 'mask')], 0)             # (432,h,w)
+    om = torch.zeros((448, h, w), device=x.device, dtype=torch.float32)
+    om[ref >= 0] = src[ref[ref >= 0]]
+    om = om.permute(1, 2, 0).contiguous()
+    wp = pack_conv3x3(weight)
+    out = torch.empty_like(x)
+    fx = _chk(flow[0], 'flow') if flow is not None else None
+    fy = _chk(flow[1], 'flow') if flow is not None else None
+    _native.check(L.pnp_dcn_nhwc_f32(_ptr(x), _ptr(om), _ptr(fx), _ptr(fy), _ptr(wp), _ptr(_chk(bias, 'bias')), _ptr(out),
+                                     h, w, _stream()), 'pnp_dcn_nhwc_f32')
+    return out

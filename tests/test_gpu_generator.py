@@ -149,3 +149,23 @@ def test_per_frame_base_qp_values_are_honoured():
         ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, c['lq'], c['QPs'], c['slices'], c['mvs'],
                                         c['base_QPs'], c['partitions'])
     assert float((out - ref).abs().max()) < TOL
+
+
+@pytest.mark.parametrize('deform', ['basic', 'fvc'])
+def test_deformable_aligners_vs_oracle(deform):
+    """deform='basic'|'fvc' (iconvsr_ipb.py:19-22): flow-guided modulated deformable alignment.  Not used
+    by the shipped configs; parity is against the oracle's restatement of mmcv's op (unpinned)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, deform=deform)
+    sd_np = gu.syn.make_state_dict(cfg, seed=71, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=710, n=1, t=3, h=64, w=72, slices='IBBBP', block=4, mv_range=16)
+    m = build(cfg, sd_np)
+    assert 'deform_align.conv_offset.2.weight' in m.state_dict()
+    out = run(m, clip).cpu()
+    c = {k: torch.from_numpy(v) for k, v in clip.items()}
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, c['lq'], c['QPs'], c['slices'], c['mvs'],
+                                        c['base_QPs'], c['partitions'])
+        vos = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), dict(cfg, deform='vos'), c['lq'], c['QPs'],
+                                        c['slices'], c['mvs'], c['base_QPs'], c['partitions'])
+    assert float((ref - vos).abs().max()) > 1e-3          # the aligner matters in this case
+    assert float((out - ref).abs().max()) < TOL

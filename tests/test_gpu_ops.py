@@ -276,3 +276,27 @@ def test_rasteriser_720p_wraparound_and_overwrite_order_vs_oracle():
     assert np.array_equal(mvs.cpu().numpy(), rm)
     assert np.array_equal(par.cpu().numpy(), rp)
     assert (rm[3, 2:] != 0).any() and (rm[0, 2:] != 0).any()      # P frames painted the previous anchors
+
+
+@pytest.mark.parametrize('with_flow', [False, True])
+def test_modulated_deform_conv_vs_oracle(with_flow):
+    """DCN aligner core (deform = basic | fvc).  Parity is against the oracle's restatement of the mmcv
+    semantics (mmcv itself is not vendored by the reference -> unpinned), incl. samples leaving the frame."""
+    from pnp_vcve_amd import ops
+    h, w = 40, 56
+    x = gu.syn.uniform(21, 'x', (1, 64, h, w), -1, 1)
+    off = gu.syn.uniform(21, 'off', (1, 288, h, w), -3.0, 3.0)
+    off[:, :, :4] *= 8.0                                     # top rows: far out of frame
+    off[:, ::7] = np.round(off[:, ::7])                      # some exactly integer offsets
+    ml = gu.syn.uniform(21, 'm', (1, 144, h, w), -2.0, 2.0)
+    wt = gu.syn.uniform(21, 'w', (64, 64, 3, 3), -0.06, 0.06)
+    b = gu.syn.uniform(21, 'b', (64,), -0.1, 0.1)
+    flow = gu.syn.uniform(21, 'fl', (1, 2, h, w), -4.0, 4.0)
+    T = torch.from_numpy
+    offset_ref = T(off)
+    if with_flow:                                            # iconvsr_mv.py:77
+        offset_ref = offset_ref + T(flow).flip(1).repeat(1, 144, 1, 1)
+    ref = cpu_ref.modulated_deform_conv2d(T(x), offset_ref, torch.sigmoid(T(ml)), T(wt), T(b), 16)
+    out = ops.modulated_deform_conv_nhwc(ops.nchw_to_nhwc(G(x))[0], G(off[0]), G(ml[0]), G(wt), G(b),
+                                         flow=G(flow[0]) if with_flow else None)
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < 5e-5

@@ -32,6 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_schema_equals_reference_state_dict():
     from pnp_vcve_amd.generator import IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par as Gen
     for over in ({}, dict(vsr=True), dict(with_cat=False), dict(one_layer=False), dict(with_se=False),
+                 dict(deform='basic'), dict(deform='fvc'),
                  dict(with_bias=False, with_se=False, num_experts=4, num_blocks=3)):
         cfg = dict(syn.DEFAULT_GENERATOR_CFG)
         cfg.update(over)

@@ -34,12 +34,15 @@ def main():
     fx = (torch.randint(-32, 33, (h // 8, w // 8), device=dev).float() / 4).repeat_interleave(8, 0).repeat_interleave(8, 1).contiguous()
     fy = (torch.randint(-32, 33, (h // 8, w // 8), device=dev).float() / 4).repeat_interleave(8, 0).repeat_interleave(8, 1).contiguous()
 
+    off = torch.randn(288, h, w, device=dev) * 1.5
+    ml = torch.randn(144, h, w, device=dev)
     variants = {
         'conv K=576 plain': (lambda: ops.conv3x3([x], [pw], bias=bias, act=2), 2 * 576 * 64),
         'conv K=576 +residual (block back)': (lambda: ops.conv3x3([x], [pw], bias=bias, residual=x2), 2 * 576 * 64),
         'conv K=768 +gamma+par+relu (block front)': (lambda: ops.conv3x3([x], [pw], bias=bias, gamma=gamma, packed_w1x1=p1, par=par, act=1), 2 * 768 * 64),
         'input conv K=1755 (lr+3x64)': (lambda: ops.conv3x3([lr4, x, x2, x3], pin, bias=bias, act=2), 2 * 195 * 9 * 64),
         'mv_warp': (lambda: ops.mv_warp_nhwc(x, fx, fy), None),
+        'dcn (deform_groups 16, flow-guided)': (lambda: ops.modulated_deform_conv_nhwc(x, off, ml, wt, bias, flow=torch.stack([fx, fy])), 'dcn'),
     }
     times = {k: [] for k in variants}
     for k, (fn, _) in variants.items():
@@ -56,7 +59,9 @@ def main():
     for k, (fn, fl) in variants.items():
         ts = sorted(times[k])
         med = ts[len(ts) // 2]
-        if fl:
+        if fl == 'dcn':
+            print(f'{k:44s} median {med:9.1f} us  min {ts[0]:9.1f} us  (incl. host-side om permutation in this wrapper)')
+        elif fl:
             print(f'{k:44s} median {med:9.1f} us  min {ts[0]:9.1f} us  {fl * h * w / med / 1e6:7.1f} TFLOP/s')
         else:
             print(f'{k:44s} median {med:9.1f} us  min {ts[0]:9.1f} us  {520.0 * h * w / med / 1e3:7.1f} GB/s')
