@@ -169,3 +169,38 @@ def test_deformable_aligners_vs_oracle(deform):
                                         c['slices'], c['mvs'], c['base_QPs'], c['partitions'])
     assert float((ref - vos).abs().max()) > 1e-3          # the aligner matters in this case
     assert float((out - ref).abs().max()) < TOL
+
+
+def test_long_clip_100_frames_vs_oracle():
+    """the reference evaluates whole 100-frame REDS clips (configs/HR_davis_LR_128x128.py:202): T = 100 keeps
+    100 feature maps live in the workspace, 4 CAA launches, many key frames."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)        # 2 blocks keep the CPU oracle at seconds
+    sd_np = gu.syn.make_state_dict(cfg, seed=88, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=880, n=1, t=100, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=35)
+    out = run(build(cfg, sd_np), clip).cpu()
+    c = {k: torch.from_numpy(v) for k, v in clip.items()}
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, c['lq'], c['QPs'], c['slices'], c['mvs'],
+                                        c['base_QPs'], c['partitions'])
+    assert out.shape == (1, 100, 3, 64, 64)
+    assert float((out - ref).abs().max()) < TOL
+
+
+def test_long_clip_720p_fits_and_runs():
+    """T = 30 at 1280x720: 30 feature slots (7 GB) + inputs; finite output and first/last-frame sanity."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=89)
+    m = build(cfg, sd_np)
+    t, h, w = 30, 720, 1280
+    g = torch.Generator(device='cuda').manual_seed(1)
+    lq = torch.rand(1, t, 3, h, w, device='cuda', generator=g)
+    mvs = (torch.randint(-16, 17, (1, t, 4, h // 8, w // 8), device='cuda', generator=g).float() / 4
+           ).repeat_interleave(8, 3).repeat_interleave(8, 4).contiguous()
+    par = torch.zeros(1, t, 3, h, w, device='cuda')
+    sl = torch.tensor([73.0 if i == 0 else (80.0 if i % 4 == 0 else 66.0) for i in range(t)], device='cuda').view(1, t, 1, 1, 1)
+    qp = torch.full((1, t, 1, 1, 1), 28 / 255.0, device='cuda')
+    bq = torch.full((1, t, 1, 1, 1), 25 / 255.0, device='cuda')
+    with torch.no_grad():
+        out = m(lq, qp, sl, mvs, bq, par)
+    assert out.shape == lq.shape and torch.isfinite(out).all()
+    assert float((out - lq).abs().mean()) < 0.2

@@ -187,3 +187,17 @@ def test_folder_dataset_reads_the_reference_layout(tmp_path):
     rec, rf, _, _, _ = gu.raster_case_inputs(dict(seed=901, h=64, w=64, slices=slices, per_frame=30))
     assert np.array_equal(item['mv_records'].numpy(), rec) and np.array_equal(item['rec_frame'].numpy(), rf)
     assert item['meta']['key'].startswith('011/')
+
+
+def test_clip_prefetcher_preserves_order_and_surfaces_errors():
+    from pnp_vcve_amd.apis import ClipPrefetcher
+    from pnp_vcve_amd.datasets import SyntheticCompressedClipDataset
+    ds = SyntheticCompressedClipDataset(num_clips=4, num_input_frames=2, height=64, width=64)
+    keys = [d['meta'][0]['key'] for d in ClipPrefetcher(ds, [2, 0, 3], 'cpu')]
+    assert [k.split('/')[0] for k in keys] == ['002', '000', '003']
+
+    class Bad(SyntheticCompressedClipDataset):
+        def __getitem__(self, i):
+            raise OSError('disk gone')
+    with pytest.raises(OSError):
+        list(ClipPrefetcher(Bad(num_clips=2), [0], 'cpu'))
