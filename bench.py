@@ -46,11 +46,10 @@ def make_inputs(seed, t, h, w, dev):
 
 
 def gpu_psnr(out, gt):
-    """reference PSNR definition (core/misc.py:51-71 + core/evaluation/metrics.py:200-215), mean over frames."""
-    o = (out.clamp(0, 1) * 255.0).round()
-    g = (gt.clamp(0, 1) * 255.0).round()
-    mse = ((o - g) ** 2).mean(dim=(0, 2, 3, 4))
-    return float((20.0 * torch.log10(255.0 / mse.sqrt())).mean())
+    """reference PSNR definition (core/misc.py:51-71 + core/evaluation/metrics.py:200-215), mean over frames,
+    from the on-device statistic kernel (pnp_psnr_sse_f32)."""
+    from pnp_vcve_amd.ops import psnr_frames
+    return float(psnr_frames(out[0], gt[0]).mean())
 
 
 def cpu_baseline(sd_np, cfg, h, w):
@@ -103,11 +102,14 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
+    backend = os.environ.get('PNP_DIST_BACKEND', 'nccl')     # 'nccl' is RCCL on ROCm; 'gloo' only for 1-GPU dry runs
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    cdev = dev if backend == 'nccl' else torch.device('cpu')   # where the tiny collective payloads live
 
     from pnp_vcve_amd import synthetic as syn
     from pnp_vcve_amd.registry import build_backbone
@@ -140,7 +142,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
     elapsed_max = float(et.item())
@@ -149,7 +151,7 @@ def main():
 
     # per-rank metrics, gathered with one small collective (PSNR, frames/s): mmedit/apis/test.py:211-233
     psnr = gpu_psnr(out, a['gt'])
-    mine = torch.tensor([psnr, args.steps * T / elapsed], dtype=torch.float64, device=dev)
+    mine = torch.tensor([psnr, args.steps * T / elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         allm = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allm, mine)
@@ -165,8 +167,9 @@ def main():
             'value': frames / elapsed_max, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed_max / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{T}x3x{h}x{w} clip per GPU per step (BASELINE configs[2] shape), full BAE+CAA '
-                                   f'forward, config HR_davis_LR_128x128 generator, seeded random weights',
+            'config': {'workload': f'{T}x3x{h}x{w} clip per GPU per step '
+                                   f'({dict(**{"720p": "BASELINE configs[2] shape", "128": "BASELINE configs[0-1] shape", "lr180": "BASELINE configs[4] LR shape"})[args.workload]}), '
+                                   f'full BAE+CAA forward, config HR_davis_LR_128x128 generator, seeded random weights',
                        'parallelism': f'clip-sharded replicas x{world}', 'frames_per_step_per_gpu': T},
             'psnr_per_rank': [float(x) for x in allm[:, 0]],
             'frames_per_s_per_rank': [float(x) for x in allm[:, 1]],
