@@ -35,3 +35,7 @@ enum { CONV_CFG_BIG = 0,    // 8x16 pixel tile, 64 output channels per block
 // grid_y > 1 only for out_mode 1 (4 sub-pixel images).
 int launch_conv3x3(const ConvArgs& a, int cfg, int grid_y, hipStream_t stream);
 int conv_pick_cfg(int H, int W);
+
+// persistent single-source variant (conv_persist.hip)
+bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y);
+int launch_conv3x3_persist(const ConvArgs& a, hipStream_t stream);

@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     const int ec = lane % CW, ep = lane / CW;
     const int n0 = lane & 31;
     const bool rowwise = a.out_mode < 2 || a.out_mode == 4;
+    // activation as ONE slope for negative values (a per-element runtime switch compiles to scalar branches)
+    const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
 
     // ---- epilogue operands are fetched EARLY (right behind the first halo-tile loads) so their
     //      latency hides under the K loop; the residual may alias `out` element-for-element.
@@ -351,8 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[j][r];
-                if (a.act == 1) v = fmaxf(v, 0.f);
-                else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
+                v = fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f);     // branch-free none / relu / leaky-relu
                 sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (NT * 32) + j * 32 + n0] = v;
             }
         asm volatile("" ::: "memory");      // keep the row reads below behind the column writes above
@@ -380,8 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
                 const int gy = ty0 + 2 * wm + (mm >> 4), gx = tx0 + (mm & 15);
                 if (gy >= H || gx >= W || co >= 3) continue;
                 float v = acc[j][r];
-                if (a.act == 1) v = fmaxf(v, 0.f);
-                else if (a.act == 2) v = v > 0.f ? v : 0.1f * v;
+                v = fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f);     // branch-free none / relu / leaky-relu
                 float base;
                 if (a.out_mode == 2) {
                     base = a.lr[co * a.lr_plane + (long)gy * W + gx];
@@ -453,6 +453,7 @@ int launch_conv3x3(const ConvArgs& a, int cfg, int grid_y, hipStream_t stream) {
         if (a.src_c[s] != 64 && a.src_c[s] != 4) return PNP_ERR_BAD_ARG;
         if (s > 0 && a.src_c[s] != 64) return PNP_ERR_BAD_ARG;   // the RGB frame may only be source 0
     }
+    if (conv_persist_eligible(a, cfg, grid_y)) return launch_conv3x3_persist(a, stream);
     switch (cfg) {
         case CONV_CFG_BIG: return launch_cfg<4, 1, 2, 2>(a, grid_y, stream);
         case CONV_CFG_SMALL: return launch_cfg<2, 2, 1, 2>(a, grid_y, stream);

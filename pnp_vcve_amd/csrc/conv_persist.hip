@@ -1,0 +1,365 @@
+// Persistent variant of the fused 3x3 conv (conv_mfma.hip) for its dominant case: ONE 64-channel source,
+// 64 output channels, frames with >= 1024 tiles -- i.e. the 16 BAE-block convs per frame and conv_hr, ~88 % of
+// the device time of a 720p clip.
+//
+// Why: the r01 timeline (tools/trace_conv.py) shows a block spending ~20 k cycles per 8x16 tile waiting for
+// its halo tile (prologue) against ~41 k cycles of MFMA work, so the two blocks of a CU alternate instead of
+// both feeding the matrix pipe.  Here a block walks a strip of tiles and requests the NEXT tile's halo into
+// registers during the LAST weight chunk of the current tile; after the epilogue it only has to drop those
+// registers into LDS.  Weight chunks keep streaming round-robin (chunk 0 of the next tile follows the last
+// chunk of this one), epilogue operands of the next tile are requested right after this tile's stores.
+//
+// Same arithmetic, same K order, same LDS layouts as conv_mfma.hip: results are bit-identical to it.
+#include "conv_mfma.h"
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+
+namespace {
+
+template <int N>
+using T = std::integral_constant<int, N>;
+
+constexpr int TH = 8, TW = 16, PW = 18, PIX = (TH + 2) * PW, PSTR = 17, NT = 2, NTB = 2;
+constexpr int CH4 = PNP_CHUNK_Q * NTB * 64;
+constexpr int LDS_BYTES = (PIX * PSTR + 2 * CH4) * 16;
+constexpr int AIT = (PIX * 16 + 255) / 256;
+constexpr int BPT = CH4 / 256;
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+template <bool PAR>
+__global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f32x4* sA = reinterpret_cast<f32x4*>(smem_raw);
+    f32x4* sB = sA + PIX * PSTR;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave;
+    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ntiles = tiles_x * ((H + TH - 1) / TH);
+
+    // ---- this block's strip: XCD x (blocks b with b % 8 == x) owns a contiguous band of tiles, the
+    //      band is dealt round-robin to the XCD's resident blocks (halo rows / weights stay in its L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int bq = ntiles >> 3, br = ntiles & 7;
+    const int xbeg = xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq;
+    const int xend = xbeg + bq + (xcd < br ? 1 : 0);
+    int tile = xbeg + slot;
+    if (tile >= xend) return;
+
+    int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+
+    // activation as ONE slope for negative values (a runtime switch per element compiles to ~10 scalar
+    // branch instructions per accumulator register -- 28 k cycles of epilogue in the first timeline)
+    const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    constexpr int CW = NT * 8, PPI = 64 / CW, EIT = 32 / PPI;
+    const int ec = lane % CW, ep = lane / CW;
+    const int n0 = lane & 31;
+
+    // Per-tile index arithmetic reads the thread/lane id through `tq`/`lq`, which are laundered through an
+    // empty asm once per tile: otherwise LICM hoists ~100 VGPRs of tile-invariant indices out of the strip
+    // loop and the kernel spills.
+    int tq = t, lq = lane;
+    float bco[NT], gco[NT], pv[3] = {0.f, 0.f, 0.f};
+    f32x4 res4[EIT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        bco[j] = a.bias ? a.bias[j * 32 + n0] : 0.f;
+        gco[j] = a.gamma ? a.gamma[j * 32 + n0] : 1.f;
+    }
+    auto prefetch_tile_operands = [&](int y0, int x0) {
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            const int p = (lq / CW) + i * PPI;
+            const int gy = y0 + 2 * wm + (p >> 4), gx = x0 + (p & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a.residual && gy < H && gx < W)
+                v = *reinterpret_cast<const f32x4*>(a.residual + ((long)gy * W + gx) * 64 + (lq % CW) * 4);
+            res4[i] = v;
+        }
+        if (PAR) {
+            const int gy = y0 + 2 * wm + my, gx = x0 + mx;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                pv[jj] = (gy < H && gx < W) ? a.par[jj * a.par_plane + (long)gy * W + gx] : 0.f;
+        }
+    };
+
+    f32x4 breg[BPT];
+    auto load_b = [&](const f32x4* g) {
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) breg[i] = g[tq + 256 * i];     // tq: see below (not hoistable)
+    };
+    auto store_b = [&](int buf) {
+        f32x4* d = sB + buf * CH4;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) d[tq + 256 * i] = breg[i];
+    };
+    const int bofs = lane;
+
+    f32x4 areg[AIT];
+    const float* sp = a.src[0];
+    // Per-tile index arithmetic reads the thread/lane id through `tq`/`lq`, which are laundered through an
+    // empty asm once per tile: otherwise LICM hoists ~100 VGPRs of tile-invariant indices out of the strip
+    // loop and the kernel spills.
+
+    // branch-free (clamped address + select) so that the loads form ONE basic block and can be dealt into
+    // the MFMA gaps of the chunk that issues them
+    auto stage_load = [&](int y0, int x0) {
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int i = tq + 256 * k;
+            const int pix = (i >> 4) < PIX ? (i >> 4) : PIX - 1, c16 = i & 15;
+            const int ry = pix / PW, rx = pix - ry * PW;
+            const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int cy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy), cx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            const unsigned off = ((unsigned)(cy * W + cx) * 64u + (unsigned)c16 * 4u) * 4u;   // < 4 GiB per map
+            f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sp) + off);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            areg[k] = inb ? v : z;
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int i = tq + 256 * k;
+            if (i < PIX * 16) sA[(i >> 4) * PSTR + (i & 15)] = areg[k];
+        }
+    };
+
+    const f32x4* a_lane = sA + ((2 * wm + my) * PW + mx) * PSTR + h;
+    auto a_wide = [&](int tap, int q) -> f32x4 {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        return a_lane[(dy * PW + dx) * PSTR + 2 * q];
+    };
+
+    const f32x4* wb = reinterpret_cast<const f32x4*>(a.wsrc[0]);
+    const f32x4* wp = PAR ? reinterpret_cast<const f32x4*>(a.wpar) : nullptr;
+
+    f32x16 acc[NT];
+    int cbuf = 0;
+    f32x4 av, bv[NT];
+    int nty0 = 0, ntx0 = 0;          // next tile of the strip (valid when has_next)
+    bool has_next = false;
+
+    // KIND 0: 3x3 tap TAP; 2: 1x1 branch (centre tap, A scaled by ps).  NEXT_TAP < 0: nothing of sA is read
+    // after this chunk's barrier.  PF: this is the tile's last chunk -> request the next tile's halo.
+    auto run_chunk = [&](auto kind_c, auto tap_c, auto ntap_c, auto pf_c, float ps, const f32x4* next) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr int TAP = decltype(tap_c)::value;
+        constexpr int NEXT_TAP = decltype(ntap_c)::value;
+        constexpr bool PF = decltype(pf_c)::value != 0;
+        const f32x4* bb = sB + cbuf * CH4 + bofs;
+        const f32x4* bn_base = sB + (cbuf ^ 1) * CH4 + bofs;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f32x4 an = av, bn[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bn[j] = bv[j];
+            if (q == 7) __syncthreads();
+            if (q == 0 && next) load_b(next);
+            if (PF && q == 1) stage_load(nty0, ntx0);     // (the current tile again when the strip ends)
+            if (q < 7) {
+                an = a_wide(TAP, q + 1);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bn[j] = bb[((q + 1) * NTB + j) * 64];
+            } else if (next) {
+                if (NEXT_TAP >= 0) an = a_wide(NEXT_TAP, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bn[j] = bn_base[j * 64];
+            }
+            f32x4 ax = av;
+            if (KIND == 2) ax *= ps;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mfma32(ax[kk], bv[j][kk], acc[j]);
+            if (q == 6 && next) store_b(cbuf ^ 1);
+#pragma unroll
+            for (int g = 0; g < 1 + NT; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int g = 0; g < BPT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            if (PF && q == 1) {
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {      // spread the 12 halo loads over the remaining MFMA gaps
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+                }
+            }
+            if (q == 6) {
+#pragma unroll
+                for (int g = 0; g < BPT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            av = an;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = bn[j];
+        }
+        cbuf ^= 1;
+    };
+    using K0 = T<0>;
+    using K2 = T<2>;
+
+    unsigned long long dbg_k = 0, dbg_e = 0, dbg_h = 0, dbg_t0 = 0, dbg_a = 0;
+    int dbg_n = 0;
+    if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memtime();
+    // ---- prologue for the first tile of the strip
+    __builtin_amdgcn_s_setprio(3);
+    stage_load(ty0, tx0);
+    load_b(wb);
+    prefetch_tile_operands(ty0, tx0);
+    stage_store();
+    store_b(0);
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+
+    for (;;) {
+        asm volatile("" : "+v"(tq), "+v"(lq));
+        if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
+        const int ntile = tile + nslots;
+        has_next = ntile < xend;
+        nty0 = has_next ? (ntile / tiles_x) * TH : ty0;
+        ntx0 = has_next ? (ntile % tiles_x) * TW : tx0;
+        // chunk 0 of the NEXT tile follows this tile's last chunk in the weight stream
+        const f32x4* wrap = has_next ? wb : nullptr;
+
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        av = a_wide(0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = sB[cbuf * CH4 + bofs + j * 64];
+
+        run_chunk(K0{}, T<0>{}, T<1>{}, T<0>{}, 1.f, wb + 1L * CH4);
+        run_chunk(K0{}, T<1>{}, T<2>{}, T<0>{}, 1.f, wb + 2L * CH4);
+        run_chunk(K0{}, T<2>{}, T<3>{}, T<0>{}, 1.f, wb + 3L * CH4);
+        run_chunk(K0{}, T<3>{}, T<4>{}, T<0>{}, 1.f, wb + 4L * CH4);
+        run_chunk(K0{}, T<4>{}, T<5>{}, T<0>{}, 1.f, wb + 5L * CH4);
+        run_chunk(K0{}, T<5>{}, T<6>{}, T<0>{}, 1.f, wb + 6L * CH4);
+        run_chunk(K0{}, T<6>{}, T<7>{}, T<0>{}, 1.f, wb + 7L * CH4);
+        run_chunk(K0{}, T<7>{}, T<8>{}, T<0>{}, 1.f, wb + 8L * CH4);
+        if constexpr (PAR) {
+            run_chunk(K0{}, T<8>{}, T<4>{}, T<0>{}, 1.f, wp);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+            run_chunk(K2{}, T<4>{}, T<4>{}, T<0>{}, pv[0], wp + 1L * CH4);
+            run_chunk(K2{}, T<4>{}, T<4>{}, T<0>{}, pv[1], wp + 2L * CH4);
+            run_chunk(K2{}, T<4>{}, T<-1>{}, T<1>{}, pv[2], wrap);
+        } else {
+            run_chunk(K0{}, T<8>{}, T<-1>{}, T<1>{}, 1.f, wrap);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+        }
+
+        unsigned long long dbg_b = 0, dbg_c = 0;
+        if (a.dbg) {
+            dbg_b = __builtin_amdgcn_s_memtime();
+            dbg_k += dbg_b - dbg_a;
+            ++dbg_n;
+        }
+        // ---- epilogue of this tile: transpose through the wave's slice of sA (free: every wave passed the
+        //      last chunk's barrier after its final A read), whole 256-B pixel rows to HBM
+        __builtin_amdgcn_s_setprio(3);
+        float* sT = reinterpret_cast<float*>(sA) + wave * (32 * NT * 32);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[j][r];
+                v = fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f);     // branch-free none / relu / leaky-relu
+                sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (NT * 32) + j * 32 + n0] = v;
+            }
+        asm volatile("" ::: "memory");
+        const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            const int p = (lq / CW) + i * PPI;
+            const int gy = ty0 + 2 * wm + (p >> 4), gx = tx0 + (p & 15);
+            const f32x4 v = sT4[p * CW + (lq % CW)] + res4[i];
+            if (gy < H && gx < W) *reinterpret_cast<f32x4*>(a.out + ((long)gy * W + gx) * 64 + (lq % CW) * 4) = v;
+        }
+        if (a.dbg) {
+            dbg_c = __builtin_amdgcn_s_memtime();
+            dbg_e += dbg_c - dbg_b;
+        }
+        if (!has_next) break;
+        // ---- hand over to the next tile: its halo is already in registers
+        __syncthreads();                 // all transposes done: sA may be overwritten
+        stage_store();
+        tile = ntile;
+        ty0 = nty0;
+        tx0 = ntx0;
+        prefetch_tile_operands(ty0, tx0);
+        __syncthreads();                 // halo visible
+        __builtin_amdgcn_s_setprio(0);
+        if (a.dbg) dbg_h += __builtin_amdgcn_s_memtime() - dbg_c;
+    }
+    if (a.dbg && t == 0) {
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 16;
+        d[0] = dbg_t0;
+        d[1] = dbg_k;
+        d[2] = dbg_e;
+        d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+        d[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+        d[6] = dbg_h;
+        d[7] = dbg_n;
+    }
+}
+
+}  // namespace
+
+static int g_persist_mode = -1;      // -1: from the environment (PNP_NO_PERSIST), 0 off, 1 on
+// Diagnostic switch (not part of include/pnpvcve.h): lets tests compare the two kernels bit for bit.
+extern "C" void pnp_debug_set_persist(int mode) { g_persist_mode = mode; }
+
+bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y) {
+    static const bool env_off = getenv("PNP_NO_PERSIST") != nullptr;
+    if (g_persist_mode == 0 || (g_persist_mode < 0 && env_off)) return false;
+    const long tiles = (long)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    return cfg == CONV_CFG_BIG && grid_y == 1 && a.nsrc == 1 && a.src_c[0] == 64 && a.out_mode == 0 && tiles >= 1024;
+}
+
+int launch_conv3x3_persist(const ConvArgs& a, hipStream_t stream) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    static int grid = 512;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_persist_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_persist_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        grid = 2 * cus;                 // two resident blocks per CU (LDS-limited)
+        grid -= grid % 8;
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    if (a.wpar) hipLaunchKernelGGL(conv3x3_persist_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(conv3x3_persist_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
+    return (int)hipGetLastError();
+}

@@ -300,3 +300,37 @@ def test_modulated_deform_conv_vs_oracle(with_flow):
     out = ops.modulated_deform_conv_nhwc(ops.nchw_to_nhwc(G(x))[0], G(off[0]), G(ml[0]), G(wt), G(b),
                                          flow=G(flow[0]) if with_flow else None)
     assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < 5e-5
+
+
+@pytest.mark.parametrize('hw', [(256, 512), (260, 516), (720, 1280)])
+def test_persistent_conv_is_bit_identical_to_the_tile_per_block_kernel(hw):
+    """frames with >= 1024 tiles run the persistent kernel (conv_persist.hip): same arithmetic in the same
+    order as conv_mfma.hip, so plain / residual (in place) / gamma+par variants must match bit for bit."""
+    import ctypes
+    from pnp_vcve_amd import _native, ops
+    L = _native.lib()
+    L.pnp_debug_set_persist.argtypes = [ctypes.c_int]
+    L.pnp_debug_set_persist.restype = None
+    h, w = hw
+    x = torch.randn(h, w, 64, device=dev())
+    r = torch.randn(h, w, 64, device=dev())
+    wt = torch.randn(64, 64, 3, 3, device=dev()) * 0.05
+    pw = ops.pack_conv3x3(wt)
+    p1 = ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev()) * 0.1 for _ in range(3)])
+    bias = torch.randn(64, device=dev()) * 0.1
+    gamma = torch.rand(64, device=dev()) * 2
+    par = torch.rand(3, h, w, device=dev())
+    variants = [dict(bias=bias, act=2), dict(bias=bias, residual=r, act=0),
+                dict(bias=bias, gamma=gamma, packed_w1x1=p1, par=par, act=1)]
+    try:
+        for kw in variants:
+            L.pnp_debug_set_persist(0)
+            a = ops.conv3x3([x], [pw], **kw)
+            L.pnp_debug_set_persist(1)
+            b = ops.conv3x3([x], [pw], **kw)
+            assert torch.equal(a, b), sorted(kw)
+    finally:
+        L.pnp_debug_set_persist(-1)
+    ref = F.leaky_relu(F.conv2d(x[:64, :96].permute(2, 0, 1).unsqueeze(0).cpu(), wt.cpu(), bias.cpu(), padding=1), 0.1)
+    got = ops.conv3x3([x], [pw], bias=bias, act=2)[:63, :95].permute(2, 0, 1).unsqueeze(0)
+    assert maxdiff(got, ref[..., :63, :95]) < TOL_CONV * 4
