@@ -183,10 +183,11 @@ def main():
             conv_ms = cb['ms'] + ci['ms'] + ch['ms']
             conv_fl = cb['work'] + ci['work'] + ch['work']
             ach = cb['work'] / (cb['ms'] * 1e-3) / 1e12 if cb['ms'] > 0 else 0.0
-            res['roofline'] = {'kernel': 'conv3x3_mfma_kernel (64->64 BAE block convs, fp32 MFMA 32x32x2)',
+            res['roofline'] = {'kernel': 'conv3x3_persist_kernel<PAR> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2; '
+                                         'conv3x3_mfma_kernel below 1024 tiles)',
                                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                               'traffic': pmc.get('conv3x3_mfma_kernel<4,1,2,2>', {}).get('hbm_bytes_per_launch'),
+                               'traffic': (pmc.get('conv3x3_persist_kernel', pmc.get('conv3x3_mfma_kernel<4,1,2,2>', {}))).get('hbm_bytes_per_launch'),
                                'traffic_source': pmc_src,
                                'launches': cb['launches'], 'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
                                'all_convs_TFLOPs': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,

@@ -132,6 +132,14 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_chann
 int pnp_psnr_sse_f32(const float* a_dev, const float* b_dev, unsigned long long* sse_dev, int frames,
                      int c, int h, int w, int crop_border, void* stream);
 
+/* SSIM statistic (mmedit/core/evaluation/metrics.py:266-355: per channel, 11x11 Gaussian sigma 1.5, 'valid'
+ * window, fp64, on the uint8-rounded frames).  Writes one partial sum of the SSIM map per 16x32 tile:
+ * partials_dev [frames*c][pnp_ssim_blocks(h,w,crop)] doubles; SSIM(frame) = mean over channels of
+ * sum(partials) / ((h-2crop-10)(w-2crop-10)). */
+int pnp_ssim_blocks(int h, int w, int crop_border);
+int pnp_ssim_partials_f32(const float* a_dev, const float* b_dev, double* partials_dev, int frames, int c, int h,
+                          int w, int crop_border, void* stream);
+
 /* Modulated deformable 3x3 conv, 64 -> 64 channels, deform_groups 16 (mmcv.ops.modulated_deform_conv2d as
  * called at mmedit/models/backbones/sr_backbones/iconvsr_mv.py:38-41,81-84; semantics restated, mmcv is not
  * vendored).  x_dev (h,w,64) pixel-major; om_dev (h,w,448): conv_offset[2] output (pre-sigmoid masks) in the

@@ -54,6 +54,8 @@ SIGNATURES = {
     'pnp_dcn_nhwc_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_void_p]),
     'pnp_dcn_ref_channel': (c_int, [c_int]),
+    'pnp_ssim_blocks': (c_int, [c_int, c_int, c_int]),
+    'pnp_ssim_partials_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_conv3x3_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
 }

@@ -188,3 +188,23 @@ def modulated_deform_conv_nhwc(x, offset, mask_logits, weight, bias, flow=None):
     _native.check(L.pnp_dcn_nhwc_f32(_ptr(x), _ptr(om), _ptr(fx), _ptr(fy), _ptr(wp), _ptr(_chk(bias, 'bias')), _ptr(out),
                                      h, w, _stream()), 'pnp_dcn_nhwc_f32')
     return out
+
+
+def ssim_frames(a, b, crop_border=0):
+    """Per-frame SSIM with the reference's definition (metrics.py:266-355), computed on the GPU in fp64.
+    a, b: (..., c, h, w); returns a float64 CPU tensor of the leading shape."""
+    a, b = _chk(a, 'a'), _chk(b, 'b')
+    if a.shape != b.shape:
+        raise AssertionError(f'Image shapes are different: {tuple(a.shape)}, {tuple(b.shape)}.')
+    c, h, w = a.shape[-3:]
+    frames = a.numel() // (c * h * w)
+    L = _native.lib()
+    nb = int(L.pnp_ssim_blocks(h, w, int(crop_border)))
+    if nb < 1:
+        raise ValueError('frames are smaller than the 11x11 SSIM window')
+    part = torch.empty((frames * c, nb), dtype=torch.float64, device=a.device)
+    _native.check(L.pnp_ssim_partials_f32(_ptr(a), _ptr(b), _ptr(part), frames, c, h, w, int(crop_border), _stream()),
+                  'pnp_ssim_partials_f32')
+    n = (h - 2 * crop_border - 10) * (w - 2 * crop_border - 10)
+    per_plane = part.sum(dim=1) / n
+    return per_plane.reshape(frames, c).mean(dim=1).cpu().reshape(a.shape[:-3])

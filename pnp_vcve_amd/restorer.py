@@ -83,6 +83,11 @@ class BasicVSR(nn.Module):
                 per_frame = psnr_frames(output[0].float(), gt[0].float().to(output.device), crop_border)
                 eval_result[metric] = float(per_frame.mean())
                 continue
+            if metric == 'SSIM' and convert_to is None and output.is_cuda and output.ndim == 5:
+                from .ops import ssim_frames           # pnp_ssim_partials_f32 (fp64 on the GPU)
+                per_frame = ssim_frames(output[0].float(), gt[0].float().to(output.device), crop_border)
+                eval_result[metric] = float(per_frame.mean())
+                continue
             if output.ndim == 5:
                 avg = []
                 for i in range(output.size(1)):

@@ -334,3 +334,17 @@ def test_persistent_conv_is_bit_identical_to_the_tile_per_block_kernel(hw):
     ref = F.leaky_relu(F.conv2d(x[:64, :96].permute(2, 0, 1).unsqueeze(0).cpu(), wt.cpu(), bias.cpu(), padding=1), 0.1)
     got = ops.conv3x3([x], [pw], bias=bias, act=2)[:63, :95].permute(2, 0, 1).unsqueeze(0)
     assert maxdiff(got, ref[..., :63, :95]) < TOL_CONV * 4
+
+
+@pytest.mark.parametrize('crop', [0, 2])
+def test_ssim_on_device_matches_host_definition(crop):
+    from pnp_vcve_amd import ops
+    from pnp_vcve_amd.metrics import ssim, tensor2img
+    a = torch.rand(3, 3, 45, 77)
+    b = (a + 0.08 * torch.randn_like(a))
+    b[2] = a[2]
+    got = ops.ssim_frames(a.to(dev()), b.to(dev()), crop)
+    for i in range(3):
+        ref = ssim(tensor2img(a[i]), tensor2img(b[i]), crop)
+        assert abs(float(got[i]) - ref) < 1e-10, (i, float(got[i]), ref)
+    assert abs(float(got[2]) - 1.0) < 1e-12

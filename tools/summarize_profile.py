@@ -7,7 +7,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ('conv3x3_mfma_kernel', 'mv_warp_nhwc_kernel', 'flow_warp_nchw_kernel', 'pack_weights_kernel',
+    for k in ('conv3x3_persist_kernel', 'conv3x3_mfma_kernel', 'dcn_mfma_kernel', 'mv_warp_nhwc_kernel', 'psnr_sse_kernel', 'flow_warp_nchw_kernel', 'pack_weights_kernel',
               'pack_lr_kernel', 'caa_predict_kernel', 'mix_bias_kernel'):
         if k in name:
             if k == 'conv3x3_mfma_kernel':
