@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
     const int bq = ntiles >> 3, br = ntiles & 7;
     const int xbeg = xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq;
     const int xend = xbeg + bq + (xcd < br ? 1 : 0);
+    // (a per-XCD atomic ticket queue instead of these static strips was measured: blocks then take 12..16 tiles
+    //  instead of 14..15 but the kernel time does not move -- the CU's tile rate, not the tail, sets it)
     int tile = xbeg + slot;
     if (tile >= xend) return;
 
@@ -147,14 +149,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
     f32x4 av, bv[NT];
     int nty0 = 0, ntx0 = 0;          // next tile of the strip (valid when has_next)
     bool has_next = false;
+    // output rows of the PREVIOUS tile, already transposed (+ residual), waiting to be stored from inside the
+    // current tile's first chunk -- no VMEM instruction is issued in the serial hand-over between two tiles
+    f32x4 orow[EIT];
+    bool have_rows = false;
+    int oy0 = 0, ox0 = 0;
+    auto store_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            const int p = (lq / CW) + i * PPI;
+            const int gy = oy0 + 2 * wm + (p >> 4), gx = ox0 + (p & 15);
+            if (gy < H && gx < W) *reinterpret_cast<f32x4*>(a.out + ((long)gy * W + gx) * 64 + (lq % CW) * 4) = orow[i];
+        }
+    };
 
     // KIND 0: 3x3 tap TAP; 2: 1x1 branch (centre tap, A scaled by ps).  NEXT_TAP < 0: nothing of sA is read
-    // after this chunk's barrier.  PF: this is the tile's last chunk -> request the next tile's halo.
+    // after this chunk's barrier.  ROLE bit 0: the tile's last chunk -> request the next tile's halo;
+    // bit 1: first chunk -> store the previous tile's rows; bit 2: second chunk -> request residual / par.
     auto run_chunk = [&](auto kind_c, auto tap_c, auto ntap_c, auto pf_c, float ps, const f32x4* next) {
         constexpr int KIND = decltype(kind_c)::value;
         constexpr int TAP = decltype(tap_c)::value;
         constexpr int NEXT_TAP = decltype(ntap_c)::value;
-        constexpr bool PF = decltype(pf_c)::value != 0;
+        constexpr int ROLE = decltype(pf_c)::value;
+        constexpr bool PF = (ROLE & 1) != 0;
         const f32x4* bb = sB + cbuf * CH4 + bofs;
         const f32x4* bn_base = sB + (cbuf ^ 1) * CH4 + bofs;
         __builtin_amdgcn_sched_barrier(0);
@@ -166,6 +183,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
             if (q == 7) __syncthreads();
             if (q == 0 && next) load_b(next);
             if (PF && q == 1) stage_load(nty0, ntx0);     // (the current tile again when the strip ends)
+            if ((ROLE & 2) && q == 1 && have_rows) store_rows();
+            if ((ROLE & 4) && q == 1) prefetch_tile_operands(ty0, tx0);
             if (q < 7) {
                 an = a_wide(TAP, q + 1);
 #pragma unroll
@@ -218,14 +237,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
     using K0 = T<0>;
     using K2 = T<2>;
 
-    unsigned long long dbg_k = 0, dbg_e = 0, dbg_h = 0, dbg_t0 = 0, dbg_a = 0;
+    unsigned long long dbg_k = 0, dbg_e = 0, dbg_h = 0, dbg_t0 = 0, dbg_a = 0, dbg_p[6] = {0, 0, 0, 0, 0, 0};
     int dbg_n = 0;
     if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memtime();
     // ---- prologue for the first tile of the strip
     __builtin_amdgcn_s_setprio(3);
     stage_load(ty0, tx0);
     load_b(wb);
-    prefetch_tile_operands(ty0, tx0);
     stage_store();
     store_b(0);
     __syncthreads();
@@ -249,8 +267,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
 #pragma unroll
         for (int j = 0; j < NT; ++j) bv[j] = sB[cbuf * CH4 + bofs + j * 64];
 
-        run_chunk(K0{}, T<0>{}, T<1>{}, T<0>{}, 1.f, wb + 1L * CH4);
-        run_chunk(K0{}, T<1>{}, T<2>{}, T<0>{}, 1.f, wb + 2L * CH4);
+        run_chunk(K0{}, T<0>{}, T<1>{}, T<2>{}, 1.f, wb + 1L * CH4);
+        run_chunk(K0{}, T<1>{}, T<2>{}, T<4>{}, 1.f, wb + 2L * CH4);
         run_chunk(K0{}, T<2>{}, T<3>{}, T<0>{}, 1.f, wb + 3L * CH4);
         run_chunk(K0{}, T<3>{}, T<4>{}, T<0>{}, 1.f, wb + 4L * CH4);
         run_chunk(K0{}, T<4>{}, T<5>{}, T<0>{}, 1.f, wb + 5L * CH4);
@@ -293,29 +311,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
                 sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (NT * 32) + j * 32 + n0] = v;
             }
         asm volatile("" ::: "memory");
+        unsigned long long dbg_x = 0;
+        if (a.dbg) {
+            dbg_x = __builtin_amdgcn_s_memtime();
+            dbg_p[0] += dbg_x - dbg_b;
+        }
+        // rows back into registers (+ residual); they are stored from inside the next tile's first chunk
         const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
 #pragma unroll
-        for (int i = 0; i < EIT; ++i) {
-            const int p = (lq / CW) + i * PPI;
-            const int gy = ty0 + 2 * wm + (p >> 4), gx = tx0 + (p & 15);
-            const f32x4 v = sT4[p * CW + (lq % CW)] + res4[i];
-            if (gy < H && gx < W) *reinterpret_cast<f32x4*>(a.out + ((long)gy * W + gx) * 64 + (lq % CW) * 4) = v;
-        }
+        for (int i = 0; i < EIT; ++i) orow[i] = sT4[((lq / CW) + i * PPI) * CW + (lq % CW)] + res4[i];
+        have_rows = true;
+        oy0 = ty0;
+        ox0 = tx0;
         if (a.dbg) {
             dbg_c = __builtin_amdgcn_s_memtime();
             dbg_e += dbg_c - dbg_b;
         }
-        if (!has_next) break;
-        // ---- hand over to the next tile: its halo is already in registers
-        __syncthreads();                 // all transposes done: sA may be overwritten
+        if (!has_next) {
+            store_rows();
+            break;
+        }
+        // ---- hand over to the next tile: its halo is already in registers; no VMEM instruction here
+        __syncthreads();                 // all transposes read back: sA may be overwritten
+        unsigned long long dbg_y = 0;
+        if (a.dbg) {
+            dbg_y = __builtin_amdgcn_s_memtime();
+            dbg_p[1] += dbg_y - dbg_c;
+        }
         stage_store();
+        if (a.dbg) {
+            const unsigned long long z = __builtin_amdgcn_s_memtime();
+            dbg_p[2] += z - dbg_y;
+            dbg_y = z;
+        }
         tile = ntile;
         ty0 = nty0;
         tx0 = ntx0;
-        prefetch_tile_operands(ty0, tx0);
+        if (a.dbg) {
+            const unsigned long long z = __builtin_amdgcn_s_memtime();
+            dbg_p[3] += z - dbg_y;
+            dbg_y = z;
+        }
         __syncthreads();                 // halo visible
         __builtin_amdgcn_s_setprio(0);
-        if (a.dbg) dbg_h += __builtin_amdgcn_s_memtime() - dbg_c;
+        if (a.dbg) {
+            const unsigned long long z = __builtin_amdgcn_s_memtime();
+            dbg_p[4] += z - dbg_y;
+            dbg_h += z - dbg_c;
+        }
     }
     if (a.dbg && t == 0) {
         unsigned long long* d = a.dbg + (size_t)blockIdx.x * 16;
@@ -327,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
         d[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
         d[6] = dbg_h;
         d[7] = dbg_n;
+        for (int i = 0; i < 5; ++i) d[8 + i] = dbg_p[i];
     }
 }
 

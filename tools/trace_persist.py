@@ -33,4 +33,7 @@ print('blocks', (n > 0).sum(), 'tiles/block min/max', n.min(), n.max())
 for name, v in (('block total', tot), ('K loop / tile', d[:, 1] / n), ('epilogue / tile', d[:, 2] / n),
                 ('hand-over / tile', d[:, 6] / np.maximum(n - 1, 1)), ('total / tile', tot / n)):
     print(f'{name:20s} mean {v.mean():10.0f}  p10 {np.percentile(v, 10):10.0f}  p90 {np.percentile(v, 90):10.0f}  max {v.max():10.0f}')
+for i, nm in enumerate(['epi: act+transpose writes', 'hand: barrier 1', 'hand: halo regs -> LDS', 'hand: operand prefetch issue', 'hand: barrier 2']):
+    v = d[:, 8 + i] / np.maximum(n - (0 if i == 0 else 1), 1)
+    print(f'  {nm:28s} mean {v.mean():10.0f}  p10 {np.percentile(v, 10):10.0f}  p90 {np.percentile(v, 90):10.0f}')
 print('kernel span (cycles)', d[:, 3].max() - d[:, 0].min())
