@@ -204,3 +204,36 @@ def test_long_clip_720p_fits_and_runs():
         out = m(lq, qp, sl, mvs, bq, par)
     assert out.shape == lq.shape and torch.isfinite(out).all()
     assert float((out - lq).abs().mean()) < 0.2
+
+
+def test_randomised_configs_and_shapes_vs_oracle():
+    """12 seeded random draws over the constructor switches, clip length, frame size, slice pattern and batch
+    size -- every draw against the pinned oracle (the reference's own option space)."""
+    rng = np.random.RandomState(20261002)
+    for trial in range(12):
+        with_bias = bool(rng.randint(2))
+        with_se = with_bias and bool(rng.randint(2))
+        cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG,
+                   num_blocks=int(rng.randint(1, 4)), num_experts=int(rng.choice([2, 6, 10])),
+                   with_cat=bool(rng.randint(2)), align_key=bool(rng.randint(2)), vsr=bool(rng.randint(4) == 0),
+                   expert_softmax=bool(rng.randint(2)), with_bias=with_bias, with_se=with_se,
+                   use_base_qp=True if with_bias else bool(rng.randint(2)),
+                   one_layer=bool(rng.randint(2)), channel_first=bool(rng.randint(2)),
+                   deform=str(rng.choice(['vos', 'vos', 'basic', 'fvc'])))
+        n, t = int(rng.choice([1, 1, 2])), int(rng.randint(1, 6))
+        h, w = 64 + 4 * int(rng.randint(0, 6)), 64 + 4 * int(rng.randint(0, 10))
+        pattern = [73] + [int(rng.choice([66, 66, 80, 73])) for _ in range(t - 1)]
+        sd_np = gu.syn.make_state_dict(cfg, seed=1000 + trial, par_gain=10.0)
+        clip = gu.syn.make_clip(seed=2000 + trial, n=n, t=t, h=h, w=w, slices=pattern, block=4,
+                                qp_mode=str(rng.choice(['qp', 'ipb'])), crf=[15, 35][:n] if n > 1 else 25,
+                                par_scale=float(rng.choice([1 / 255.0, 1.0])))
+        out = run(build(cfg, sd_np), clip).cpu()
+        c = {k: torch.from_numpy(v) for k, v in clip.items()}
+        with torch.no_grad():
+            ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, c['lq'], c['QPs'], c['slices'],
+                                            c['mvs'], c['base_QPs'], c['partitions'])
+        # some draws (par = 1 with the 10x partition gain, two dynamic layers) blow the activations up to 1e8 in
+        # the reference itself: the gate is relative to the output scale
+        scale = max(1.0, float(ref.abs().max()))
+        d = float((out - ref).abs().max()) / scale
+        assert out.shape == ref.shape and d < TOL, (trial, cfg, (n, t, h, w), pattern, d, scale)
