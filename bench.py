@@ -94,6 +94,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='720p', choices=sorted(WORKLOADS))
     ap.add_argument('--frames', type=int, default=7)
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
+                    help="fp16 = BASELINE configs[4]'s opt-in 'fp16 MFMA convs' (fp16 operands, fp32 accumulate and "
+                         "feature maps); the headline metric is the default fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-kernel HIP-event timing')
     args = ap.parse_args()
@@ -118,6 +121,7 @@ def main():
     m = build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     m = m.to(dev).eval()
+    m.fp16_enabled = args.precision == 'fp16'
 
     h, w = WORKLOADS[args.workload]
     T = args.frames
@@ -166,7 +170,9 @@ def main():
                       else f'enhanced frames/sec ({w}x{h}, {T}-frame window)',
             'value': frames / elapsed_max, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed_max / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'fp32' else 'f16 MFMA operands, f32 accumulate / feature maps (opt-in)',
+            'data': 'synthetic',
             'config': {'workload': f'{T}x3x{h}x{w} clip per GPU per step '
                                    f'({dict(**{"720p": "BASELINE configs[2] shape", "128": "BASELINE configs[0-1] shape", "lr180": "BASELINE configs[4] LR shape"})[args.workload]}), '
                                    f'full BAE+CAA forward, config HR_davis_LR_128x128 generator, seeded random weights',
@@ -193,6 +199,19 @@ def main():
                                'all_convs_TFLOPs': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                                'device_ms_per_step': {'conv_block': cb['ms'] / args.steps, 'conv_input': ci['ms'] / args.steps,
                                                       'conv_head': ch['ms'] / args.steps, 'mv_warp': wp['ms'] / args.steps}}
+            if args.precision == 'fp16':
+                # At the fp16 matrix rate the block convs are HBM-bound: price them in bytes.  Per frame the kind holds
+                # 16 front halves (read x, write o, 3 partition planes), 16 back halves (read o, read x, write) and conv_hr.
+                nb = 2 * cfg['num_blocks']
+                bytes_frame = h * w * (nb * (512 + 12) + nb * 768 + 512)
+                gbs = bytes_frame * T * args.steps / (cb['ms'] * 1e-3) / 1e9 if cb['ms'] > 0 else 0.0
+                res['roofline'] = {'kernel': 'conv3x3_f16_kernel<PAR,LR4> (64->64 BAE-block convs + conv_hr; fp16 MFMA 32x32x16, '
+                                             'weights resident in LDS, persistent strips)',
+                                   'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                   'frac': gbs / PEAK_HBM_GBS, 'traffic': None, 'launches': cb['launches'],
+                                   'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
+                                   'matrix_TFLOPs': ach, 'matrix_peak_TFLOPs': 2500.0,
+                                   'device_ms_per_step': res['roofline']['device_ms_per_step']}
             if wp['launches']:
                 gbs = wp['work'] / (wp['ms'] * 1e-3) / 1e9
                 res['roofline_mv_warp'] = {'kernel': 'mv_warp_nhwc_kernel (MV-guided bilinear alignment)', 'bound': 'hbm',

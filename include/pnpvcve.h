@@ -5,7 +5,7 @@
  * /root/reference).  All pointers named *_dev are device (HBM) addresses owned by the
  * caller; the library allocates no device memory, launches asynchronously on the supplied
  * stream (a hipStream_t passed as void*) and returns 0 on success, a hipError_t value, or
- * one of the PNP_ERR_* codes.  fp32 throughout.  No global state: every call is re-entrant.
+ * one of the PNP_ERR_* codes.  fp32 throughout unless PNP_PREC_F16 is selected.  No global state: every call is re-entrant.
  */
 #ifndef PNPVCVE_H
 #define PNPVCVE_H
@@ -51,6 +51,16 @@ int64_t pnp_generator_param_dim(const pnp_generator* g, int i, int d);
 int64_t pnp_generator_param_offset(const pnp_generator* g, int i);
 int64_t pnp_generator_flat_floats(const pnp_generator* g);
 int64_t pnp_generator_packed_floats(const pnp_generator* g);
+
+/* Arithmetic of the 64-channel convs (BASELINE configs[4]; mmcv's wrap_fp16_model / fp16_enabled switch,
+ * mmedit/models/restorers/basic_restorer.py:64 @auto_fp16).  PNP_PREC_F32 (default): exact fp32 MFMA.
+ * PNP_PREC_F16: activations and weights rounded to fp16 as MFMA operands, fp32 accumulation, fp32 feature
+ * maps in HBM; conv_last and an RGB-only input conv stay fp32.  Set it BEFORE sizing/packing: it changes
+ * pnp_generator_packed_floats and pnp_generator_workspace_bytes. */
+#define PNP_PREC_F32 0
+#define PNP_PREC_F16 1
+int pnp_generator_set_precision(pnp_generator* g, int precision);
+int pnp_generator_get_precision(const pnp_generator* g);
 
 /* flat (reference layouts) -> packed (MFMA B images); replaces nothing in the reference,
  * it is the checkpoint-load-time half of mmcv load_checkpoint (iconvsr.py:510-523). */
@@ -123,6 +133,16 @@ int pnp_pack_conv1x1_f32(const float* w_dev, float* dst_dev, void* stream);
 int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_channels,
                     const float* const* packed_w_dev, const float* bias_dev, const float* gamma_dev,
                     const float* packed_w1x1_dev, const float* par_dev, const float* residual_dev,
+                    int act, float* out_dev, int h, int w, void* stream);
+
+/* The same op with fp16 MFMA operands (fp32 sources, accumulation and output): packed_w_f16 are fp16 images
+ * made by pnp_f16_image_from_f32 from the fp32 images above (nchunks = 9 per 64-channel source, 1 per RGB0
+ * source, 3 for the 1x1 branches; same element count, so nchunks * 8192 bytes).  At least one source must
+ * have 64 channels; several 64-channel sources exclude gamma / residual; otherwise PNP_ERR_UNSUPPORTED. */
+int pnp_f16_image_from_f32(const float* packed_w_dev, void* dst_dev, int nchunks, void* stream);
+int pnp_conv3x3_f16(int nsrc, const float* const* srcs_dev, const int* src_channels,
+                    const void* const* packed_w_f16_dev, const float* bias_dev, const float* gamma_dev,
+                    const void* packed_w1x1_f16_dev, const float* par_dev, const float* residual_dev,
                     int act, float* out_dev, int h, int w, void* stream);
 
 /* Per-frame sum of squared differences of the uint8-rounded frames (the statistic behind

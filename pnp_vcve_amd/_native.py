@@ -36,6 +36,8 @@ SIGNATURES = {
     'pnp_generator_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       POINTER(c_float), POINTER(c_float), POINTER(c_float),
                                       c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'pnp_generator_set_precision': (c_int, [c_void_p, c_int]),
+    'pnp_generator_get_precision': (c_int, [c_void_p]),
     'pnp_generator_profile': (c_int, [c_void_p, c_int]),
     'pnp_generator_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),
                                            POINTER(ctypes.c_double)]),
@@ -57,6 +59,9 @@ SIGNATURES = {
     'pnp_ssim_blocks': (c_int, [c_int, c_int, c_int]),
     'pnp_ssim_partials_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_conv3x3_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'pnp_f16_image_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'pnp_conv3x3_f16': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
 }
 

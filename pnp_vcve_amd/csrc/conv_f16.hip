@@ -1,0 +1,500 @@
+// fp16-operand variant of the fused 3x3 conv (BASELINE configs[4], "fp16 MFMA convs"): the same op as
+// conv_mfma.hip -- same sources, same epilogue, fp32 feature maps in HBM, fp32 accumulation -- with the
+// A (activation) and B (weight) operands rounded to fp16 on their way into LDS and contracted by
+// v_mfma_f32_32x32x16_f16 (16x the fp32 matrix rate).  Opt-in (pnp_generator_set_precision); the fp32
+// kernels stay the default and the parity reference.
+//
+// At this MFMA rate the conv is HBM-bound (a 128-pixel tile moves 64..96 KB and needs ~1 us of matrix
+// pipe), so the kernel is organised around memory, not around the K loop:
+//   * persistent: one 256-thread block per CU walks a strip of 8x16 tiles of its XCD's band;
+//   * ALL weights of the launch live in LDS for the block's lifetime (9 taps x 64 x 64 fp16 = 72 KiB,
+//     + 24 KiB for the three 1x1 partition branches or 6 KiB for the RGB source) -- no weight streaming,
+//     so the K loop has no barrier and its only traffic is LDS reads (3 ds_read_b128 per 2 MFMAs);
+//   * the halo tile of tile i+2 is requested (fp32, registers) as soon as the halo of tile i+1 has been
+//     converted into LDS, the residual / partition values of tile i+1 right after tile i's stores:
+//     ~110 KB are in flight per CU for a whole tile period;
+//   * the accumulator tile is transposed through a per-wave LDS slice and stored as whole 256-B pixel rows.
+//
+// LDS map (bytes):  A tile 10 rows x 2816 (18 px x 144 B, row stride = 0 mod 256: every ds_read_b128 of
+// the K loop is conflict-free) | B 73728 | X 24576 (par branches or RGB-source weights) | T 32768
+// (4 waves x 32 px x 64 ch fp32) | L 1440 (RGB halo, 4 x fp16 per pixel)  = 160672 <= 163840.
+//
+// fp16 image of a weight chunk (made by f16_image_kernel from the fp32 "B image" of common.h): 1-KiB
+// units [k-step s][n-tile][lane][8], lane (n, h) holding input channels 16 s + 8 h + 0..7 of output
+// channel 32 nt + n -- the B fragment of v_mfma_f32_32x32x16_f16 -- so a fragment is ONE lane-linear
+// ds_read_b128 and the global image is copied to LDS verbatim.
+#include "conv_mfma.h"
+#include <mutex>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 16, PW = 18, PSB = 144, RSB = 2816;
+constexpr int NPIX = (TH + 2) * PW;               // 180 halo pixels
+constexpr int A_BYTES = (TH + 2) * RSB;           // 28160
+constexpr int UNIT = 1024;
+constexpr int B_BYTES = 9 * 4 * 2 * UNIT;         // 73728
+constexpr int X_BYTES = 3 * 4 * 2 * UNIT;         // 24576
+constexpr int T_BYTES = 4 * 32 * 64 * 4;          // 32768
+constexpr int L_BYTES = NPIX * 8;                 // 1440
+constexpr int OFF_B = A_BYTES, OFF_X = OFF_B + B_BYTES, OFF_T = OFF_X + X_BYTES, OFF_L = OFF_T + T_BYTES;
+constexpr int LDS_BYTES = OFF_L + L_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int AIT = (NPIX * 16 + 255) / 256;      // float4 halo loads per thread
+
+struct F16Args {
+    const float* src;       // NHWC64 fp32
+    const _Float16* w;      // 72 units per blockIdx.y
+    const float* lr4;       // NHWC4 fp32 (RGB0) or nullptr
+    const _Float16* wlr;    // 8 units (k = 4*tap + channel; the first 6 are read)
+    const _Float16* wpar;   // 24 units or nullptr
+    const float* par;
+    long par_plane;
+    const float* bias;
+    const float* gamma;
+    const float* residual;
+    float* out;
+    long w_ystride;         // halfs
+    int bias_ystride;
+    int res_pre;            // residual is added BEFORE the activation (partial sum of a K-split launch chain)
+    int H, W, act, out_mode, out_cstride;
+    unsigned long long* dbg;
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for
+// the halo / residual prefetches this kernel deliberately keeps in flight across tiles.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Every per-pixel global access goes through a buffer descriptor: an out-of-image lane gets the offset OOB,
+// which the hardware range check turns into "load 0" / "drop the store" -- zero padding, ragged tiles and an
+// absent residual (a descriptor of 0 bytes) cost no branch, so a tile's body is one basic block and the
+// compiler's vmcnt bookkeeping stays exact across the prefetches in flight.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    // readfirstlane: the size must be provably wave-uniform or every access becomes a waterfall loop
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
+}
+
+__device__ __forceinline__ h4 to_h4(f32x4 v) {
+    // saturate instead of overflowing to inf (a single out-of-range activation would poison the frame)
+    v = __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x4)(-65504.f)), (f32x4)(65504.f));
+    return __builtin_convertvector(v, h4);
+}
+
+template <bool PAR, bool LR4>
+__global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
+    static_assert(!(PAR && LR4), "the X region holds either the par branches or the RGB weights");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ntiles = tiles_x * ((H + TH - 1) / TH);
+    const int yimg = blockIdx.y;
+
+    // strip: XCD x (blocks with blockIdx.x % 8 == x) owns a contiguous band of tiles, dealt round-robin
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int bq = ntiles >> 3, br = ntiles & 7;
+    const int xbeg = xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq;
+    const int xend = xbeg + bq + (xcd < br ? 1 : 0);
+    int tile = xbeg + slot;
+    if (tile >= xend) return;
+
+    unsigned long long dbg_t0 = 0, dbg_k = 0, dbg_e = 0, dbg_h = 0, dbg_w = 0, dbg_p[4] = {0, 0, 0, 0};
+    int dbg_n = 0;
+    if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memtime();
+
+    // ---- halo staging (fp32 registers -> fp16 LDS)
+    f32x4 areg[AIT], lreg = {0.f, 0.f, 0.f, 0.f};
+    const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;       // < 4 GiB per feature map
+    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, map_bytes);
+    const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(LR4 ? a.lr4 : a.src, LR4 ? map_bytes / 16 : 0);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? a.residual : a.src, a.residual ? map_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
+    // Tile-invariant parts of the halo addressing, once per thread: float4 slot i = t + 256 k is channel quad
+    // i & 15 of halo pixel i >> 4.  Rows above / below the image need no test (the offset leaves the
+    // descriptor's range by itself); columns left / right of it would wrap into the neighbouring row.
+    unsigned hrel[AIT];
+    int hrx[AIT], hlds[AIT];
+#pragma unroll
+    for (int k = 0; k < AIT; ++k) {
+        const int i = t + 256 * k;
+        const int pix = i >> 4, c16 = i & 15;
+        const int ry = pix / PW, rx = pix - ry * PW;
+        hrel[k] = ((unsigned)(ry * W + rx) * 64u + (unsigned)c16 * 4u) * 4u;
+        hrx[k] = pix < NPIX ? rx : 0x4000;          // slots past the tile: never in range
+        hlds[k] = ry * RSB + rx * PSB + c16 * 8;
+    }
+    unsigned lrel = 0;
+    int lrx = 0x4000;
+    if (LR4) {
+        const int ry = t / PW, rx = t - ry * PW;
+        lrel = (unsigned)(ry * W + rx) * 16u;
+        lrx = t < NPIX ? rx : 0x4000;
+    }
+    // `live` false: a strip's last tile has no successor -- every offset is out of range, nothing is fetched
+    auto stage_load = [&](int y0, int x0, bool live) {
+        const unsigned hbase = (unsigned)((y0 - 1) * W + (x0 - 1)) * 256u;
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const bool ok = live & ((unsigned)(x0 - 1 + hrx[k]) < (unsigned)W);
+            areg[k] = buf_load4(r_src, ok ? hbase + hrel[k] : OOB);
+        }
+        if (LR4) {
+            const bool ok = live & ((unsigned)(x0 - 1 + lrx) < (unsigned)W);
+            lreg = buf_load4(r_lr, ok ? (unsigned)((y0 - 1) * W + (x0 - 1)) * 16u + lrel : OOB);
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < AIT; ++k)
+            if (hrx[k] < PW) *reinterpret_cast<h4*>(smem + hlds[k]) = to_h4(areg[k]);
+        if (LR4 && t < NPIX) *reinterpret_cast<h4*>(smem + OFF_L + t * 8) = to_h4(lreg);
+    };
+
+    // ---- epilogue geometry: a lane owns 16 B (4 channels) of one pixel row per iteration
+    constexpr int EIT = 8;
+    const int ec = lane & 15, ep = lane >> 4;
+    const int n0 = lane & 31;
+    const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    const float k_pre = a.res_pre ? 1.f : 0.f, k_post = 1.f - k_pre;
+
+    float bco[2], gco[2], pv[3] = {0.f, 0.f, 0.f};
+    f32x4 res4[EIT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bco[j] = a.bias ? a.bias[yimg * a.bias_ystride + j * 32 + n0] : 0.f;
+        gco[j] = a.gamma ? a.gamma[j * 32 + n0] : 1.f;
+    }
+    // rows of the wave's 2 x 16 pixel slice: iteration i is pixel row i >> 2, column (lane >> 4) + 4 (i & 3)
+    const unsigned row_bytes = (unsigned)W * 256u;
+    auto prefetch_tile_operands = [&](int y0, int x0) {
+        const unsigned rbase = ((unsigned)((y0 + 2 * wave) * W + x0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            const bool ok = x0 + ep + 4 * (i & 3) < W;
+            res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
+        }
+        if (PAR) {
+            const int gy = y0 + 2 * wave + my, gx = x0 + mx;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                pv[jj] = buf_load1(r_par, ((gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+        }
+    };
+    // output addressing of the three row-wise modes as one affine form (uniform scalars, no per-store switch)
+    //   byte offset of output pixel (gy, gx) = gy * o_sy + gx * o_sx + o_c0  (+ 16 B per float4 of the row)
+    unsigned o_sy, o_sx, o_c0;
+    __amdgpu_buffer_rsrc_t r_out;
+    {
+        const int o_mul = a.out_mode == 1 ? 2 : 1;
+        const unsigned o_pix = (a.out_mode == 4 ? (unsigned)a.out_cstride : 64u) * 4u;      // bytes per output pixel
+        const unsigned o_row = (unsigned)(o_mul * W) * o_pix;
+        o_sy = (unsigned)__builtin_amdgcn_readfirstlane((int)(o_mul * o_row));
+        o_sx = (unsigned)__builtin_amdgcn_readfirstlane((int)(o_mul * o_pix));
+        o_c0 = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)(a.out_mode == 1 ? (yimg >> 1) * o_row + (yimg & 1) * o_pix : (a.out_mode == 4 ? 256u * (unsigned)yimg : 0u)));
+        r_out = make_rsrc(a.out, (unsigned)(o_mul * H) * o_row);
+    }
+
+    int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    int ntile = tile + nslots;
+    bool has_next = ntile < xend;
+
+    // ---- prologue: first halo + operands requested, then the weights (global fp16 image -> LDS verbatim)
+    stage_load(ty0, tx0, true);
+    prefetch_tile_operands(ty0, tx0);
+    {
+        const f32x4* g = reinterpret_cast<const f32x4*>(a.w + (long)yimg * a.w_ystride);
+        f32x4* d = reinterpret_cast<f32x4*>(smem + OFF_B);
+#pragma unroll
+        for (int i = 0; i < B_BYTES / 16 / 256; ++i) d[t + 256 * i] = g[t + 256 * i];
+        if (PAR) {
+            const f32x4* gp = reinterpret_cast<const f32x4*>(a.wpar);
+            f32x4* dp = reinterpret_cast<f32x4*>(smem + OFF_X);
+#pragma unroll
+            for (int i = 0; i < X_BYTES / 16 / 256; ++i) dp[t + 256 * i] = gp[t + 256 * i];
+        }
+        if (LR4) {
+            const f32x4* gp = reinterpret_cast<const f32x4*>(a.wlr);
+            f32x4* dp = reinterpret_cast<f32x4*>(smem + OFF_X);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (t + 256 * i < 6 * UNIT / 16) dp[t + 256 * i] = gp[t + 256 * i];
+        }
+    }
+    stage_store();
+    stage_load((ntile / tiles_x) * TH, (ntile % tiles_x) * TW, has_next);
+    lds_barrier();
+
+    const char* a_lane = smem + (2 * wave + my) * RSB + mx * PSB + 16 * h;
+    const char* b_lane = smem + OFF_B + lane * 16;
+    const char* x_lane = smem + OFF_X + lane * 16;
+    // RGB source: k = 16 s + 8 h + j  ->  tap 4 s + 2 h + (j >> 2), channel j & 3; taps beyond 8 carry zero
+    // weights and re-read tap 8 (finite values)
+    int l_off[3][2];
+    if (LR4) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int tap = 4 * s + 2 * h + u;
+                tap = tap > 8 ? 8 : tap;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                l_off[s][u] = OFF_L + ((2 * wave + my + dy) * PW + mx + dx) * 8;
+            }
+    }
+    float* sT = reinterpret_cast<float*>(smem + OFF_T) + wave * 2048;
+
+    for (;;) {
+        unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0;
+        if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+        // ---- K loop: no barrier, no global traffic of its own.  Fragments are fetched DEPTH k-steps ahead of
+        //      the MFMAs that use them (the compiler's own schedule keeps ~1 step in flight and stalls on LDS
+        //      latency: 3600 instead of 2300 cycles per tile); sched_barrier pins one fetch group per MFMA pair.
+        constexpr int NS = 36 + (LR4 ? 3 : 0) + (PAR ? 12 : 0), DEPTH = 4;     // 3 * DEPTH <= 15 (lgkmcnt)
+        h8 fa[DEPTH], fb0[DEPTH], fb1[DEPTH];
+        auto fetch = [&](int k) {       // k is a compile-time constant after unrolling
+            const int sl = k % DEPTH;
+            if (k < 36) {
+                const int tap = k >> 2, sk = k & 3, dy = tap / 3, dx = tap - dy * 3;
+                fa[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
+                fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 0) * UNIT);
+                fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 1) * UNIT);
+            } else if (LR4) {
+                const int sk = k - 36;
+                const h4 lo = *reinterpret_cast<const h4*>(smem + l_off[sk][0]);
+                const h4 hi = *reinterpret_cast<const h4*>(smem + l_off[sk][1]);
+                fa[sl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 0) * UNIT);
+                fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 1) * UNIT);
+            } else {
+                const int q = k - 36;
+                fa[sl] = *reinterpret_cast<const h8*>(a_lane + RSB + PSB + 32 * (q & 3));
+                fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 0) * UNIT);
+                fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 1) * UNIT);
+            }
+        };
+        auto bias_gamma = [&]() {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+        };
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) fetch(k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int sl = k % DEPTH;
+            h8 av = fa[sl];
+            const h8 b0 = fb0[sl], b1 = fb1[sl];
+            if (PAR && k == 36) bias_gamma();       // (conv + bias) * gamma BEFORE the 1x1 partition branches
+            if (PAR && k >= 36) av *= (_Float16)pv[(k - 36) >> 2];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+            if (k + DEPTH < NS) fetch(k + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!PAR) bias_gamma();
+        if (a.dbg) dbg_b = __builtin_amdgcn_s_memtime();
+
+        // ---- epilogue.  Accumulator register r of lane (n0, h) is pixel (r&3) + 8 (r>>2) + 4 h of the wave's
+        //      32-pixel M tile, channel 32 j + n0: transpose through the wave's private LDS slice.
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc[j][r];
+        asm volatile("" ::: "memory");
+        const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+        f32x4 rows[EIT];
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];      // all reads in flight together
+        const unsigned obase = (unsigned)(ty0 + 2 * wave) * o_sy + (unsigned)(tx0 + ep) * o_sx + o_c0 + (unsigned)ec * 16u;
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            f32x4 v = rows[i] + k_pre * res4[i];
+            v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+            v += k_post * res4[i];
+            const bool ok = tx0 + ep + 4 * (i & 3) < W;
+            buf_store4(r_out, ok ? obase + (unsigned)(i >> 2) * o_sy + (unsigned)(i & 3) * 4u * o_sx : OOB, v);
+        }
+        if (a.dbg) {
+            dbg_c = __builtin_amdgcn_s_memtime();
+            dbg_k += dbg_b - dbg_a;
+            dbg_e += dbg_c - dbg_b;
+            ++dbg_n;
+        }
+        if (!has_next) break;
+
+        // ---- hand over: operands of the next tile, its halo into LDS, then request the halo after it
+        tile = ntile;
+        ty0 = (tile / tiles_x) * TH;
+        tx0 = (tile % tiles_x) * TW;
+        prefetch_tile_operands(ty0, tx0);
+        unsigned long long dbg_d = 0, dbg_x = 0;
+        if (a.dbg) dbg_x = __builtin_amdgcn_s_memtime();
+        lds_barrier();                   // every wave is done reading the A tile
+        if (a.dbg) {
+            dbg_d = __builtin_amdgcn_s_memtime();
+            dbg_p[0] += dbg_x - dbg_c;   // operand prefetch issue
+            dbg_p[1] += dbg_d - dbg_x;   // barrier 1
+        }
+        stage_store();                   // waits for the halo requested one tile ago
+        if (a.dbg) {
+            dbg_x = __builtin_amdgcn_s_memtime();
+            dbg_w += dbg_x - dbg_d;
+        }
+        ntile = tile + nslots;
+        has_next = ntile < xend;
+        stage_load((ntile / tiles_x) * TH, (ntile % tiles_x) * TW, has_next);
+        if (a.dbg) {
+            dbg_d = __builtin_amdgcn_s_memtime();
+            dbg_p[2] += dbg_d - dbg_x;   // next-next halo request issue
+        }
+        lds_barrier();
+        if (a.dbg) {
+            dbg_x = __builtin_amdgcn_s_memtime();
+            dbg_p[3] += dbg_x - dbg_d;   // barrier 2
+            dbg_h += dbg_x - dbg_c;
+        }
+    }
+    if (a.dbg && t == 0) {
+        unsigned long long* d = a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
+        d[0] = dbg_t0;
+        d[1] = dbg_k;
+        d[2] = dbg_e;
+        d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+        d[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+        d[6] = dbg_h;
+        d[7] = dbg_n;
+        d[8] = dbg_w;
+        for (int i = 0; i < 4; ++i) d[9 + i] = dbg_p[i];
+    }
+}
+
+// fp32 B image (common.h) -> fp16 image, chunk by chunk: element (s, nt, lane = (h, n), j) of the fp16 chunk is
+// input channel k = 16 s + 8 h + j, i.e. fp32 element ((k >> 3) * NTB + nt, ((k >> 2) & 1) * 32 + n, k & 3).
+__global__ __launch_bounds__(256) void f16_image_kernel(const float* __restrict__ src, _Float16* __restrict__ dst,
+                                                       int ntb, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int per_chunk = PNP_CHUNK_Q * ntb * 256;
+    const long chunk = idx / per_chunk;
+    const int rem = (int)(idx - chunk * per_chunk);
+    const int j = rem & 7, lane = (rem >> 3) & 63, nt = (rem >> 9) % ntb, s = rem / (512 * ntb);
+    const int n = lane & 31, hh = lane >> 5;
+    const int k = 16 * s + 8 * hh + j;
+    const float v = src[chunk * per_chunk + (((k >> 3) * ntb + nt) * 64 + ((k >> 2) & 1) * 32 + n) * 4 + (k & 3)];
+    dst[idx] = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+}
+
+int f16_grid(int grid_y) {
+    static std::once_flag once;
+    static int cus = 256;
+    std::call_once(once, [&] {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    int g = cus / grid_y;
+    g -= g % 8;
+    return g < 8 ? 8 : g;
+}
+
+template <bool PAR, bool LR4>
+int launch_one(const F16Args& fa, int grid_y, hipStream_t stream) {
+    auto kern = conv3x3_f16_kernel<PAR, LR4>;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    hipLaunchKernelGGL(kern, dim3(f16_grid(grid_y), grid_y), dim3(256), LDS_BYTES, stream, fa);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t stream) {
+    if (nchunks < 1 || (ntb != 1 && ntb != 2)) return PNP_ERR_BAD_ARG;
+    const long total = (long)nchunks * pnp_chunk_floats(ntb);
+    hipLaunchKernelGGL(f16_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src,
+                       reinterpret_cast<_Float16*>(dst), ntb, total);
+    return (int)hipGetLastError();
+}
+
+bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
+    if (cfg == CONV_CFG_RGB) return false;
+    if (a.out_mode != 0 && a.out_mode != 1 && a.out_mode != 4) return false;
+    int nwide = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        if (a.src_c[s] == 64) ++nwide;
+        if (!a.wsrc_h[s]) return false;
+    }
+    if (nwide == 0) return false;                        // an RGB-only input conv stays on the fp32 kernel
+    if (nwide > 1 && (a.residual || a.gamma || grid_y != 1 || a.out_mode != 0)) return false;
+    if (a.wpar && (a.nsrc != 1 || !a.wpar_h || grid_y != 1)) return false;
+    return true;
+}
+
+// A conv over several 64-channel sources runs as a chain of single-source launches that accumulate through
+// `out` (fp32, added before the activation of the last link): every link keeps its weights resident in LDS.
+int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
+    int lr_idx = -1, wide[4], nwide = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        if (a.src_c[s] == 4) lr_idx = s;
+        else wide[nwide++] = s;
+    }
+    for (int k = 0; k < nwide; ++k) {
+        const bool first = k == 0, last = k == nwide - 1;
+        F16Args f;
+        f.src = a.src[wide[k]];
+        f.w = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]);
+        f.lr4 = (first && lr_idx >= 0) ? a.src[lr_idx] : nullptr;
+        f.wlr = (first && lr_idx >= 0) ? reinterpret_cast<const _Float16*>(a.wsrc_h[lr_idx]) : nullptr;
+        f.wpar = reinterpret_cast<const _Float16*>(a.wpar ? a.wpar_h : nullptr);
+        f.par = a.par;
+        f.par_plane = a.par_plane;
+        f.bias = first ? a.bias : nullptr;
+        f.gamma = a.gamma;
+        f.residual = first ? (nwide == 1 ? a.residual : nullptr) : a.out;
+        f.res_pre = first ? 0 : 1;
+        f.out = a.out;
+        f.w_ystride = a.w_ystride;
+        f.bias_ystride = a.bias_ystride;
+        f.H = a.H;
+        f.W = a.W;
+        f.act = last ? a.act : 0;
+        f.out_mode = a.out_mode;
+        f.out_cstride = a.out_cstride;
+        f.dbg = a.dbg;
+        int rc;
+        if (f.wpar) rc = launch_one<true, false>(f, grid_y, stream);
+        else if (f.lr4) rc = launch_one<false, true>(f, grid_y, stream);
+        else rc = launch_one<false, false>(f, grid_y, stream);
+        if (rc) return rc;
+    }
+    return PNP_OK;
+}

@@ -9,6 +9,9 @@ struct ConvArgs {
     int src_c[4];           // 64 or 4
     int nsrc;
     const float* wpar;      // 3 chunks (conv16x16, conv16x8, conv8x8) or nullptr
+    const void* wsrc_h[4];  // fp16 twins of wsrc / wpar (conv_f16.hip), read only when prec == 1
+    const void* wpar_h;
+    int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
     const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
     long par_plane;         // floats between planes
     const float* bias;      // [N] or nullptr
@@ -35,6 +38,11 @@ enum { CONV_CFG_BIG = 0,    // 8x16 pixel tile, 64 output channels per block
 // grid_y > 1 only for out_mode 1 (4 sub-pixel images).
 int launch_conv3x3(const ConvArgs& a, int cfg, int grid_y, hipStream_t stream);
 int conv_pick_cfg(int H, int W);
+
+// fp16-operand variant (conv_f16.hip): fp32 B image -> fp16 image (same element count, chunk by chunk)
+int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t stream);
+bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y);
+int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream);
 
 // persistent single-source variant (conv_persist.hip)
 bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y);

@@ -62,6 +62,7 @@ struct ProfRec {
 
 struct pnp_generator {
     pnp_generator_cfg cfg;
+    int prec = PNP_PREC_F32;          // pnp_generator_set_precision
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -96,7 +97,7 @@ struct pnp_generator {
     }
     int64_t add_packed(int64_t n) {
         const int64_t o = packed_floats;
-        packed_floats += (n + 63) & ~int64_t(63);
+        packed_floats += (n + 4095) & ~int64_t(4095);   // whole chunks: the fp16 mirror is made chunk by chunk
         return o;
     }
 };
@@ -269,6 +270,7 @@ struct ProfScope {
 
 struct Workspace {
     float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om;
+    float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 only
     int64_t bytes;
 };
 
@@ -305,6 +307,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     W.gamma = take((int64_t)t * 64);
     W.mixw = take((int64_t)t * g->ndyn * IMG_WIDE);
     W.mixb = take((int64_t)t * g->ndyn * 64);
+    W.mixh = g->prec == PNP_PREC_F16 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
     W.bytes = off;
     return W;
 }
@@ -340,7 +343,17 @@ int pnp_generator_param_ndim(const pnp_generator* g, int i) { return (int)g->par
 int64_t pnp_generator_param_dim(const pnp_generator* g, int i, int d) { return g->params[i].shape[d]; }
 int64_t pnp_generator_param_offset(const pnp_generator* g, int i) { return g->params[i].offset; }
 int64_t pnp_generator_flat_floats(const pnp_generator* g) { return g->flat_floats; }
-int64_t pnp_generator_packed_floats(const pnp_generator* g) { return g->packed_floats; }
+// fp32 images, then (PNP_PREC_F16) their fp16 mirror: element i of the mirror region is element i of the images
+int64_t pnp_generator_packed_floats(const pnp_generator* g) {
+    return g->prec == PNP_PREC_F16 ? g->packed_floats + g->packed_floats / 2 : g->packed_floats;
+}
+
+int pnp_generator_set_precision(pnp_generator* g, int precision) {
+    if (!g || (precision != PNP_PREC_F32 && precision != PNP_PREC_F16)) return PNP_ERR_BAD_ARG;
+    g->prec = precision;
+    return PNP_OK;
+}
+int pnp_generator_get_precision(const pnp_generator* g) { return g ? g->prec : -1; }
 
 int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
@@ -409,6 +422,10 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
                                packed + g->up_bias[u], 256, 256, 1);
         }
     }
+    if (g->prec == PNP_PREC_F16) {   // every region is whole 64-output-channel chunks (the others are never read as fp16)
+        rc = launch_f16_image(packed, packed + g->packed_floats, (int)(g->packed_floats / IMG_CHUNK), 2, st);
+        if (rc) return rc;
+    }
     return (int)hipGetLastError();
 }
 
@@ -433,6 +450,15 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
     const int os = c.vsr ? 4 : 1;
     int rc;
 
+    // fp16 mirror of a weight image that lives in `packed` or in the per-clip expert mixtures
+    const int64_t n_mix = (int64_t)t * g->ndyn * IMG_WIDE;
+    auto twin = [&](const float* p) -> const void* {
+        if (g->prec != PNP_PREC_F16 || !p) return nullptr;
+        if (p >= packed && p < packed + g->packed_floats)
+            return reinterpret_cast<const uint16_t*>(packed + g->packed_floats) + (p - packed);
+        if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixh) + (p - W.mixw);
+        return nullptr;
+    };
     auto conv = [&](int nsrc, const float* const* srcs, const int* sc, const float* const* ws, const float* bias,
                     const float* gamma, const float* wpar, const float* parp, const float* residual, int act,
                     float* dst, int H, int Wd, int mode, int cfgsel, int gy, const float* lrp, long lr_plane,
@@ -440,12 +466,15 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         a.nsrc = nsrc;
+        a.prec = g->prec == PNP_PREC_F16 ? 1 : 0;
         for (int s = 0; s < nsrc; ++s) {
             a.src[s] = srcs[s];
             a.src_c[s] = sc[s];
             a.wsrc[s] = ws[s];
+            a.wsrc_h[s] = twin(ws[s]);
         }
         a.wpar = wpar;
+        a.wpar_h = twin(wpar);
         a.par = parp;
         a.par_plane = (long)H * Wd;
         a.bias = bias;
@@ -592,6 +621,11 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
                 rc = launch_mix_bias(flat + g->dyn_b, W.ew + (int64_t)i * E, W.mixb + (int64_t)u * g->ndyn * 64, E, 64,
                                      g->ndyn, st);
                 if (rc) return rc;
+                if (g->prec == PNP_PREC_F16) {
+                    rc = launch_f16_image(a.dst, reinterpret_cast<uint16_t*>(W.mixh) + (int64_t)u * g->ndyn * IMG_WIDE,
+                                          g->ndyn * 9, 2, st);
+                    if (rc) return rc;
+                }
             }
             uidx[i] = u;
         }
@@ -877,6 +911,42 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels,
     a.out_mode = 0;
     a.dbg = g_conv_dbg;
     return launch_conv3x3(a, conv_pick_cfg(h, w), 1, (hipStream_t)st);
+}
+
+int pnp_f16_image_from_f32(const float* packed_w, void* dst, int nchunks, void* st) {
+    if (!packed_w || !dst) return PNP_ERR_BAD_ARG;
+    return launch_f16_image(packed_w, dst, nchunks, 2, (hipStream_t)st);
+}
+
+int pnp_conv3x3_f16(int nsrc, const float* const* srcs, const int* src_channels, const void* const* packed_w_f16,
+                    const float* bias, const float* gamma, const void* packed_w1x1_f16, const float* par,
+                    const float* residual, int act, float* out, int h, int w, void* st) {
+    if (nsrc < 1 || nsrc > 4) return PNP_ERR_BAD_ARG;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = nsrc;
+    a.prec = 1;
+    for (int s = 0; s < nsrc; ++s) {
+        a.src[s] = srcs[s];
+        a.src_c[s] = src_channels[s];
+        a.wsrc_h[s] = packed_w_f16[s];
+    }
+    a.wpar = reinterpret_cast<const float*>(packed_w1x1_f16);   // only its presence is read on this path
+    a.wpar_h = packed_w1x1_f16;
+    a.par = par;
+    a.par_plane = (long)h * w;
+    a.bias = bias;
+    a.gamma = gamma;
+    a.residual = residual;
+    a.out = out;
+    a.H = h;
+    a.W = w;
+    a.act = act;
+    a.out_mode = 0;
+    a.dbg = g_conv_dbg;
+    if (a.wpar && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
+    if (!conv_f16_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
+    return launch_conv3x3_f16(a, 1, (hipStream_t)st);
 }
 
 }  // extern "C"

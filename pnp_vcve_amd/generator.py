@@ -78,6 +78,22 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         self._pack_key = None
         self._workspace = {}
 
+    # ---------------------------------------------------------------- precision
+    @property
+    def fp16_enabled(self):
+        """mmcv's fp16 switch (wrap_fp16_model sets it; basic_restorer.py:64 @auto_fp16 reads it).  True selects
+        fp16 MFMA operands for the 64-channel convs (pnp_generator_set_precision); default False = exact fp32."""
+        return int(_native.lib().pnp_generator_get_precision(self._handle)) == 1
+
+    @fp16_enabled.setter
+    def fp16_enabled(self, value):
+        L = _native.lib()
+        _native.check(L.pnp_generator_set_precision(self._handle, 1 if value else 0), 'pnp_generator_set_precision')
+        self._packed_floats = int(L.pnp_generator_packed_floats(self._handle))
+        self._flat = self._packed = None        # images and workspace are sized per precision
+        self._pack_key = None
+        self._workspace = {}
+
     # ---------------------------------------------------------------- parameters
     def _register(self, dotted, param):
         mod = self
@@ -122,7 +138,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
 
     def _ensure_packed(self, device):
         params = dict(self.named_parameters())
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params.values())
+        key = (str(device), self._packed_floats) + tuple((p.data_ptr(), p._version) for p in params.values())
         if self._pack_key == key:
             return
         flat = torch.zeros(self._flat_floats, device=device, dtype=torch.float32)

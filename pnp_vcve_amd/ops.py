@@ -115,8 +115,23 @@ def pack_conv1x1(weights):
     return dst
 
 
-def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, residual=None, act=0):
-    """Fused conv over pixel-major sources [(h,w,64) or (h,w,4)].  See include/pnpvcve.h."""
+def f16_image(packed):
+    """fp32 packed weight image (whole chunks) -> fp16 image for conv3x3(..., fp16=True)."""
+    packed = _chk(packed, 'packed')
+    nchunks, rem = divmod(packed.numel(), 4096)
+    if rem:
+        raise ValueError('packed image must be whole 4096-float chunks')
+    dst = torch.empty(packed.numel(), device=packed.device, dtype=torch.float16)
+    _native.check(_native.lib().pnp_f16_image_from_f32(_ptr(packed), ctypes.c_void_p(dst.data_ptr()), nchunks, _stream()),
+                  'pnp_f16_image_from_f32')
+    return dst
+
+
+def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, residual=None, act=0, fp16=False):
+    """Fused conv over pixel-major sources [(h,w,64) or (h,w,4)].  See include/pnpvcve.h.
+    fp16=True: packed_w / packed_w1x1 are f16_image() tensors and the MFMA operands are fp16."""
+    if fp16:
+        return _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act)
     srcs = [_chk(s, 'src') for s in srcs]
     h, w = srcs[0].shape[:2]
     n = len(srcs)
@@ -128,6 +143,24 @@ def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, r
     _native.check(_native.lib().pnp_conv3x3_f32(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]),
                                                 _ptr(keep[3]), _ptr(keep[4]), act, _ptr(out), h, w, _stream()),
                   'pnp_conv3x3_f32')
+    return out
+
+
+def _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act):
+    srcs = [_chk(s, 'src') for s in srcs]
+    for p in list(packed_w) + ([packed_w1x1] if packed_w1x1 is not None else []):
+        if not p.is_cuda or p.dtype != torch.float16 or not p.is_contiguous():
+            raise TypeError('fp16 conv: weight images must be contiguous CUDA float16 tensors (ops.f16_image)')
+    h, w = srcs[0].shape[:2]
+    n = len(srcs)
+    out = torch.empty((h, w, 64), device=srcs[0].device, dtype=torch.float32)
+    sp = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    sc = (ctypes.c_int * n)(*[s.shape[2] for s in srcs])
+    wp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in packed_w])
+    keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, par, residual)]
+    w1 = ctypes.c_void_p(packed_w1x1.data_ptr()) if packed_w1x1 is not None else None
+    _native.check(_native.lib().pnp_conv3x3_f16(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), w1, _ptr(keep[2]),
+                                                _ptr(keep[3]), act, _ptr(out), h, w, _stream()), 'pnp_conv3x3_f16')
     return out
 
 

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Diagnostic: per-block phase sums of the fp16-operand persistent conv kernel (shader-clock stamps)."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pnp_vcve_amd import _native, ops  # noqa: E402
+
+h, w = 720, 1280
+mode = sys.argv[1] if len(sys.argv) > 1 else 'res'
+dev = torch.device('cuda:0')
+x = torch.randn(h, w, 64, device=dev)
+x2 = torch.randn(h, w, 64, device=dev)
+pw = ops.f16_image(ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev) * 0.05))
+p1 = ops.f16_image(ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev) * 0.1 for _ in range(3)]))
+par = (torch.rand(3, h, w, device=dev) > 0.66).float() / 255.0
+bias = torch.randn(64, device=dev) * 0.1
+L = _native.lib()
+L.pnp_debug_set_conv_trace.argtypes = [ctypes.c_void_p]
+L.pnp_debug_set_conv_trace.restype = None
+
+
+def run():
+    if mode == 'res':
+        return ops.conv3x3([x], [pw], bias=bias, residual=x2, fp16=True)
+    if mode == 'par':
+        return ops.conv3x3([x], [pw], bias=bias, packed_w1x1=p1, par=par, act=1, fp16=True)
+    return ops.conv3x3([x], [pw], bias=bias, act=2, fp16=True)
+
+
+for _ in range(3):
+    run()
+dbg = torch.zeros(512 * 16, dtype=torch.int64, device=dev)
+L.pnp_debug_set_conv_trace(ctypes.c_void_p(dbg.data_ptr()))
+run()
+torch.cuda.synchronize()
+L.pnp_debug_set_conv_trace(ctypes.c_void_p(0))
+d = dbg.cpu().numpy().reshape(512, 16)
+d = d[d[:, 7] > 0]
+n = d[:, 7]
+tot = d[:, 3] - d[:, 0]
+print('mode', mode, 'blocks', len(d), 'tiles/block min/max', n.min(), n.max())
+for name, v in (('block total', tot), ('K loop / tile', d[:, 1] / n), ('epilogue / tile', d[:, 2] / n),
+                ('hand-over / tile', d[:, 6] / np.maximum(n - 1, 1)),
+                ('  of which halo wait+cvt+LDS', d[:, 8] / np.maximum(n - 1, 1)), ('total / tile', tot / n)):
+    print(f'{name:30s} mean {v.mean():10.0f}  p10 {np.percentile(v, 10):10.0f}  p90 {np.percentile(v, 90):10.0f}  max {v.max():10.0f}')
+for i, nm in enumerate(['operand prefetch issue', 'barrier 1', 'halo(i+2) request issue', 'barrier 2']):
+    v = d[:, 9 + i] / np.maximum(n - 1, 1)
+    print(f'    {nm:26s} mean {v.mean():10.0f}  p10 {np.percentile(v, 10):10.0f}  p90 {np.percentile(v, 90):10.0f}')
+for xcc in sorted(set(d[:, 5] & 15)):      # the shader clock is per XCD
+    e = d[(d[:, 5] & 15) == xcc]
+    print(f'xcd {xcc}: span {e[:, 3].max() - e[:, 0].min()} cycles, start spread {e[:, 0].max() - e[:, 0].min()}')
