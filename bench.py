@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
                     help="fp16 = BASELINE configs[4]'s opt-in 'fp16 MFMA convs' (fp16 operands, fp32 accumulate and "
                          "feature maps); the headline metric is the default fp32")
+    ap.add_argument('--vsr', action='store_true', help='x4 SR heads (generator vsr=True): output is 4h x 4w')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-kernel HIP-event timing')
     args = ap.parse_args()
@@ -117,6 +118,7 @@ def main():
     from pnp_vcve_amd import synthetic as syn
     from pnp_vcve_amd.registry import build_backbone
     cfg = dict(syn.DEFAULT_GENERATOR_CFG)
+    cfg['vsr'] = bool(args.vsr)
     sd_np = syn.make_state_dict(cfg, seed=2025)
     m = build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
@@ -154,7 +156,10 @@ def main():
     m.profile(False)
 
     # per-rank metrics, gathered with one small collective (PSNR, frames/s): mmedit/apis/test.py:211-233
-    psnr = gpu_psnr(out, a['gt'])
+    gt = a['gt']
+    if args.vsr:        # synthetic HR ground truth: the LR one, nearest-upsampled (only feeds the gathered metric)
+        gt = gt.repeat_interleave(4, -1).repeat_interleave(4, -2).contiguous()
+    psnr = gpu_psnr(out, gt)
     mine = torch.tensor([psnr, args.steps * T / elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         allm = [torch.zeros_like(mine) for _ in range(world)]
@@ -176,6 +181,7 @@ def main():
             'config': {'workload': f'{T}x3x{h}x{w} clip per GPU per step '
                                    f'({dict(**{"720p": "BASELINE configs[2] shape", "128": "BASELINE configs[0-1] shape", "lr180": "BASELINE configs[4] LR shape"})[args.workload]}), '
                                    f'full BAE+CAA forward, config HR_davis_LR_128x128 generator, seeded random weights',
+                       'vsr_x4_heads': bool(args.vsr),
                        'parallelism': f'clip-sharded replicas x{world}', 'frames_per_step_per_gpu': T},
             'psnr_per_rank': [float(x) for x in allm[:, 0]],
             'frames_per_s_per_rank': [float(x) for x in allm[:, 1]],
@@ -203,7 +209,7 @@ def main():
                 # At the fp16 matrix rate the block convs are HBM-bound: price them in bytes.  Per frame the kind holds
                 # 16 front halves (read x, write o, 3 partition planes), 16 back halves (read o, read x, write) and conv_hr.
                 nb = 2 * cfg['num_blocks']
-                bytes_frame = h * w * (nb * (512 + 12) + nb * 768 + 512)
+                bytes_frame = h * w * (nb * (512 + 12) + nb * 768 + (16 if args.vsr else 1) * 512)
                 gbs = bytes_frame * T * args.steps / (cb['ms'] * 1e-3) / 1e9 if cb['ms'] > 0 else 0.0
                 res['roofline'] = {'kernel': 'conv3x3_f16_kernel<PAR,LR4> (64->64 BAE-block convs + conv_hr; fp16 MFMA 32x32x16, '
                                              'weights resident in LDS, persistent strips)',

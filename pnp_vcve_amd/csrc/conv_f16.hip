@@ -42,10 +42,11 @@ constexpr int L_BYTES = NPIX * 8;                 // 1440
 constexpr int OFF_B = A_BYTES, OFF_X = OFF_B + B_BYTES, OFF_T = OFF_X + X_BYTES, OFF_L = OFF_T + T_BYTES;
 constexpr int LDS_BYTES = OFF_L + L_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-constexpr int AIT = (NPIX * 16 + 255) / 256;      // float4 halo loads per thread
+constexpr int AIT32 = (NPIX * 16 + 255) / 256;    // 16-byte halo loads per thread, fp32 source (4 channels each)
+constexpr int AIT16 = (NPIX * 8 + 255) / 256;     //                               fp16 source (8 channels each)
 
 struct F16Args {
-    const float* src;       // NHWC64 fp32
+    const void* src;        // NHWC64, fp32 or (SRC16) fp16
     const _Float16* w;      // 72 units per blockIdx.y
     const float* lr4;       // NHWC4 fp32 (RGB0) or nullptr
     const _Float16* wlr;    // 8 units (k = 4*tap + channel; the first 6 are read)
@@ -55,7 +56,7 @@ struct F16Args {
     const float* bias;
     const float* gamma;
     const float* residual;
-    float* out;
+    void* out;              // fp32, or (OUT16, out_mode 0, no residual) fp16 NHWC64
     long w_ystride;         // halfs
     int bias_ystride;
     int res_pre;            // residual is added BEFORE the activation (partial sum of a K-split launch chain)
@@ -93,9 +94,14 @@ __device__ __forceinline__ h4 to_h4(f32x4 v) {
     return __builtin_convertvector(v, h4);
 }
 
-template <bool PAR, bool LR4>
+// SRC16 / OUT16: the source / the output is an fp16 NHWC64 map.  Used for the intermediate of a BAE block
+// (front half writes it, back half reads it): it is consumed only as an MFMA A operand, i.e. it would be
+// rounded to fp16 by its reader anyway, so storing it rounded is bit-identical and halves its HBM traffic.
+template <bool PAR, bool LR4, bool SRC16, bool OUT16>
 __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
     static_assert(!(PAR && LR4), "the X region holds either the par branches or the RGB weights");
+    constexpr int AIT = SRC16 ? AIT16 : AIT32;
+    constexpr int CPP = SRC16 ? 8 : 16;            // 16-byte slots per halo pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -120,10 +126,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
     // ---- halo staging (fp32 registers -> fp16 LDS)
     f32x4 areg[AIT], lreg = {0.f, 0.f, 0.f, 0.f};
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;       // < 4 GiB per feature map
-    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, map_bytes);
-    const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(LR4 ? a.lr4 : a.src, LR4 ? map_bytes / 16 : 0);
-    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? a.residual : a.src, a.residual ? map_bytes : 0);
-    const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
+    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, SRC16 ? map_bytes / 2 : map_bytes);
+    const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(LR4 ? (const void*)a.lr4 : a.src, LR4 ? map_bytes / 16 : 0);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : a.src, a.residual ? map_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
     // Tile-invariant parts of the halo addressing, once per thread: float4 slot i = t + 256 k is channel quad
     // i & 15 of halo pixel i >> 4.  Rows above / below the image need no test (the offset leaves the
     // descriptor's range by itself); columns left / right of it would wrap into the neighbouring row.
@@ -132,11 +138,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
 #pragma unroll
     for (int k = 0; k < AIT; ++k) {
         const int i = t + 256 * k;
-        const int pix = i >> 4, c16 = i & 15;
+        const int pix = i / CPP, cs = i % CPP;
         const int ry = pix / PW, rx = pix - ry * PW;
-        hrel[k] = ((unsigned)(ry * W + rx) * 64u + (unsigned)c16 * 4u) * 4u;
+        hrel[k] = (unsigned)(ry * W + rx) * (SRC16 ? 128u : 256u) + (unsigned)cs * 16u;
         hrx[k] = pix < NPIX ? rx : 0x4000;          // slots past the tile: never in range
-        hlds[k] = ry * RSB + rx * PSB + c16 * 8;
+        hlds[k] = ry * RSB + rx * PSB + cs * (SRC16 ? 16 : 8);
     }
     unsigned lrel = 0;
     int lrx = 0x4000;
@@ -145,23 +151,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
         lrel = (unsigned)(ry * W + rx) * 16u;
         lrx = t < NPIX ? rx : 0x4000;
     }
-    // `live` false: a strip's last tile has no successor -- every offset is out of range, nothing is fetched
-    auto stage_load = [&](int y0, int x0, bool live) {
-        const unsigned hbase = (unsigned)((y0 - 1) * W + (x0 - 1)) * 256u;
-#pragma unroll
-        for (int k = 0; k < AIT; ++k) {
-            const bool ok = live & ((unsigned)(x0 - 1 + hrx[k]) < (unsigned)W);
-            areg[k] = buf_load4(r_src, ok ? hbase + hrel[k] : OOB);
-        }
-        if (LR4) {
-            const bool ok = live & ((unsigned)(x0 - 1 + lrx) < (unsigned)W);
-            lreg = buf_load4(r_lr, ok ? (unsigned)((y0 - 1) * W + (x0 - 1)) * 16u + lrel : OOB);
-        }
+    // One halo request (slot k of the thread) for the tile at (y0, x0).  `live` false: a strip's last tile has no
+    // successor -- the offset is out of range and nothing is fetched.
+    auto halo_load = [&](int k, int y0, int x0, bool live) {
+        const unsigned hbase = (unsigned)((y0 - 1) * W + (x0 - 1)) * (SRC16 ? 128u : 256u);
+        const bool ok = live & ((unsigned)(x0 - 1 + hrx[k]) < (unsigned)W);
+        areg[k] = buf_load4(r_src, ok ? hbase + hrel[k] : OOB);
+    };
+    auto lr_load = [&](int y0, int x0, bool live) {
+        const bool ok = live & ((unsigned)(x0 - 1 + lrx) < (unsigned)W);
+        lreg = buf_load4(r_lr, ok ? (unsigned)((y0 - 1) * W + (x0 - 1)) * 16u + lrel : OOB);
     };
     auto stage_store = [&]() {
 #pragma unroll
         for (int k = 0; k < AIT; ++k)
-            if (hrx[k] < PW) *reinterpret_cast<h4*>(smem + hlds[k]) = to_h4(areg[k]);
+            if (hrx[k] < PW) {
+                if (SRC16) *reinterpret_cast<f32x4*>(smem + hlds[k]) = areg[k];      // 8 halfs, verbatim
+                else *reinterpret_cast<h4*>(smem + hlds[k]) = to_h4(areg[k]);
+            }
         if (LR4 && t < NPIX) *reinterpret_cast<h4*>(smem + OFF_L + t * 8) = to_h4(lreg);
     };
 
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
     auto prefetch_tile_operands = [&](int y0, int x0) {
         const unsigned rbase = ((unsigned)((y0 + 2 * wave) * W + x0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
 #pragma unroll
-        for (int i = 0; i < EIT; ++i) {
+        for (int i = 0; i < (OUT16 ? 0 : EIT); ++i) {
             const bool ok = x0 + ep + 4 * (i & 3) < W;
             res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
         }
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
     __amdgpu_buffer_rsrc_t r_out;
     {
         const int o_mul = a.out_mode == 1 ? 2 : 1;
-        const unsigned o_pix = (a.out_mode == 4 ? (unsigned)a.out_cstride : 64u) * 4u;      // bytes per output pixel
+        const unsigned o_pix = OUT16 ? 128u : (a.out_mode == 4 ? (unsigned)a.out_cstride : 64u) * 4u;   // bytes per output pixel
         const unsigned o_row = (unsigned)(o_mul * W) * o_pix;
         o_sy = (unsigned)__builtin_amdgcn_readfirstlane((int)(o_mul * o_row));
         o_sx = (unsigned)__builtin_amdgcn_readfirstlane((int)(o_mul * o_pix));
@@ -215,7 +222,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
     bool has_next = ntile < xend;
 
     // ---- prologue: first halo + operands requested, then the weights (global fp16 image -> LDS verbatim)
-    stage_load(ty0, tx0, true);
+#pragma unroll
+    for (int k = 0; k < AIT; ++k) halo_load(k, ty0, tx0, true);
+    if (LR4) lr_load(ty0, tx0, true);
     prefetch_tile_operands(ty0, tx0);
     {
         const f32x4* g = reinterpret_cast<const f32x4*>(a.w + (long)yimg * a.w_ystride);
@@ -237,7 +246,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
         }
     }
     stage_store();
-    stage_load((ntile / tiles_x) * TH, (ntile % tiles_x) * TW, has_next);
+    {
+        const int ny0 = (ntile / tiles_x) * TH, nx0 = (ntile % tiles_x) * TW;
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) halo_load(k, ny0, nx0, has_next);
+        if (LR4) lr_load(ny0, nx0, has_next);
+    }
     lds_barrier();
 
     const char* a_lane = smem + (2 * wave + my) * RSB + mx * PSB + 16 * h;
@@ -268,9 +282,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-        // ---- K loop: no barrier, no global traffic of its own.  Fragments are fetched DEPTH k-steps ahead of
-        //      the MFMAs that use them (the compiler's own schedule keeps ~1 step in flight and stalls on LDS
-        //      latency: 3600 instead of 2300 cycles per tile); sched_barrier pins one fetch group per MFMA pair.
+        // ---- K loop: no barrier, no global traffic.  Fragments are fetched DEPTH k-steps ahead of the MFMAs that
+        //      use them (the compiler's own schedule keeps ~1 step in flight and stalls on LDS latency: 3600
+        //      instead of 2300 cycles per tile); sched_barrier pins one fetch group per MFMA pair.
+        //      (Issuing the tile period's loads / stores from in here, one per k-step, was measured: a wave whose
+        //      global instruction waits for the CU's memory pipe cannot issue its MFMAs either, the K loop grew
+        //      from 2500 to 5500 cycles and the tile got slower.)
         constexpr int NS = 36 + (LR4 ? 3 : 0) + (PAR ? 12 : 0), DEPTH = 4;     // 3 * DEPTH <= 15 (lgkmcnt)
         h8 fa[DEPTH], fb0[DEPTH], fb1[DEPTH];
         auto fetch = [&](int k) {       // k is a compile-time constant after unrolling
@@ -326,6 +343,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
             for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc[j][r];
         asm volatile("" ::: "memory");
         const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+        if (OUT16) {
+            // a lane owns 8 channels (16 B of fp16) of one pixel: 4 instead of 8 stores per wave
+            const int ec8 = lane & 7, ep8 = lane >> 3;
+            f32x4 lo[4], hi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8];
+                hi[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8 + 1];
+            }
+            const unsigned obase = (unsigned)(ty0 + 2 * wave) * o_sy + (unsigned)(tx0 + ep8) * o_sx + (unsigned)ec8 * 16u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 u = lo[i], v = hi[i];
+                u = __builtin_elementwise_max(u, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(u, (f32x4)(0.f));
+                v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+                const h4 uh = to_h4(u), vh = to_h4(v);
+                const h8 pk = __builtin_shufflevector(uh, vh, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bool ok = tx0 + ep8 + 8 * (i & 1) < W;
+                buf_store4(r_out, ok ? obase + (unsigned)(i >> 1) * o_sy + (unsigned)(i & 1) * 8u * o_sx : OOB,
+                           __builtin_bit_cast(f32x4, pk));
+            }
+        } else {
         f32x4 rows[EIT];
 #pragma unroll
         for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];      // all reads in flight together
@@ -337,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
             v += k_post * res4[i];
             const bool ok = tx0 + ep + 4 * (i & 3) < W;
             buf_store4(r_out, ok ? obase + (unsigned)(i >> 2) * o_sy + (unsigned)(i & 3) * 4u * o_sx : OOB, v);
+        }
         }
         if (a.dbg) {
             dbg_c = __builtin_amdgcn_s_memtime();
@@ -366,7 +406,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
         }
         ntile = tile + nslots;
         has_next = ntile < xend;
-        stage_load((ntile / tiles_x) * TH, (ntile % tiles_x) * TW, has_next);
+        {
+            const int ny0 = (ntile / tiles_x) * TH, nx0 = (ntile % tiles_x) * TW;
+#pragma unroll
+            for (int k = 0; k < AIT; ++k) halo_load(k, ny0, nx0, has_next);
+            if (LR4) lr_load(ny0, nx0, has_next);
+        }
         if (a.dbg) {
             dbg_d = __builtin_amdgcn_s_memtime();
             dbg_p[2] += dbg_d - dbg_x;   // next-next halo request issue
@@ -421,9 +466,9 @@ int f16_grid(int grid_y) {
     return g < 8 ? 8 : g;
 }
 
-template <bool PAR, bool LR4>
+template <bool PAR, bool LR4, bool SRC16, bool OUT16>
 int launch_one(const F16Args& fa, int grid_y, hipStream_t stream) {
-    auto kern = conv3x3_f16_kernel<PAR, LR4>;
+    auto kern = conv3x3_f16_kernel<PAR, LR4, SRC16, OUT16>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -456,6 +501,9 @@ bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
     if (nwide == 0) return false;                        // an RGB-only input conv stays on the fp32 kernel
     if (nwide > 1 && (a.residual || a.gamma || grid_y != 1 || a.out_mode != 0)) return false;
     if (a.wpar && (a.nsrc != 1 || !a.wpar_h || grid_y != 1)) return false;
+    if ((a.src_f16 || a.out_f16) && (a.nsrc != 1 || grid_y != 1 || a.out_mode != 0)) return false;
+    if (a.src_f16 && a.out_f16) return false;
+    if (a.out_f16 && a.residual) return false;
     return true;
 }
 
@@ -490,10 +538,15 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         f.out_mode = a.out_mode;
         f.out_cstride = a.out_cstride;
         f.dbg = a.dbg;
+        const bool s16 = a.src_f16 != 0, o16 = a.out_f16 != 0;      // single-source launches only (conv_f16_eligible)
         int rc;
-        if (f.wpar) rc = launch_one<true, false>(f, grid_y, stream);
-        else if (f.lr4) rc = launch_one<false, true>(f, grid_y, stream);
-        else rc = launch_one<false, false>(f, grid_y, stream);
+        if (f.lr4) rc = launch_one<false, true, false, false>(f, grid_y, stream);
+        else if (f.wpar) rc = s16 ? launch_one<true, false, true, false>(f, grid_y, stream)
+                              : o16 ? launch_one<true, false, false, true>(f, grid_y, stream)
+                                    : launch_one<true, false, false, false>(f, grid_y, stream);
+        else rc = s16 ? launch_one<false, false, true, false>(f, grid_y, stream)
+                  : o16 ? launch_one<false, false, false, true>(f, grid_y, stream)
+                        : launch_one<false, false, false, false>(f, grid_y, stream);
         if (rc) return rc;
     }
     return PNP_OK;

@@ -12,6 +12,7 @@ struct ConvArgs {
     const void* wsrc_h[4];  // fp16 twins of wsrc / wpar (conv_f16.hip), read only when prec == 1
     const void* wpar_h;
     int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
+    int src_f16, out_f16;   // prec 1, single source, out_mode 0: src[0] / out is an fp16 NHWC64 map
     const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
     long par_plane;         // floats between planes
     const float* bias;      // [N] or nullptr

@@ -60,7 +60,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
     // branch instructions per accumulator register -- 28 k cycles of epilogue in the first timeline)
     const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     constexpr int CW = NT * 8, PPI = 64 / CW, EIT = 32 / PPI;
-    const int ec = lane % CW, ep = lane / CW;
     const int n0 = lane & 31;
 
     // Per-tile index arithmetic reads the thread/lane id through `tq`/`lq`, which are laundered through an

@@ -27,6 +27,8 @@
 
 namespace {
 
+bool g_f16_storage = true;             // pnp_debug_set_f16_storage
+
 constexpr int64_t IMG_WIDE = 9 * 4096;   // floats: 9 chunks, 64 output channels
 constexpr int64_t IMG_CHUNK = 4096;      // 1 chunk, 64 output channels
 constexpr int64_t IMG_RGB = 9 * 2048;    // conv_last: 9 chunks, 32 (3 valid) output channels
@@ -450,6 +452,8 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
     const int os = c.vsr ? 4 : 1;
     int rc;
 
+    // io16: 1 = `dst` is written as an fp16 map, 2 = `src` is one (the intermediate of a BAE block, PNP_PREC_F16 only)
+    int io16 = 0;
     // fp16 mirror of a weight image that lives in `packed` or in the per-clip expert mixtures
     const int64_t n_mix = (int64_t)t * g->ndyn * IMG_WIDE;
     auto twin = [&](const float* p) -> const void* {
@@ -490,6 +494,8 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
         a.act = act;
         a.out_mode = mode;
         a.out_cstride = 448;
+        a.out_f16 = io16 == 1;
+        a.src_f16 = io16 == 2;
         // algorithmic FLOPs of this launch (reference channel counts, not padded ones)
         double kreal = 0;
         for (int s = 0; s < nsrc; ++s) kreal += 9.0 * (sc[s] == 64 ? 64 : 3);
@@ -507,6 +513,7 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
         const float* ws[1] = {wimg};
         return conv(1, srcs, sc, ws, bias, gamma, wpar, parp, residual, act, dst, h, w, 0, cfg_lr, 1, nullptr, 0, 0, 0);
     };
+    const bool f16_maps = g->prec == PNP_PREC_F16 && g_f16_storage;
 
     // deform_align(feat, flow) -> W.kw  (iconvsr_ipb.py:19-24 dispatch; iconvsr_mv.py:12-84)
     auto align = [&](const float* feat, const float* fxp, const float* fyp) -> int {
@@ -656,14 +663,17 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
                                               : W.mixb + ((int64_t)u * g->ndyn + K.dyn_conv1) * 64;
                 const float* g1 = c.one_layer ? nullptr : gam;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
+                    io16 = f16_maps ? 1 : 0;
                     r = conv1src(x, w2, b2, gam, packed + K.w1x1, parp, nullptr, 1, W.tmp1);
-                    if (r) return r;
-                    r = conv1src(W.tmp1, w1, b1, g1, nullptr, nullptr, x, 0, dst);
+                    io16 = f16_maps ? 2 : 0;
+                    if (!r) r = conv1src(W.tmp1, w1, b1, g1, nullptr, nullptr, x, 0, dst);
                 } else {                 // sr_backbone_utils.py:314-327
+                    io16 = f16_maps ? 1 : 0;
                     r = conv1src(x, w1, b1, g1, nullptr, nullptr, nullptr, 1, W.tmp1);
-                    if (r) return r;
-                    r = conv1src(W.tmp1, w2, b2, gam, packed + K.w1x1, parp, x, 0, dst);
+                    io16 = f16_maps ? 2 : 0;
+                    if (!r) r = conv1src(W.tmp1, w2, b2, gam, packed + K.w1x1, parp, x, 0, dst);
                 }
+                io16 = 0;
                 if (r) return r;
                 x = dst;
             }
@@ -880,6 +890,10 @@ int pnp_pack_conv3x3_f32(const float* w, const float* ew, int E, int cout, int c
 int pnp_pack_conv1x1_f32(const float* w, float* dst, void* st) {
     return launch_pack_weights(plain_pack(w, 64, 1, PACK_1X1, 0, 2, 64, dst), 1, (hipStream_t)st);
 }
+
+// Diagnostic only (not part of include/pnpvcve.h): 0 keeps the BAE-block intermediate in fp32 on the fp16 path (tests
+// compare the two bit for bit).
+void pnp_debug_set_f16_storage(int on) { g_f16_storage = on != 0; }
 
 // Diagnostic only (not part of include/pnpvcve.h): per-block shader-clock timeline of the next
 // pnp_conv3x3_f32 launches, 8 u64 per block.  Used by tools/trace_conv.py.

@@ -195,3 +195,22 @@ def test_f16_precision_switch_resizes_buffers_and_round_trips():
     assert m.fp16_enabled is True and m._packed_floats == n32 + n32 // 2
     m.fp16_enabled = False
     assert m._packed_floats == n32
+
+
+def test_f16_intermediate_maps_are_bit_identical_to_fp32_storage():
+    """The BAE-block intermediate is only ever an MFMA A operand: writing it rounded (fp16 map) instead of rounding it
+    in its reader must not change a single bit of the clip."""
+    import ctypes
+    from pnp_vcve_amd import _native
+    L = _native.lib()
+    L.pnp_debug_set_f16_storage.argtypes = [ctypes.c_int]
+    L.pnp_debug_set_f16_storage.restype = None
+    for name in ('gen_parfloat_72x88', 'gen_channel_last_64x64', 'gen_two_layer_64x64'):
+        case = [c for c in gu.GEN_CASES if c['name'] == name][0]
+        try:
+            L.pnp_debug_set_f16_storage(0)
+            a, _ = _run(case, True)
+        finally:
+            L.pnp_debug_set_f16_storage(1)
+        b, _ = _run(case, True)
+        assert torch.equal(a, b), name
