@@ -33,15 +33,17 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 16, PW = 18, PSB = 144, RSB = 2816;
 constexpr int NPIX = (TH + 2) * PW;               // 180 halo pixels
-constexpr int A_BYTES = (TH + 2) * RSB;           // 28160
+constexpr int A_BYTES = (TH + 2) * RSB;           // 28160 per group
 constexpr int UNIT = 1024;
 constexpr int B_BYTES = 9 * 4 * 2 * UNIT;         // 73728
 constexpr int X_BYTES = 3 * 4 * 2 * UNIT;         // 24576
-constexpr int T_BYTES = 4 * 32 * 64 * 4;          // 32768
-constexpr int L_BYTES = NPIX * 8;                 // 1440
-constexpr int OFF_B = A_BYTES, OFF_X = OFF_B + B_BYTES, OFF_T = OFF_X + X_BYTES, OFF_L = OFF_T + T_BYTES;
-constexpr int LDS_BYTES = OFF_L + L_BYTES;
+constexpr int T_BYTES = 4 * 8 * 64 * 4;           // 8192: 4 waves x 8 pixels x 64 channels fp32
+constexpr int L_BYTES = 1536;                     // RGB halo of one group (180 x 8 B), inside X behind its 6 units
+constexpr int OFF_A = 0, OFF_B = 2 * A_BYTES, OFF_X = OFF_B + B_BYTES, OFF_T = OFF_X + X_BYTES;
+constexpr int OFF_L = OFF_X + 8 * UNIT;
+constexpr int LDS_BYTES = OFF_T + T_BYTES;        // 162816
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(OFF_L + 2 * L_BYTES <= OFF_T, "RGB halos fit behind the RGB weights");
 constexpr int AIT32 = (NPIX * 16 + 255) / 256;    // 16-byte halo loads per thread, fp32 source (4 channels each)
 constexpr int AIT16 = (NPIX * 8 + 255) / 256;     //                               fp16 source (8 channels each)
 
@@ -98,51 +100,67 @@ __device__ __forceinline__ h4 to_h4(f32x4 v) {
 // (front half writes it, back half reads it): it is consumed only as an MFMA A operand, i.e. it would be
 // rounded to fp16 by its reader anyway, so storing it rounded is bit-identical and halves its HBM traffic.
 template <bool PAR, bool LR4, bool SRC16, bool OUT16>
-__global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
+__global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
     static_assert(!(PAR && LR4), "the X region holds either the par branches or the RGB weights");
     constexpr int AIT = SRC16 ? AIT16 : AIT32;
     constexpr int CPP = SRC16 ? 8 : 16;            // 16-byte slots per halo pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // 8 waves = two groups of 4.  A group is what a whole block was in the first version of this kernel: it walks
+    // its own strip of tiles with its own A tile.  `t`, `wave` are relative to the group.
+    const int grp = threadIdx.x >> 8, t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
     const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
     const int ntiles = tiles_x * ((H + TH - 1) / TH);
     const int yimg = blockIdx.y;
 
-    // strip: XCD x (blocks with blockIdx.x % 8 == x) owns a contiguous band of tiles, dealt round-robin
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    // strips: XCD x (blocks with blockIdx.x % 8 == x) owns a contiguous band of tiles, dealt round-robin to the
+    // 2 * nslots groups resident on it
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, step = 2 * (gridDim.x >> 3);
     const int bq = ntiles >> 3, br = ntiles & 7;
     const int xbeg = xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq;
     const int xend = xbeg + bq + (xcd < br ? 1 : 0);
-    int tile = xbeg + slot;
-    if (tile >= xend) return;
+    // The two groups of a block take ADJACENT tiles (their halos overlap: L1 / L2 hits; measured +12 % at 720p over
+    // tiles half a round apart) -- unless the band has fewer tiles than groups: then group 1 of every block comes
+    // after group 0 of all blocks, so that a small frame spreads over the CUs first.
+    const bool dense = xend - xbeg >= step;
+    const int first0 = xbeg + (dense ? 2 * slot : slot), first1 = first0 + (dense ? 1 : (step >> 1));
+    const int cnt0 = first0 < xend ? (xend - 1 - first0) / step + 1 : 0;
+    const int cnt1 = first1 < xend ? (xend - 1 - first1) / step + 1 : 0;
+    if (cnt0 == 0) return;                                   // the whole block (cnt1 <= cnt0)
+    const int cnt = grp ? cnt1 : cnt0;
+    // group g contracts its j-th tile in phase g + 2 j and finishes it (epilogue, next halo) in phase g + 2 j + 1
+    const int nphase = (2 * cnt1 + 1 > 2 * cnt0) ? 2 * cnt1 + 1 : 2 * cnt0;
+    int tile = grp ? first1 : first0;
 
-    unsigned long long dbg_t0 = 0, dbg_k = 0, dbg_e = 0, dbg_h = 0, dbg_w = 0, dbg_p[4] = {0, 0, 0, 0};
+    unsigned long long dbg_t0 = 0, dbg_k = 0, dbg_e = 0, dbg_h = 0, dbg_w = 0, dbg_b = 0;
     int dbg_n = 0;
     if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memtime();
 
-    // ---- halo staging (fp32 registers -> fp16 LDS)
+    char* const sA = smem + OFF_A + grp * A_BYTES;
+    char* const sL = smem + OFF_L + grp * L_BYTES;
+
+    // ---- halo staging (fp32 or fp16 registers -> fp16 LDS)
     f32x4 areg[AIT], lreg = {0.f, 0.f, 0.f, 0.f};
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;       // < 4 GiB per feature map
     const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, SRC16 ? map_bytes / 2 : map_bytes);
     const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(LR4 ? (const void*)a.lr4 : a.src, LR4 ? map_bytes / 16 : 0);
     const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : a.src, a.residual ? map_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
-    // Tile-invariant parts of the halo addressing, once per thread: float4 slot i = t + 256 k is channel quad
-    // i & 15 of halo pixel i >> 4.  Rows above / below the image need no test (the offset leaves the
+    // Tile-invariant parts of the halo addressing, once per thread: 16-byte slot i = t + 256 k is channel group
+    // i % CPP of halo pixel i / CPP.  Rows above / below the image need no test (the offset leaves the
     // descriptor's range by itself); columns left / right of it would wrap into the neighbouring row.
     unsigned hrel[AIT];
-    int hrx[AIT], hlds[AIT];
+    int hpk[AIT];                                   // LDS byte offset | halo column << 16 (registers are scarce at 2 waves/SIMD)
 #pragma unroll
     for (int k = 0; k < AIT; ++k) {
         const int i = t + 256 * k;
         const int pix = i / CPP, cs = i % CPP;
         const int ry = pix / PW, rx = pix - ry * PW;
         hrel[k] = (unsigned)(ry * W + rx) * (SRC16 ? 128u : 256u) + (unsigned)cs * 16u;
-        hrx[k] = pix < NPIX ? rx : 0x4000;          // slots past the tile: never in range
-        hlds[k] = ry * RSB + rx * PSB + cs * (SRC16 ? 16 : 8);
+        const int col = pix < NPIX ? rx : 0x4000;   // slots past the tile: never in range
+        hpk[k] = (ry * RSB + rx * PSB + cs * (SRC16 ? 16 : 8)) | (col << 16);
     }
     unsigned lrel = 0;
     int lrx = 0x4000;
@@ -151,25 +169,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
         lrel = (unsigned)(ry * W + rx) * 16u;
         lrx = t < NPIX ? rx : 0x4000;
     }
-    // One halo request (slot k of the thread) for the tile at (y0, x0).  `live` false: a strip's last tile has no
-    // successor -- the offset is out of range and nothing is fetched.
-    auto halo_load = [&](int k, int y0, int x0, bool live) {
+    // `live` false (no such tile): every offset is out of range and nothing is fetched
+    auto stage_load = [&](int y0, int x0, bool live) {
         const unsigned hbase = (unsigned)((y0 - 1) * W + (x0 - 1)) * (SRC16 ? 128u : 256u);
-        const bool ok = live & ((unsigned)(x0 - 1 + hrx[k]) < (unsigned)W);
-        areg[k] = buf_load4(r_src, ok ? hbase + hrel[k] : OOB);
-    };
-    auto lr_load = [&](int y0, int x0, bool live) {
-        const bool ok = live & ((unsigned)(x0 - 1 + lrx) < (unsigned)W);
-        lreg = buf_load4(r_lr, ok ? (unsigned)((y0 - 1) * W + (x0 - 1)) * 16u + lrel : OOB);
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            int pk = hpk[k];
+            asm volatile("" : "+v"(pk));            // keeps LICM from unpacking it back into two loop-invariant registers
+            const bool ok = live & ((unsigned)(x0 - 1 + (pk >> 16)) < (unsigned)W);
+            areg[k] = buf_load4(r_src, ok ? hbase + hrel[k] : OOB);
+        }
+        if (LR4) {
+            const bool ok = live & ((unsigned)(x0 - 1 + lrx) < (unsigned)W);
+            lreg = buf_load4(r_lr, ok ? (unsigned)((y0 - 1) * W + (x0 - 1)) * 16u + lrel : OOB);
+        }
     };
     auto stage_store = [&]() {
 #pragma unroll
-        for (int k = 0; k < AIT; ++k)
-            if (hrx[k] < PW) {
-                if (SRC16) *reinterpret_cast<f32x4*>(smem + hlds[k]) = areg[k];      // 8 halfs, verbatim
-                else *reinterpret_cast<h4*>(smem + hlds[k]) = to_h4(areg[k]);
+        for (int k = 0; k < AIT; ++k) {
+            int pk = hpk[k];
+            asm volatile("" : "+v"(pk));
+            if ((pk >> 16) < PW) {
+                if (SRC16) *reinterpret_cast<f32x4*>(sA + (pk & 0xffff)) = areg[k];      // 8 halfs, verbatim
+                else *reinterpret_cast<h4*>(sA + (pk & 0xffff)) = to_h4(areg[k]);
             }
-        if (LR4 && t < NPIX) *reinterpret_cast<h4*>(smem + OFF_L + t * 8) = to_h4(lreg);
+        }
+        if (LR4 && t < NPIX) *reinterpret_cast<h4*>(sL + t * 8) = to_h4(lreg);
     };
 
     // ---- epilogue geometry: a lane owns 16 B (4 channels) of one pixel row per iteration
@@ -188,18 +213,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
     }
     // rows of the wave's 2 x 16 pixel slice: iteration i is pixel row i >> 2, column (lane >> 4) + 4 (i & 3)
     const unsigned row_bytes = (unsigned)W * 256u;
-    auto prefetch_tile_operands = [&](int y0, int x0) {
+    auto prefetch_tile_operands = [&](int y0, int x0, bool live) {
         const unsigned rbase = ((unsigned)((y0 + 2 * wave) * W + x0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
 #pragma unroll
         for (int i = 0; i < (OUT16 ? 0 : EIT); ++i) {
-            const bool ok = x0 + ep + 4 * (i & 3) < W;
+            const bool ok = live & (x0 + ep + 4 * (i & 3) < W);
             res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
         }
         if (PAR) {
             const int gy = y0 + 2 * wave + my, gx = x0 + mx;
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj)
-                pv[jj] = buf_load1(r_par, ((gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+                pv[jj] = buf_load1(r_par, (live & (gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
         }
     };
     // output addressing of the three row-wise modes as one affine form (uniform scalars, no per-store switch)
@@ -218,223 +243,217 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const F16Args a) {
     }
 
     int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-    int ntile = tile + nslots;
-    bool has_next = ntile < xend;
+    int done = 0;                       // tiles this group has finished
+    bool acc_live = false;              // a contracted tile is waiting for its epilogue
 
-    // ---- prologue: first halo + operands requested, then the weights (global fp16 image -> LDS verbatim)
-#pragma unroll
-    for (int k = 0; k < AIT; ++k) halo_load(k, ty0, tx0, true);
-    if (LR4) lr_load(ty0, tx0, true);
-    prefetch_tile_operands(ty0, tx0);
+    // ---- prologue: first halo + operands requested, then the weights (global fp16 image -> LDS verbatim, all 512
+    //      threads), the halo converted into the group's A tile, the second halo requested
+    stage_load(ty0, tx0, cnt > 0);
+    prefetch_tile_operands(ty0, tx0, cnt > 0);
     {
+        const int tt = threadIdx.x;
         const f32x4* g = reinterpret_cast<const f32x4*>(a.w + (long)yimg * a.w_ystride);
         f32x4* d = reinterpret_cast<f32x4*>(smem + OFF_B);
 #pragma unroll
-        for (int i = 0; i < B_BYTES / 16 / 256; ++i) d[t + 256 * i] = g[t + 256 * i];
+        for (int i = 0; i < B_BYTES / 16 / 512; ++i) d[tt + 512 * i] = g[tt + 512 * i];
         if (PAR) {
             const f32x4* gp = reinterpret_cast<const f32x4*>(a.wpar);
             f32x4* dp = reinterpret_cast<f32x4*>(smem + OFF_X);
 #pragma unroll
-            for (int i = 0; i < X_BYTES / 16 / 256; ++i) dp[t + 256 * i] = gp[t + 256 * i];
+            for (int i = 0; i < X_BYTES / 16 / 512; ++i) dp[tt + 512 * i] = gp[tt + 512 * i];
         }
         if (LR4) {
             const f32x4* gp = reinterpret_cast<const f32x4*>(a.wlr);
             f32x4* dp = reinterpret_cast<f32x4*>(smem + OFF_X);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (t + 256 * i < 6 * UNIT / 16) dp[t + 256 * i] = gp[t + 256 * i];
+            if (tt < 6 * UNIT / 16) dp[tt] = gp[tt];
         }
     }
     stage_store();
     {
-        const int ny0 = (ntile / tiles_x) * TH, nx0 = (ntile % tiles_x) * TW;
-#pragma unroll
-        for (int k = 0; k < AIT; ++k) halo_load(k, ny0, nx0, has_next);
-        if (LR4) lr_load(ny0, nx0, has_next);
+        const int nt = tile + step;
+        stage_load((nt / tiles_x) * TH, (nt % tiles_x) * TW, cnt > 1);
     }
     lds_barrier();
 
-    const char* a_lane = smem + (2 * wave + my) * RSB + mx * PSB + 16 * h;
+    const char* a_lane = sA + (2 * wave + my) * RSB + mx * PSB + 16 * h;
     const char* b_lane = smem + OFF_B + lane * 16;
     const char* x_lane = smem + OFF_X + lane * 16;
     // RGB source: k = 16 s + 8 h + j  ->  tap 4 s + 2 h + (j >> 2), channel j & 3; taps beyond 8 carry zero
     // weights and re-read tap 8 (finite values)
-    int l_off[3][2];
-    if (LR4) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                int tap = 4 * s + 2 * h + u;
-                tap = tap > 8 ? 8 : tap;
-                const int dy = tap / 3, dx = tap - dy * 3;
-                l_off[s][u] = OFF_L + ((2 * wave + my + dy) * PW + mx + dx) * 8;
-            }
-    }
-    float* sT = reinterpret_cast<float*>(smem + OFF_T) + wave * 2048;
-
-    for (;;) {
-        unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0;
-        if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
-        f32x16 acc[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-        // ---- K loop: no barrier, no global traffic.  Fragments are fetched DEPTH k-steps ahead of the MFMAs that
-        //      use them (the compiler's own schedule keeps ~1 step in flight and stalls on LDS latency: 3600
-        //      instead of 2300 cycles per tile); sched_barrier pins one fetch group per MFMA pair.
-        //      (Issuing the tile period's loads / stores from in here, one per k-step, was measured: a wave whose
-        //      global instruction waits for the CU's memory pipe cannot issue its MFMAs either, the K loop grew
-        //      from 2500 to 5500 cycles and the tile got slower.)
-        constexpr int NS = 36 + (LR4 ? 3 : 0) + (PAR ? 12 : 0), DEPTH = 4;     // 3 * DEPTH <= 15 (lgkmcnt)
-        h8 fa[DEPTH], fb0[DEPTH], fb1[DEPTH];
-        auto fetch = [&](int k) {       // k is a compile-time constant after unrolling
-            const int sl = k % DEPTH;
-            if (k < 36) {
-                const int tap = k >> 2, sk = k & 3, dy = tap / 3, dx = tap - dy * 3;
-                fa[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
-                fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 0) * UNIT);
-                fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 1) * UNIT);
-            } else if (LR4) {
-                const int sk = k - 36;
-                const h4 lo = *reinterpret_cast<const h4*>(smem + l_off[sk][0]);
-                const h4 hi = *reinterpret_cast<const h4*>(smem + l_off[sk][1]);
-                fa[sl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 0) * UNIT);
-                fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 1) * UNIT);
-            } else {
-                const int q = k - 36;
-                fa[sl] = *reinterpret_cast<const h8*>(a_lane + RSB + PSB + 32 * (q & 3));
-                fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 0) * UNIT);
-                fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 1) * UNIT);
-            }
+    const int l_base = ((2 * wave + my) * PW + mx) * 8;
+    auto l_off = [&](int sk, int u) -> int {      // compile-time sk, u: two constants selected by the lane's k-half
+        auto tap_off = [](int tap) {
+            tap = tap > 8 ? 8 : tap;
+            return ((tap / 3) * PW + tap % 3) * 8;
         };
-        auto bias_gamma = [&]() {
+        return l_base + (h ? tap_off(4 * sk + 2 + u) : tap_off(4 * sk + u));
+    };
+    // Transpose slices (32 px x 64 ch fp32 = 8 KiB per wave): in its memory phase a group's A tile is dead until the
+    // next halo is written, so waves 0..2 use it and wave 3 the 8 KiB T region (shared by the groups: only one is in
+    // its memory phase at a time).  A block barrier in the middle of every phase separates the transposes from the
+    // halo write; the group in its matrix phase passes it between two k-steps.
+    static_assert(3 * 8192 <= A_BYTES && T_BYTES >= 8192, "transpose slices");
+    float* sT = reinterpret_cast<float*>(wave < 3 ? sA + wave * 8192 : smem + OFF_T);
+    f32x16 acc[2];
+
+    for (int phase = 0; phase < nphase; ++phase) {
+        if ((phase & 1) == grp) {
+            if (done < cnt) {
+                // =================== matrix phase: contract the tile in the group's A tile.  No barrier, no global
+                // traffic.  Fragments are fetched DEPTH k-steps ahead of the MFMAs that use them (the compiler's own
+                // schedule keeps ~1 step in flight and stalls on LDS latency); sched_barrier pins one fetch group
+                // per MFMA pair.
+                unsigned long long dbg_a = 0;
+                if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                constexpr int NS = 36 + (LR4 ? 3 : 0) + (PAR ? 12 : 0);
+                constexpr int DEPTH = LR4 ? 3 : 4;       // 3 * DEPTH <= 15 (lgkmcnt); the RGB variant is out of registers at 4
+                h8 fa[DEPTH], fb0[DEPTH], fb1[DEPTH];
+                auto fetch = [&](int k) {       // k is a compile-time constant after unrolling
+                    const int sl = k % DEPTH;
+                    if (k < 36) {
+                        const int tap = k >> 2, sk = k & 3, dy = tap / 3, dx = tap - dy * 3;
+                        fa[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
+                        fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 0) * UNIT);
+                        fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 1) * UNIT);
+                    } else if (LR4) {
+                        const int sk = k - 36;
+                        const h4 lo = *reinterpret_cast<const h4*>(sL + l_off(sk, 0));
+                        const h4 hi = *reinterpret_cast<const h4*>(sL + l_off(sk, 1));
+                        fa[sl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 0) * UNIT);
+                        fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 1) * UNIT);
+                    } else {
+                        const int q = k - 36;
+                        fa[sl] = *reinterpret_cast<const h8*>(a_lane + RSB + PSB + 32 * (q & 3));
+                        fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 0) * UNIT);
+                        fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 1) * UNIT);
+                    }
+                };
+                auto bias_gamma = [&]() {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+                };
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k) fetch(k);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int sl = k % DEPTH;
+                    h8 av = fa[sl];
+                    const h8 b0 = fb0[sl], b1 = fb1[sl];
+                    if (PAR && k == 36) bias_gamma();       // (conv + bias) * gamma BEFORE the 1x1 partition branches
+                    if (PAR && k >= 36) av *= (_Float16)pv[(k - 36) >> 2];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+                    if (k + DEPTH < NS) fetch(k + DEPTH);
+                    if (k == NS / 2) __builtin_amdgcn_s_barrier();      // the phase's middle barrier (no LDS hand-off here)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!PAR) bias_gamma();
+                acc_live = true;
+                if (a.dbg) dbg_k += __builtin_amdgcn_s_memtime() - dbg_a;
+            } else {
+                __builtin_amdgcn_s_barrier();
+            }
+        } else if (acc_live) {
+            // =================== memory phase (the other group is in its matrix phase): finish the tile contracted
+            // one phase ago, bring the next halo into the A tile, request the one after it.
+            unsigned long long dbg_a = 0, dbg_c = 0;
+            if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
+            // Accumulator register r of lane (n0, h) is pixel (r&3) + 8 (r>>2) + 4 h of the wave's 32-pixel M tile,
+            // channel 32 j + n0.  Pass q transposes pixels 8 q .. 8 q + 7 through the wave's 2-KiB slice.
+            const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
-        };
+                for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc[j][r];
+            asm volatile("" ::: "memory");
+            if (OUT16) {
+                // a lane owns 8 channels (16 B of fp16) of one pixel: 4 instead of 8 stores per wave
+                const int ec8 = lane & 7, ep8 = lane >> 3;
+                f32x4 lo[4], hi[4];
 #pragma unroll
-        for (int k = 0; k < DEPTH; ++k) fetch(k);
-        __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8];
+                    hi[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8 + 1];
+                }
+                asm volatile("" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int sl = k % DEPTH;
-            h8 av = fa[sl];
-            const h8 b0 = fb0[sl], b1 = fb1[sl];
-            if (PAR && k == 36) bias_gamma();       // (conv + bias) * gamma BEFORE the 1x1 partition branches
-            if (PAR && k >= 36) av *= (_Float16)pv[(k - 36) >> 2];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
-            if (k + DEPTH < NS) fetch(k + DEPTH);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!PAR) bias_gamma();
-        if (a.dbg) dbg_b = __builtin_amdgcn_s_memtime();
-
-        // ---- epilogue.  Accumulator register r of lane (n0, h) is pixel (r&3) + 8 (r>>2) + 4 h of the wave's
-        //      32-pixel M tile, channel 32 j + n0: transpose through the wave's private LDS slice.
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 u = lo[i], v = hi[i];
+                    u = __builtin_elementwise_max(u, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(u, (f32x4)(0.f));
+                    v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+                    const h4 uh = to_h4(u), vh = to_h4(v);
+                    const h8 pk = __builtin_shufflevector(uh, vh, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const int gx = tx0 + ep8 + 8 * (i & 1);
+                    const unsigned o = (unsigned)(ty0 + 2 * wave + (i >> 1)) * o_sy + (unsigned)gx * o_sx + (unsigned)ec8 * 16u;
+                    buf_store4(r_out, gx < W ? o : OOB, __builtin_bit_cast(f32x4, pk));
+                }
+            } else {
+                f32x4 rows[EIT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];      // all reads in flight together
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc[j][r];
-        asm volatile("" ::: "memory");
-        const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
-        if (OUT16) {
-            // a lane owns 8 channels (16 B of fp16) of one pixel: 4 instead of 8 stores per wave
-            const int ec8 = lane & 7, ep8 = lane >> 3;
-            f32x4 lo[4], hi[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lo[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8];
-                hi[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8 + 1];
+                for (int i = 0; i < EIT; ++i) {        // pixel row i >> 2, column ep + 4 (i & 3) of the wave's slice
+                    f32x4 v = rows[i] + k_pre * res4[i];
+                    v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+                    v += k_post * res4[i];
+                    const int gx = tx0 + ep + 4 * (i & 3);
+                    const unsigned o = (unsigned)(ty0 + 2 * wave + (i >> 2)) * o_sy + (unsigned)gx * o_sx + o_c0 + (unsigned)ec * 16u;
+                    buf_store4(r_out, gx < W ? o : OOB, v);
+                }
             }
-            const unsigned obase = (unsigned)(ty0 + 2 * wave) * o_sy + (unsigned)(tx0 + ep8) * o_sx + (unsigned)ec8 * 16u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 u = lo[i], v = hi[i];
-                u = __builtin_elementwise_max(u, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(u, (f32x4)(0.f));
-                v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
-                const h4 uh = to_h4(u), vh = to_h4(v);
-                const h8 pk = __builtin_shufflevector(uh, vh, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bool ok = tx0 + ep8 + 8 * (i & 1) < W;
-                buf_store4(r_out, ok ? obase + (unsigned)(i >> 1) * o_sy + (unsigned)(i & 1) * 8u * o_sx : OOB,
-                           __builtin_bit_cast(f32x4, pk));
+            acc_live = false;
+            ++done;
+            if (a.dbg) {
+                dbg_c = __builtin_amdgcn_s_memtime();
+                dbg_e += dbg_c - dbg_a;
+                ++dbg_n;
             }
+            const bool more = done < cnt;
+            if (more) {
+                tile += step;
+                ty0 = (tile / tiles_x) * TH;
+                tx0 = (tile % tiles_x) * TW;
+                prefetch_tile_operands(ty0, tx0, true);
+            }
+            lds_barrier();      // middle barrier: every wave of the group has read its transposed rows back
+            if (more) {
+                unsigned long long dbg_d = 0;
+                if (a.dbg) dbg_d = __builtin_amdgcn_s_memtime();
+                stage_store();                   // waits for the halo requested one memory phase ago
+                if (a.dbg) dbg_w += __builtin_amdgcn_s_memtime() - dbg_d;
+                const int nt = tile + step;
+                stage_load((nt / tiles_x) * TH, (nt % tiles_x) * TW, done + 1 < cnt);
+            }
+            if (a.dbg) dbg_h += __builtin_amdgcn_s_memtime() - dbg_c;
         } else {
-        f32x4 rows[EIT];
-#pragma unroll
-        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];      // all reads in flight together
-        const unsigned obase = (unsigned)(ty0 + 2 * wave) * o_sy + (unsigned)(tx0 + ep) * o_sx + o_c0 + (unsigned)ec * 16u;
-#pragma unroll
-        for (int i = 0; i < EIT; ++i) {
-            f32x4 v = rows[i] + k_pre * res4[i];
-            v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
-            v += k_post * res4[i];
-            const bool ok = tx0 + ep + 4 * (i & 3) < W;
-            buf_store4(r_out, ok ? obase + (unsigned)(i >> 2) * o_sy + (unsigned)(i & 3) * 4u * o_sx : OOB, v);
+            __builtin_amdgcn_s_barrier();
         }
-        }
-        if (a.dbg) {
-            dbg_c = __builtin_amdgcn_s_memtime();
-            dbg_k += dbg_b - dbg_a;
-            dbg_e += dbg_c - dbg_b;
-            ++dbg_n;
-        }
-        if (!has_next) break;
-
-        // ---- hand over: operands of the next tile, its halo into LDS, then request the halo after it
-        tile = ntile;
-        ty0 = (tile / tiles_x) * TH;
-        tx0 = (tile % tiles_x) * TW;
-        prefetch_tile_operands(ty0, tx0);
-        unsigned long long dbg_d = 0, dbg_x = 0;
+        unsigned long long dbg_x = 0;
         if (a.dbg) dbg_x = __builtin_amdgcn_s_memtime();
-        lds_barrier();                   // every wave is done reading the A tile
-        if (a.dbg) {
-            dbg_d = __builtin_amdgcn_s_memtime();
-            dbg_p[0] += dbg_x - dbg_c;   // operand prefetch issue
-            dbg_p[1] += dbg_d - dbg_x;   // barrier 1
-        }
-        stage_store();                   // waits for the halo requested one tile ago
-        if (a.dbg) {
-            dbg_x = __builtin_amdgcn_s_memtime();
-            dbg_w += dbg_x - dbg_d;
-        }
-        ntile = tile + nslots;
-        has_next = ntile < xend;
-        {
-            const int ny0 = (ntile / tiles_x) * TH, nx0 = (ntile % tiles_x) * TW;
-#pragma unroll
-            for (int k = 0; k < AIT; ++k) halo_load(k, ny0, nx0, has_next);
-            if (LR4) lr_load(ny0, nx0, has_next);
-        }
-        if (a.dbg) {
-            dbg_d = __builtin_amdgcn_s_memtime();
-            dbg_p[2] += dbg_d - dbg_x;   // next-next halo request issue
-        }
         lds_barrier();
-        if (a.dbg) {
-            dbg_x = __builtin_amdgcn_s_memtime();
-            dbg_p[3] += dbg_x - dbg_d;   // barrier 2
-            dbg_h += dbg_x - dbg_c;
-        }
+        if (a.dbg) dbg_b += __builtin_amdgcn_s_memtime() - dbg_x;
     }
     if (a.dbg && t == 0) {
-        unsigned long long* d = a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
+        unsigned long long* d = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + grp) * 16;
         d[0] = dbg_t0;
         d[1] = dbg_k;
         d[2] = dbg_e;
         d[3] = __builtin_amdgcn_s_memtime();
         d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
-        d[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+        d[5] = nphase;
         d[6] = dbg_h;
         d[7] = dbg_n;
         d[8] = dbg_w;
-        for (int i = 0; i < 4; ++i) d[9 + i] = dbg_p[i];
+        d[9] = dbg_b;
     }
 }
 
@@ -476,7 +495,7 @@ int launch_one(const F16Args& fa, int grid_y, hipStream_t stream) {
                                        LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
-    hipLaunchKernelGGL(kern, dim3(f16_grid(grid_y), grid_y), dim3(256), LDS_BYTES, stream, fa);
+    hipLaunchKernelGGL(kern, dim3(f16_grid(grid_y), grid_y), dim3(512), LDS_BYTES, stream, fa);
     return (int)hipGetLastError();
 }
 

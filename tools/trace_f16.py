@@ -39,18 +39,12 @@ L.pnp_debug_set_conv_trace(ctypes.c_void_p(dbg.data_ptr()))
 run()
 torch.cuda.synchronize()
 L.pnp_debug_set_conv_trace(ctypes.c_void_p(0))
-d = dbg.cpu().numpy().reshape(512, 16)
+d = dbg.cpu().numpy().reshape(512, 16)      # one row per 4-wave group (2 per block)
 d = d[d[:, 7] > 0]
 n = d[:, 7]
 tot = d[:, 3] - d[:, 0]
-print('mode', mode, 'blocks', len(d), 'tiles/block min/max', n.min(), n.max())
-for name, v in (('block total', tot), ('K loop / tile', d[:, 1] / n), ('epilogue / tile', d[:, 2] / n),
-                ('hand-over / tile', d[:, 6] / np.maximum(n - 1, 1)),
-                ('  of which halo wait+cvt+LDS', d[:, 8] / np.maximum(n - 1, 1)), ('total / tile', tot / n)):
-    print(f'{name:30s} mean {v.mean():10.0f}  p10 {np.percentile(v, 10):10.0f}  p90 {np.percentile(v, 90):10.0f}  max {v.max():10.0f}')
-for i, nm in enumerate(['operand prefetch issue', 'barrier 1', 'halo(i+2) request issue', 'barrier 2']):
-    v = d[:, 9 + i] / np.maximum(n - 1, 1)
-    print(f'    {nm:26s} mean {v.mean():10.0f}  p10 {np.percentile(v, 10):10.0f}  p90 {np.percentile(v, 90):10.0f}')
-for xcc in sorted(set(d[:, 5] & 15)):      # the shader clock is per XCD
-    e = d[(d[:, 5] & 15) == xcc]
-    print(f'xcd {xcc}: span {e[:, 3].max() - e[:, 0].min()} cycles, start spread {e[:, 0].max() - e[:, 0].min()}')
+print('mode', mode, 'groups', len(d), 'tiles/group min/max', n.min(), n.max(), 'phases', d[:, 5].min(), d[:, 5].max())
+for name, v in (('group total', tot), ('matrix phase / tile', d[:, 1] / n), ('memory phase: epilogue / tile', d[:, 2] / n),
+                ('memory phase: rest / tile', d[:, 6] / n), ('  of which halo wait+cvt+LDS', d[:, 8] / n),
+                ('barrier wait / tile', d[:, 9] / n), ('total / tile', tot / n)):
+    print(f'{name:32s} mean {v.mean():10.0f}  p10 {np.percentile(v, 10):10.0f}  p90 {np.percentile(v, 90):10.0f}  max {v.max():10.0f}')
