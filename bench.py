@@ -26,12 +26,13 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s achievable)
 
 
-def committed_pmc_traffic():
+def committed_pmc_traffic(precision='fp32'):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json, written by
     tools/profile_gpu.sh for this same command at 720p): (2 x FETCH_SIZE + WRITE_SIZE) KiB, the gfx950
     correction of MI355X_MICROARCH.md.  None when no profile has been committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json'))
+                   if ('fp16' in os.path.basename(f)) == (precision == 'fp16'))
     if not files:
         return {}, None
     with open(files[-1]) as f:
@@ -186,7 +187,7 @@ def main():
             'psnr_per_rank': [float(x) for x in allm[:, 0]],
             'frames_per_s_per_rank': [float(x) for x in allm[:, 1]],
         }
-        pmc, pmc_src = committed_pmc_traffic() if args.workload == '720p' else ({}, None)
+        pmc, pmc_src = committed_pmc_traffic(args.precision) if args.workload == '720p' and not args.vsr else ({}, None)
         if prof is not None:
             cb = prof['conv_block']
             ci = prof['conv_input']
@@ -211,10 +212,14 @@ def main():
                 nb = 2 * cfg['num_blocks']
                 bytes_frame = h * w * (nb * (512 + 12) + nb * 768 + (16 if args.vsr else 1) * 512)
                 gbs = bytes_frame * T * args.steps / (cb['ms'] * 1e-3) / 1e9 if cb['ms'] > 0 else 0.0
+                f16k = [v for k, v in pmc.items() if 'conv3x3_f16_kernel' in k]      # launch-weighted mean over the variants
+                f16_traffic = (sum(v['hbm_bytes_per_launch'] * v['launches'] for v in f16k) / sum(v['launches'] for v in f16k)
+                               if f16k else None)
                 res['roofline'] = {'kernel': 'conv3x3_f16_kernel<PAR,LR4> (64->64 BAE-block convs + conv_hr; fp16 MFMA 32x32x16, '
                                              'weights resident in LDS, persistent strips)',
                                    'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                   'frac': gbs / PEAK_HBM_GBS, 'traffic': None, 'launches': cb['launches'],
+                                   'frac': gbs / PEAK_HBM_GBS, 'traffic': f16_traffic, 'traffic_source': pmc_src,
+                                   'launches': cb['launches'],
                                    'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
                                    'matrix_TFLOPs': ach, 'matrix_peak_TFLOPs': 2500.0,
                                    'device_ms_per_step': res['roofline']['device_ms_per_step']}

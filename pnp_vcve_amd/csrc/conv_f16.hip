@@ -1,23 +1,33 @@
 // fp16-operand variant of the fused 3x3 conv (BASELINE configs[4], "fp16 MFMA convs"): the same op as
-// conv_mfma.hip -- same sources, same epilogue, fp32 feature maps in HBM, fp32 accumulation -- with the
-// A (activation) and B (weight) operands rounded to fp16 on their way into LDS and contracted by
-// v_mfma_f32_32x32x16_f16 (16x the fp32 matrix rate).  Opt-in (pnp_generator_set_precision); the fp32
-// kernels stay the default and the parity reference.
+// conv_mfma.hip -- same sources, same epilogue, fp32 accumulation -- with the A (activation) and B (weight)
+// operands rounded to fp16 on their way into LDS and contracted by v_mfma_f32_32x32x16_f16 (16x the fp32
+// matrix rate).  Opt-in (pnp_generator_set_precision); the fp32 kernels stay the default and the parity
+// reference.  Feature maps stay fp32 in HBM, except the intermediate of a BAE block (SRC16 / OUT16 below).
 //
-// At this MFMA rate the conv is HBM-bound (a 128-pixel tile moves 64..96 KB and needs ~1 us of matrix
-// pipe), so the kernel is organised around memory, not around the K loop:
-//   * persistent: one 256-thread block per CU walks a strip of 8x16 tiles of its XCD's band;
-//   * ALL weights of the launch live in LDS for the block's lifetime (9 taps x 64 x 64 fp16 = 72 KiB,
-//     + 24 KiB for the three 1x1 partition branches or 6 KiB for the RGB source) -- no weight streaming,
-//     so the K loop has no barrier and its only traffic is LDS reads (3 ds_read_b128 per 2 MFMAs);
-//   * the halo tile of tile i+2 is requested (fp32, registers) as soon as the halo of tile i+1 has been
-//     converted into LDS, the residual / partition values of tile i+1 right after tile i's stores:
-//     ~110 KB are in flight per CU for a whole tile period;
-//   * the accumulator tile is transposed through a per-wave LDS slice and stored as whole 256-B pixel rows.
+// At this MFMA rate a 128-pixel tile needs ~1.2 us of matrix pipe but moves 64..110 KB through the CU's memory
+// pipe, which takes roughly one 1-KiB wave instruction per 100 cycles and stalls the issuing wave meanwhile.
+// So the kernel is organised around memory, not around the K loop:
+//   * persistent: one 512-thread block per CU; ALL weights of the launch live in LDS for its lifetime
+//     (9 taps x 64 x 64 fp16 = 72 KiB, + 24 KiB for the three 1x1 partition branches or 6 KiB for the RGB
+//     source) -- no weight streaming, so the K loop has no barrier and its only traffic is LDS reads
+//     (3 ds_read_b128 per 2 MFMAs, fetched 4 k-steps ahead);
+//   * the block is TWO groups of 4 waves in anti-phase.  Each group walks its own strip of 8x16 tiles with its
+//     own A tile; in every phase one group contracts a tile (matrix phase) while the other finishes the tile it
+//     contracted one phase earlier (memory phase: transpose, residual, activation, 256-B pixel rows to HBM, next
+//     halo fp32 -> fp16 -> LDS, request the halo after it).  Two block barriers per phase; the accumulators wait
+//     in registers across them.  The two groups of a CU take adjacent tiles (shared halo columns hit L1/L2);
+//   * halo tiles are requested ~1.3 phases before they are needed and the residual / partition values one
+//     phase before, all through buffer descriptors: out-of-image lanes, ragged tiles and an absent residual are
+//     out-of-range offsets (load 0 / store dropped), so a phase is branch-free and hipcc's vmcnt bookkeeping
+//     stays exact with ~110 KB in flight per group.
+// Measured and rejected: issuing the loads / stores one per k-step from inside the K loop (a wave waiting on the
+// memory pipe cannot issue its MFMAs either: K loop 2500 -> 5500 cycles); 4 transposes of 8 pixels through a
+// 2-KiB slice (8 LDS round trips per tile instead of 2 under the other group's K-loop traffic).
 //
-// LDS map (bytes):  A tile 10 rows x 2816 (18 px x 144 B, row stride = 0 mod 256: every ds_read_b128 of
-// the K loop is conflict-free) | B 73728 | X 24576 (par branches or RGB-source weights) | T 32768
-// (4 waves x 32 px x 64 ch fp32) | L 1440 (RGB halo, 4 x fp16 per pixel)  = 160672 <= 163840.
+// LDS map (bytes):  A tiles 2 x 28160 (10 rows x 2816: 18 px x 144 B, row stride = 0 mod 256 -- every
+// ds_read_b128 of the K loop is conflict-free) | B 73728 | X 24576 (par branches, or RGB weights + the two RGB
+// halos) | T 8192  = 162816 <= 163840.  Transposes (32 px x 64 ch fp32 = 8 KiB per wave) go through the
+// group's own A tile, which is dead in its memory phase (waves 0..2), and T (wave 3).
 //
 // fp16 image of a weight chunk (made by f16_image_kernel from the fp32 "B image" of common.h): 1-KiB
 // units [k-step s][n-tile][lane][8], lane (n, h) holding input channels 16 s + 8 h + 0..7 of output

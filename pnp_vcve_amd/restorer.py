@@ -55,6 +55,16 @@ class BasicVSR(nn.Module):
         if pretrained is not None:
             self.generator.init_weights(pretrained)
 
+    # mmcv's mixed-precision switch (basic_restorer.py:45-46 `self.fp16_enabled = False`, set by wrap_fp16_model): here it
+    # selects the generator's fp16-operand conv kernels (BASELINE configs[4]); the default stays exact fp32.
+    @property
+    def fp16_enabled(self):
+        return self.generator.fp16_enabled
+
+    @fp16_enabled.setter
+    def fp16_enabled(self, value):
+        self.generator.fp16_enabled = bool(value)
+
     def check_if_mirror_extended(self, lrs):
         """basicvsr.py:52-68."""
         is_mirror_extended = False
@@ -140,3 +150,11 @@ class BasicVSR(nn.Module):
                 os.makedirs(osp.dirname(p), exist_ok=True)
                 Image.fromarray(tensor2img(output)[..., ::-1]).save(p)
         return results
+
+
+def wrap_fp16_model(model):
+    """mmcv.runner.wrap_fp16_model: switch on `fp16_enabled` of every sub-module that has it."""
+    for m in model.modules():
+        if hasattr(type(m), 'fp16_enabled') or 'fp16_enabled' in getattr(m, '__dict__', {}):
+            m.fp16_enabled = True
+    return model

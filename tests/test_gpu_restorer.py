@@ -54,6 +54,21 @@ def test_test_driver_cli(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), '000', '00000000.png'))
 
 
+def test_test_driver_cli_fp16_switch_matches_fp32_psnr():
+    """`--fp16` (mmcv's wrap_fp16_model idiom) drives the fp16-operand kernels; PSNR within north_star's 1e-3 dB."""
+    import re
+    vals = []
+    for extra in ([], ['--fp16']):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'),
+                              os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128_IPB.py'), 'none',
+                              '--cfg-options', 'data.test.num_clips=2', 'data.test.num_input_frames=5',
+                              'data.test.height=128', 'data.test.width=128', '--seed', '0'] + extra,   # same random init
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        vals.append(float(re.search(r'Eval-PSNR: ([0-9.]+)', out.stdout).group(1)))
+    assert vals[0] != vals[1] and abs(vals[0] - vals[1]) < 1e-3, vals
+
+
 def test_folder_dataset_end_to_end_with_gpu_rasteriser(tmp_path):
     """dist_test-style run on an on-disk clip tree in the reference's layout: frames + MV records from disk,
     dense maps painted on the GPU, generator, on-device PSNR -- against the oracle fed with the oracle's maps."""

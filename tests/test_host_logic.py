@@ -201,3 +201,22 @@ def test_clip_prefetcher_preserves_order_and_surfaces_errors():
             raise OSError('disk gone')
     with pytest.raises(OSError):
         list(ClipPrefetcher(Bad(num_clips=2), [0], 'cpu'))
+
+
+def test_wrap_fp16_model_flips_only_modules_that_carry_the_switch():
+    """mmcv.runner.wrap_fp16_model semantics (basic_restorer.py:45-46): set fp16_enabled where it exists."""
+    import torch.nn as nn
+    from pnp_vcve_amd.restorer import wrap_fp16_model
+
+    class WithSwitch(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fp16_enabled = False
+
+    class Plain(nn.Module):
+        pass
+
+    m = nn.Sequential(WithSwitch(), Plain(), nn.Sequential(WithSwitch()))
+    wrap_fp16_model(m)
+    assert m[0].fp16_enabled is True and m[2][0].fp16_enabled is True
+    assert not hasattr(m[1], 'fp16_enabled')

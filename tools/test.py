@@ -33,6 +33,8 @@ def parse_args():
     p.add_argument('--tmpdir')
     p.add_argument('--cfg-options', nargs='+', default=None)
     p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    p.add_argument('--fp16', action='store_true',
+                   help='fp16 MFMA operands for the 64-channel convs (same as `fp16 = dict()` in the config); default fp32')
     p.add_argument('--local_rank', type=int, default=0)
     a = p.parse_args()
     if 'LOCAL_RANK' not in os.environ:
@@ -63,6 +65,9 @@ def main():
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
     torch.cuda.set_device(dev)
     model = model.to(dev)          # no DDP wrap: inference replicas share nothing
+    if cfg.get('fp16', None) is not None or args.fp16:      # mmcv idiom: `fp16 = dict(...)` in the config
+        from pnp_vcve_amd.restorer import wrap_fp16_model
+        wrap_fp16_model(model)
     outputs = multi_gpu_test(model, dataset, save_image=args.save_path is not None, save_path=args.save_path,
                              device=dev, metrics=tuple(cfg.test_cfg['metrics']))
     if rank == 0:
