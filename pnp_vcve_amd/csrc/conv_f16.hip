@@ -68,6 +68,8 @@ struct F16Args {
     const float* bias;
     const float* gamma;
     const float* residual;
+    const float* lr;        // RGB head (out_mode 2 / 3): the low-quality frame, 3 NCHW planes
+    long lr_plane;
     void* out;              // fp32, or (OUT16, out_mode 0, no residual) fp16 NHWC64
     long w_ystride;         // halfs
     int bias_ystride;
@@ -109,9 +111,13 @@ __device__ __forceinline__ h4 to_h4(f32x4 v) {
 // SRC16 / OUT16: the source / the output is an fp16 NHWC64 map.  Used for the intermediate of a BAE block
 // (front half writes it, back half reads it): it is consumed only as an MFMA A operand, i.e. it would be
 // rounded to fp16 by its reader anyway, so storing it rounded is bit-identical and halves its HBM traffic.
-template <bool PAR, bool LR4, bool SRC16, bool OUT16>
+// RGB: the conv_last head -- ONE 32-channel N tile (3 valid), output = 3 NCHW planes + the low-quality frame
+// (out_mode 2) or + its bilinear x4 upsampling (out_mode 3).
+template <bool PAR, bool LR4, bool SRC16, bool OUT16, bool RGB>
 __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
     static_assert(!(PAR && LR4), "the X region holds either the par branches or the RGB weights");
+    static_assert(!RGB || (!PAR && !LR4 && !OUT16), "the RGB head is a plain single-source conv");
+    constexpr int NT = RGB ? 1 : 2;                // 32-channel N tiles per wave
     constexpr int AIT = SRC16 ? AIT16 : AIT32;
     constexpr int CPP = SRC16 ? 8 : 16;            // 16-byte slots per halo pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -156,7 +162,8 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;       // < 4 GiB per feature map
     const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, SRC16 ? map_bytes / 2 : map_bytes);
     const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(LR4 ? (const void*)a.lr4 : a.src, LR4 ? map_bytes / 16 : 0);
-    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : a.src, a.residual ? map_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_res = RGB ? make_rsrc(a.lr, (unsigned)(3 * a.lr_plane * 4))
+                                             : make_rsrc(a.residual ? (const void*)a.residual : a.src, a.residual ? map_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
     // Tile-invariant parts of the halo addressing, once per thread: 16-byte slot i = t + 256 k is channel group
     // i % CPP of halo pixel i / CPP.  Rows above / below the image need no test (the offset leaves the
@@ -214,16 +221,54 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
     const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     const float k_pre = a.res_pre ? 1.f : 0.f, k_post = 1.f - k_pre;
 
-    float bco[2], gco[2], pv[3] = {0.f, 0.f, 0.f};
+    float bco[NT], gco[NT], pv[3] = {0.f, 0.f, 0.f};
     f32x4 res4[EIT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NT; ++j) {
         bco[j] = a.bias ? a.bias[yimg * a.bias_ystride + j * 32 + n0] : 0.f;
         gco[j] = a.gamma ? a.gamma[j * 32 + n0] : 1.f;
     }
     // rows of the wave's 2 x 16 pixel slice: iteration i is pixel row i >> 2, column (lane >> 4) + 4 (i & 3)
     const unsigned row_bytes = (unsigned)W * 256u;
+    // RGB head: value slot (pass, lane) is channel 2 pass + (lane >> 5), pixel lane & 31 of the wave's slice; its base
+    // is the low-quality pixel (mode 2) or 4 bilinear taps of the quarter-size frame (mode 3,
+    // F.interpolate(scale_factor=4, 'bilinear', align_corners=False), iconvsr_ipb_par.py:41,140)
+    float lrv[2][4], lrw[2];
+    auto prefetch_rgb_operands = [&](int y0, int x0, bool live) {
+        const int gy = y0 + 2 * wave + (m >> 4), gx = x0 + (m & 15);
+        const bool inb = live & (gy < H) & (gx < W);
+        if (a.out_mode == 2) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int c = 2 * pass + h;
+                lrv[pass][0] = buf_load1(r_res, (inb & (c < 3)) ? (unsigned)(c * a.lr_plane + (long)gy * W + gx) * 4u : OOB);
+            }
+        } else {
+            const int lh = H >> 2, lw = W >> 2;
+            float sy = (gy + 0.5f) * 0.25f - 0.5f, sx = (gx + 0.5f) * 0.25f - 0.5f;
+            sy = sy < 0.f ? 0.f : sy;
+            sx = sx < 0.f ? 0.f : sx;
+            const int y0i = (int)sy, x0i = (int)sx;
+            const int y1i = y0i + (y0i < lh - 1 ? 1 : 0), x1i = x0i + (x0i < lw - 1 ? 1 : 0);
+            lrw[0] = sy - y0i;
+            lrw[1] = sx - x0i;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int c = 2 * pass + h;
+                const bool ok = inb & (c < 3);
+                const long pb = c * a.lr_plane;
+                lrv[pass][0] = buf_load1(r_res, ok ? (unsigned)(pb + (long)y0i * lw + x0i) * 4u : OOB);
+                lrv[pass][1] = buf_load1(r_res, ok ? (unsigned)(pb + (long)y0i * lw + x1i) * 4u : OOB);
+                lrv[pass][2] = buf_load1(r_res, ok ? (unsigned)(pb + (long)y1i * lw + x0i) * 4u : OOB);
+                lrv[pass][3] = buf_load1(r_res, ok ? (unsigned)(pb + (long)y1i * lw + x1i) * 4u : OOB);
+            }
+        }
+    };
     auto prefetch_tile_operands = [&](int y0, int x0, bool live) {
+        if (RGB) {
+            prefetch_rgb_operands(y0, x0, live);
+            return;
+        }
         const unsigned rbase = ((unsigned)((y0 + 2 * wave) * W + x0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
 #pragma unroll
         for (int i = 0; i < (OUT16 ? 0 : EIT); ++i) {
@@ -249,7 +294,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
         o_sx = (unsigned)__builtin_amdgcn_readfirstlane((int)(o_mul * o_pix));
         o_c0 = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)(a.out_mode == 1 ? (yimg >> 1) * o_row + (yimg & 1) * o_pix : (a.out_mode == 4 ? 256u * (unsigned)yimg : 0u)));
-        r_out = make_rsrc(a.out, (unsigned)(o_mul * H) * o_row);
+        r_out = RGB ? make_rsrc(a.out, (unsigned)H * (unsigned)W * 12u) : make_rsrc(a.out, (unsigned)(o_mul * H) * o_row);
     }
 
     int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
@@ -265,7 +310,8 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
         const f32x4* g = reinterpret_cast<const f32x4*>(a.w + (long)yimg * a.w_ystride);
         f32x4* d = reinterpret_cast<f32x4*>(smem + OFF_B);
 #pragma unroll
-        for (int i = 0; i < B_BYTES / 16 / 512; ++i) d[tt + 512 * i] = g[tt + 512 * i];
+        for (int i = 0; i < (B_BYTES / 2 * NT / 16 + 511) / 512; ++i)
+            if (tt + 512 * i < B_BYTES / 2 * NT / 16) d[tt + 512 * i] = g[tt + 512 * i];
         if (PAR) {
             const f32x4* gp = reinterpret_cast<const f32x4*>(a.wpar);
             f32x4* dp = reinterpret_cast<f32x4*>(smem + OFF_X);
@@ -304,7 +350,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
     // halo write; the group in its matrix phase passes it between two k-steps.
     static_assert(3 * 8192 <= A_BYTES && T_BYTES >= 8192, "transpose slices");
     float* sT = reinterpret_cast<float*>(wave < 3 ? sA + wave * 8192 : smem + OFF_T);
-    f32x16 acc[2];
+    f32x16 acc[NT];
 
     for (int phase = 0; phase < nphase; ++phase) {
         if ((phase & 1) == grp) {
@@ -316,7 +362,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                 unsigned long long dbg_a = 0;
                 if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
                 constexpr int NS = 36 + (LR4 ? 3 : 0) + (PAR ? 12 : 0);
@@ -327,8 +373,8 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                     if (k < 36) {
                         const int tap = k >> 2, sk = k & 3, dy = tap / 3, dx = tap - dy * 3;
                         fa[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
-                        fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 0) * UNIT);
-                        fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (k * 2 + 1) * UNIT);
+                        fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (k * NT + 0) * UNIT);
+                        if (NT == 2) fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (k * NT + 1) * UNIT);
                     } else if (LR4) {
                         const int sk = k - 36;
                         const h4 lo = *reinterpret_cast<const h4*>(sL + l_off(sk, 0));
@@ -345,7 +391,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                 };
                 auto bias_gamma = [&]() {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NT; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
                 };
@@ -360,7 +406,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                     if (PAR && k == 36) bias_gamma();       // (conv + bias) * gamma BEFORE the 1x1 partition branches
                     if (PAR && k >= 36) av *= (_Float16)pv[(k - 36) >> 2];
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+                    if (NT == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[NT - 1], 0, 0, 0);
                     if (k + DEPTH < NS) fetch(k + DEPTH);
                     if (k == NS / 2) __builtin_amdgcn_s_barrier();      // the phase's middle barrier (no LDS hand-off here)
                     __builtin_amdgcn_sched_barrier(0);
@@ -380,11 +426,36 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
             // channel 32 j + n0.  Pass q transposes pixels 8 q .. 8 q + 7 through the wave's 2-KiB slice.
             const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc[j][r];
+                for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (32 * NT) + j * 32 + n0] = acc[j][r];
             asm volatile("" ::: "memory");
-            if (OUT16) {
+            if (RGB) {
+                // [pixel][32 channels] slice: two passes of 64 (channel, pixel) values -> whole 64-B row segments of the
+                // output planes instead of 16 six-lane stores
+                float val[2];
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) val[pass] = sT[m * 32 + ((2 * pass + h) & 3)];
+                asm volatile("" ::: "memory");
+                const int gy = ty0 + 2 * wave + (m >> 4), gx = tx0 + (m & 15);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int c = 2 * pass + h;
+                    float v = val[pass];
+                    v = fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f);
+                    float base;
+                    if (a.out_mode == 2) {
+                        base = lrv[pass][0];
+                    } else {
+                        const float ly = lrw[0], lx = lrw[1];
+                        base = (1.f - ly) * ((1.f - lx) * lrv[pass][0] + lx * lrv[pass][1]) +
+                               ly * ((1.f - lx) * lrv[pass][2] + lx * lrv[pass][3]);
+                    }
+                    const bool ok = (c < 3) & (gy < H) & (gx < W);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + base), r_out,
+                                                          (int)(ok ? (unsigned)((long)c * H * W + (long)gy * W + gx) * 4u : OOB), 0, 0);
+                }
+            } else if (OUT16) {
                 // a lane owns 8 channels (16 B of fp16) of one pixel: 4 instead of 8 stores per wave
                 const int ec8 = lane & 7, ep8 = lane >> 3;
                 f32x4 lo[4], hi[4];
@@ -495,9 +566,9 @@ int f16_grid(int grid_y) {
     return g < 8 ? 8 : g;
 }
 
-template <bool PAR, bool LR4, bool SRC16, bool OUT16>
+template <bool PAR, bool LR4, bool SRC16, bool OUT16, bool RGB = false>
 int launch_one(const F16Args& fa, int grid_y, hipStream_t stream) {
-    auto kern = conv3x3_f16_kernel<PAR, LR4, SRC16, OUT16>;
+    auto kern = conv3x3_f16_kernel<PAR, LR4, SRC16, OUT16, RGB>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -520,7 +591,9 @@ int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStrea
 }
 
 bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
-    if (cfg == CONV_CFG_RGB) return false;
+    if (cfg == CONV_CFG_RGB)     // conv_last: one 64-channel source, 3 NCHW planes + the low-quality frame
+        return (a.out_mode == 2 || a.out_mode == 3) && a.nsrc == 1 && a.src_c[0] == 64 && a.wsrc_h[0] && grid_y == 1 &&
+               !a.wpar && !a.residual && !a.gamma && !a.out_f16 && a.lr;
     if (a.out_mode != 0 && a.out_mode != 1 && a.out_mode != 4) return false;
     int nwide = 0;
     for (int s = 0; s < a.nsrc; ++s) {
@@ -557,6 +630,8 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         f.bias = first ? a.bias : nullptr;
         f.gamma = a.gamma;
         f.residual = first ? (nwide == 1 ? a.residual : nullptr) : a.out;
+        f.lr = a.lr;
+        f.lr_plane = a.lr_plane;
         f.res_pre = first ? 0 : 1;
         f.out = a.out;
         f.w_ystride = a.w_ystride;
@@ -569,7 +644,10 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         f.dbg = a.dbg;
         const bool s16 = a.src_f16 != 0, o16 = a.out_f16 != 0;      // single-source launches only (conv_f16_eligible)
         int rc;
-        if (f.lr4) rc = launch_one<false, true, false, false>(f, grid_y, stream);
+        if (a.out_mode == 2 || a.out_mode == 3)
+            rc = s16 ? launch_one<false, false, true, false, true>(f, grid_y, stream)
+                     : launch_one<false, false, false, false, true>(f, grid_y, stream);
+        else if (f.lr4) rc = launch_one<false, true, false, false>(f, grid_y, stream);
         else if (f.wpar) rc = s16 ? launch_one<true, false, true, false>(f, grid_y, stream)
                               : o16 ? launch_one<true, false, false, true>(f, grid_y, stream)
                                     : launch_one<true, false, false, false>(f, grid_y, stream);

@@ -427,6 +427,9 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
     if (g->prec == PNP_PREC_F16) {   // every region is whole 64-output-channel chunks (the others are never read as fp16)
         rc = launch_f16_image(packed, packed + g->packed_floats, (int)(g->packed_floats / IMG_CHUNK), 2, st);
         if (rc) return rc;
+        // conv_last's image has ONE 32-channel N tile per k-step: its chunks are half as long
+        rc = launch_f16_image(packed + g->last_img, reinterpret_cast<uint16_t*>(packed + g->packed_floats) + g->last_img, 9, 1, st);
+        if (rc) return rc;
     }
     return (int)hipGetLastError();
 }
@@ -743,13 +746,16 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
             const float* s1[1];
             const int c1[1] = {64};
             const float* w1[1];
-            if (!c.vsr) {   // :144-146
+            if (!c.vsr) {   // :144-146; conv_hr's output feeds only conv_last: an fp16 map on the fp16 path
+                io16 = f16_maps ? 1 : 0;
                 rc = conv1src(feat, packed + g->hr_img, flat + g->hr_bias, nullptr, nullptr, nullptr, nullptr, 2, W.tmp1);
-                if (rc) return rc;
                 s1[0] = W.tmp1;
                 w1[0] = packed + g->last_img;
-                rc = conv(1, s1, c1, w1, packed + g->last_bias, nullptr, nullptr, nullptr, nullptr, 0, out_i, h, w, 2,
-                          CONV_CFG_RGB, 1, lr_i, hw, 0, 0);
+                io16 = f16_maps ? 2 : 0;
+                if (!rc)
+                    rc = conv(1, s1, c1, w1, packed + g->last_bias, nullptr, nullptr, nullptr, nullptr, 0, out_i, h, w, 2,
+                              CONV_CFG_RGB, 1, lr_i, hw, 0, 0);
+                io16 = 0;
                 if (rc) return rc;
             } else {        // :135-142
                 s1[0] = feat;
@@ -764,13 +770,16 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
                 if (rc) return rc;
                 s1[0] = W.u2;
                 w1[0] = packed + g->hr_img;
+                io16 = f16_maps ? 1 : 0;
                 rc = conv(1, s1, c1, w1, flat + g->hr_bias, nullptr, nullptr, nullptr, nullptr, 2, W.u3, 4 * h, 4 * w, 0,
                           conv_pick_cfg(4 * h, 4 * w), 1, nullptr, 0, 0, 0);
-                if (rc) return rc;
                 s1[0] = W.u3;
                 w1[0] = packed + g->last_img;
-                rc = conv(1, s1, c1, w1, packed + g->last_bias, nullptr, nullptr, nullptr, nullptr, 0, out_i, 4 * h,
-                          4 * w, 3, CONV_CFG_RGB, 1, lr_i, hw, 0, 0);
+                io16 = f16_maps ? 2 : 0;
+                if (!rc)
+                    rc = conv(1, s1, c1, w1, packed + g->last_bias, nullptr, nullptr, nullptr, nullptr, 0, out_i, 4 * h,
+                              4 * w, 3, CONV_CFG_RGB, 1, lr_i, hw, 0, 0);
+                io16 = 0;
                 if (rc) return rc;
             }
         }

@@ -214,3 +214,40 @@ def test_f16_intermediate_maps_are_bit_identical_to_fp32_storage():
             L.pnp_debug_set_f16_storage(1)
         b, _ = _run(case, True)
         assert torch.equal(a, b), name
+
+
+def test_f16_randomised_configs_track_the_fp32_path():
+    """Seeded draws over the constructor switches / shapes (incl. the x4 heads and both DCN aligners, whose offset
+    convs also run on the fp16 kernels): the fp16 path must stay finite and close to the fp32 path of the same build."""
+    import pnp_vcve_amd as P
+    rng = np.random.RandomState(77)
+    worst = 0.0
+    for trial in range(10):
+        with_bias = bool(rng.randint(2))
+        cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG,
+                   num_blocks=int(rng.randint(1, 4)), num_experts=int(rng.choice([2, 6])),
+                   with_cat=bool(rng.randint(2)), align_key=bool(rng.randint(2)), vsr=bool(rng.randint(3) == 0),
+                   expert_softmax=True, with_bias=with_bias, with_se=with_bias and bool(rng.randint(2)),
+                   use_base_qp=True, one_layer=bool(rng.randint(2)), channel_first=bool(rng.randint(2)),
+                   deform=str(rng.choice(['vos', 'vos', 'basic', 'fvc'])))
+        n, t = int(rng.choice([1, 2])), int(rng.randint(1, 5))
+        h, w = 64 + 4 * int(rng.randint(0, 6)), 64 + 4 * int(rng.randint(0, 10))
+        sd_np = gu.syn.make_state_dict(cfg, seed=3000 + trial, par_gain=1.0)
+        clip = gu.syn.make_clip(seed=4000 + trial, n=n, t=t, h=h, w=w, slices='IBBBP',
+                                block=4, qp_mode='ipb', crf=[15, 35][:n] if n > 1 else 25)
+        m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+        m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
+        m = m.to(dev()).eval()
+        a = {k: G(v) for k, v in clip.items()}
+        outs = []
+        for f16 in (False, True):
+            m.fp16_enabled = f16
+            with torch.no_grad():
+                outs.append(m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']).cpu())
+        assert torch.isfinite(outs[1]).all(), (trial, cfg)
+        scale = max(1.0, float(outs[0].abs().max()))
+        d = float((outs[0] - outs[1]).abs().max()) / scale
+        worst = max(worst, d)
+        print(f'trial {trial}: deform={cfg["deform"]} vsr={cfg["vsr"]} {n}x{t}x{h}x{w}  max|fp16-fp32|/scale = {d:.3e}')
+        assert 0.0 < d < TOL_F16_PATH, (trial, cfg, (n, t, h, w), d, scale)
+    print('worst', worst)
