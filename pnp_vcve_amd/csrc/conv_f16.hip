@@ -22,7 +22,10 @@
 //     stays exact with ~110 KB in flight per group.
 // Measured and rejected: issuing the loads / stores one per k-step from inside the K loop (a wave waiting on the
 // memory pipe cannot issue its MFMAs either: K loop 2500 -> 5500 cycles); 4 transposes of 8 pixels through a
-// 2-KiB slice (8 LDS round trips per tile instead of 2 under the other group's K-loop traffic).
+// 2-KiB slice (8 LDS round trips per tile instead of 2 under the other group's K-loop traffic); the two groups
+// free-running instead of phase-locked (a 4-wave barrier out of an LDS counter, transposes in two passes through
+// the group's own A tile): same 122 us per block-conv launch -- what limits a CU here is not the phase coupling but
+// how many global requests it keeps in flight (~10 GB/s per CU against a 24 GB/s HBM share on the front half).
 //
 // LDS map (bytes):  A tiles 2 x 28160 (10 rows x 2816: 18 px x 144 B, row stride = 0 mod 256 -- every
 // ds_read_b128 of the K loop is conflict-free) | B 73728 | X 24576 (par branches, or RGB weights + the two RGB
