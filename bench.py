@@ -39,9 +39,9 @@ def committed_pmc_traffic(precision='fp32'):
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def make_inputs(seed, t, h, w, dev):
+def make_inputs(seed, t, h, w, dev, n=1):
     from pnp_vcve_amd import synthetic as syn
-    clip = syn.make_clip(seed=seed, n=1, t=t, h=h, w=w, slices='IBBBP', qp_mode='qp', crf=25,
+    clip = syn.make_clip(seed=seed, n=n, t=t, h=h, w=w, slices='IBBBP', qp_mode='qp', crf=25 if n == 1 else [25] * n,
                          block=8 if h % 8 == 0 else 4)
     return clip, {k: torch.from_numpy(v).to(dev) for k, v in clip.items()}
 
@@ -50,7 +50,7 @@ def gpu_psnr(out, gt):
     """reference PSNR definition (core/misc.py:51-71 + core/evaluation/metrics.py:200-215), mean over frames,
     from the on-device statistic kernel (pnp_psnr_sse_f32)."""
     from pnp_vcve_amd.ops import psnr_frames
-    return float(psnr_frames(out[0], gt[0]).mean())
+    return float(psnr_frames(out, gt).mean())
 
 
 def cpu_baseline(sd_np, cfg, h, w):
@@ -99,6 +99,8 @@ def main():
                     help="fp16 = BASELINE configs[4]'s opt-in 'fp16 MFMA convs' (fp16 operands, fp32 accumulate and "
                          "feature maps); the headline metric is the default fp32")
     ap.add_argument('--vsr', action='store_true', help='x4 SR heads (generator vsr=True): output is 4h x 4w')
+    ap.add_argument('--clips', type=int, default=1,
+                    help='clips per GPU per step (one batch; small frames run them concurrently, DESIGN.md section 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-kernel HIP-event timing')
     args = ap.parse_args()
@@ -128,7 +130,7 @@ def main():
 
     h, w = WORKLOADS[args.workload]
     T = args.frames
-    clip, a = make_inputs(1000 + rank, T, h, w, dev)      # clip `rank` of the synthetic set (sampler rule: idx[rank::world])
+    clip, a = make_inputs(1000 + rank, T, h, w, dev, args.clips)   # clip `rank` of the synthetic set (sampler rule: idx[rank::world])
 
     def step():
         with torch.no_grad():
@@ -161,7 +163,7 @@ def main():
     if args.vsr:        # synthetic HR ground truth: the LR one, nearest-upsampled (only feeds the gathered metric)
         gt = gt.repeat_interleave(4, -1).repeat_interleave(4, -2).contiguous()
     psnr = gpu_psnr(out, gt)
-    mine = torch.tensor([psnr, args.steps * T / elapsed], dtype=torch.float64, device=cdev)
+    mine = torch.tensor([psnr, args.steps * T * args.clips / elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         allm = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allm, mine)
@@ -170,7 +172,7 @@ def main():
         allm = mine.cpu().numpy()[None]
 
     if rank == 0:
-        frames = world * args.steps * T
+        frames = world * args.steps * T * args.clips
         res = {
             'metric': 'enhanced frames/sec (1280x720, 7-frame window)' if args.workload == '720p'
                       else f'enhanced frames/sec ({w}x{h}, {T}-frame window)',
@@ -179,11 +181,11 @@ def main():
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.precision == 'fp32' else 'f16 MFMA operands, f32 accumulate / feature maps (opt-in)',
             'data': 'synthetic',
-            'config': {'workload': f'{T}x3x{h}x{w} clip per GPU per step '
+            'config': {'workload': f'{args.clips} x {T}x3x{h}x{w} clip per GPU per step '
                                    f'({dict(**{"720p": "BASELINE configs[2] shape", "128": "BASELINE configs[0-1] shape", "lr180": "BASELINE configs[4] LR shape"})[args.workload]}), '
                                    f'full BAE+CAA forward, config HR_davis_LR_128x128 generator, seeded random weights',
                        'vsr_x4_heads': bool(args.vsr),
-                       'parallelism': f'clip-sharded replicas x{world}', 'frames_per_step_per_gpu': T},
+                       'parallelism': f'clip-sharded replicas x{world}', 'frames_per_step_per_gpu': T * args.clips},
             'psnr_per_rank': [float(x) for x in allm[:, 0]],
             'frames_per_s_per_rank': [float(x) for x in allm[:, 1]],
         }

@@ -594,9 +594,10 @@ int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStrea
 }
 
 bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
+    const bool has_par = a.wpar || a.wpar_h;
     if (cfg == CONV_CFG_RGB)     // conv_last: one 64-channel source, 3 NCHW planes + the low-quality frame
         return (a.out_mode == 2 || a.out_mode == 3) && a.nsrc == 1 && a.src_c[0] == 64 && a.wsrc_h[0] && grid_y == 1 &&
-               !a.wpar && !a.residual && !a.gamma && !a.out_f16 && a.lr;
+               !has_par && !a.residual && !a.gamma && !a.out_f16 && a.lr;
     if (a.out_mode != 0 && a.out_mode != 1 && a.out_mode != 4) return false;
     int nwide = 0;
     for (int s = 0; s < a.nsrc; ++s) {
@@ -605,7 +606,7 @@ bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
     }
     if (nwide == 0) return false;                        // an RGB-only input conv stays on the fp32 kernel
     if (nwide > 1 && (a.residual || a.gamma || grid_y != 1 || a.out_mode != 0)) return false;
-    if (a.wpar && (a.nsrc != 1 || !a.wpar_h || grid_y != 1)) return false;
+    if (has_par && (a.nsrc != 1 || !a.wpar_h || !a.par || grid_y != 1)) return false;
     if ((a.src_f16 || a.out_f16) && (a.nsrc != 1 || grid_y != 1 || a.out_mode != 0)) return false;
     if (a.src_f16 && a.out_f16) return false;
     if (a.out_f16 && a.residual) return false;
@@ -627,7 +628,7 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         f.w = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]);
         f.lr4 = (first && lr_idx >= 0) ? a.src[lr_idx] : nullptr;
         f.wlr = (first && lr_idx >= 0) ? reinterpret_cast<const _Float16*>(a.wsrc_h[lr_idx]) : nullptr;
-        f.wpar = reinterpret_cast<const _Float16*>(a.wpar ? a.wpar_h : nullptr);
+        f.wpar = reinterpret_cast<const _Float16*>(a.wpar_h);
         f.par = a.par;
         f.par_plane = a.par_plane;
         f.bias = first ? a.bias : nullptr;

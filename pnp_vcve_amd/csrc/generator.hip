@@ -70,6 +70,10 @@ struct pnp_generator {
     mutable std::vector<hipEvent_t> prof_pool;
     mutable size_t prof_used = 0;
     mutable std::vector<ProfRec> prof_recs;
+    // side streams / events for batch-level concurrency (pnp_generator_forward with a multi-context workspace)
+    mutable std::vector<hipStream_t> side_streams;
+    mutable std::vector<hipEvent_t> join_events;
+    mutable hipEvent_t fork_event = nullptr;
     std::vector<ParamInfo> params;
     int64_t flat_floats = 0, packed_floats = 0;
     int ndyn = 0;
@@ -336,6 +340,9 @@ int pnp_generator_create(const pnp_generator_cfg* cfg, pnp_generator** out) {
 void pnp_generator_destroy(pnp_generator* g) {
     if (!g) return;
     for (hipEvent_t e : g->prof_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->join_events) (void)hipEventDestroy(e);
+    for (hipStream_t s : g->side_streams) (void)hipStreamDestroy(s);
+    if (g->fork_event) (void)hipEventDestroy(g->fork_event);
     delete g;
 }
 
@@ -438,17 +445,15 @@ int64_t pnp_generator_workspace_bytes(const pnp_generator* g, int t, int h, int 
     return carve(g, nullptr, t, h, w).bytes;
 }
 
-int pnp_generator_forward(const pnp_generator* g, const float* flat, const float* packed, const float* lrs,
-                          const float* mvs, const float* par, const float* slices, const float* qps,
-                          const float* base_qps, float* out, void* workspace, int64_t workspace_bytes, int n, int t,
-                          int h, int w, void* stream_) {
-    hipStream_t st = (hipStream_t)stream_;
+}  // extern "C"
+
+namespace {
+
+// One sample (clip) of the batch on one stream with one workspace context.
+int forward_sample(const pnp_generator* g, const float* flat, const float* packed, const float* lr_b, const float* mv_b,
+                   const float* par_b, const float* sl, const float* qp, const float* bq, float* out_b,
+                   const Workspace& W, int t, int h, int w, hipStream_t st) {
     const auto& c = g->cfg;
-    if (n < 1 || t < 1) return PNP_ERR_BAD_ARG;
-    if (h < 64 || w < 64) return PNP_ERR_SIZE_ASSERT;
-    if ((h % 4) || (w % 4)) return PNP_ERR_SIZE_VALUE;
-    const Workspace W = carve(g, (char*)workspace, t, h, w);
-    if (workspace_bytes < W.bytes || (reinterpret_cast<uintptr_t>(workspace) & 255)) return PNP_ERR_WORKSPACE;
     const int64_t hw = (int64_t)h * w, fm = hw * 64;
     const int E = c.num_experts;
     const int cfg_lr = conv_pick_cfg(h, w);
@@ -558,14 +563,7 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
         return launch_dcn(d, st);
     };
 
-    for (int b = 0; b < n; ++b) {
-        const float* lr_b = lrs + (int64_t)b * t * 3 * hw;
-        const float* mv_b = mvs + (int64_t)b * t * 4 * hw;
-        const float* par_b = par + (int64_t)b * t * 3 * hw;
-        float* out_b = out + (int64_t)b * t * 3 * hw * os * os;
-        const float* sl = slices + (int64_t)b * t;
-        const float* qp = qps + (int64_t)b * t;
-        const float* bq = base_qps + (int64_t)b * t;
+    {
         const float* qe = c.use_base_qp ? bq : qp;
 
         rc = launch_pack_lr(lr_b, W.lr4, t, h, w, st);
@@ -787,6 +785,65 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
     return PNP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int pnp_generator_forward(const pnp_generator* g, const float* flat, const float* packed, const float* lrs,
+                          const float* mvs, const float* par, const float* slices, const float* qps,
+                          const float* base_qps, float* out, void* workspace, int64_t workspace_bytes, int n, int t,
+                          int h, int w, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n < 1 || t < 1) return PNP_ERR_BAD_ARG;
+    if (h < 64 || w < 64) return PNP_ERR_SIZE_ASSERT;
+    if ((h % 4) || (w % 4)) return PNP_ERR_SIZE_VALUE;
+    const int64_t ctx_bytes = carve(g, nullptr, t, h, w).bytes;
+    if (workspace_bytes < ctx_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255)) return PNP_ERR_WORKSPACE;
+    const int64_t hw = (int64_t)h * w;
+    const int os = g->cfg.vsr ? 4 : 1;
+    // Samples of a batch never interact.  With a workspace of k contexts they run k at a time on the library's side
+    // streams (forked from / joined to the caller's stream with events): small frames leave most of the chip idle.
+    int nctx = (int)(workspace_bytes / ctx_bytes);
+    nctx = nctx > PNP_MAX_CONTEXTS ? PNP_MAX_CONTEXTS : nctx;
+    nctx = nctx > n ? n : nctx;
+    if (nctx > 1) {
+        while ((int)g->side_streams.size() < nctx) {
+            hipStream_t s;
+            hipEvent_t e;
+            hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            if (err != hipSuccess) return (int)err;
+            err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (err != hipSuccess) return (int)err;
+            g->side_streams.push_back(s);
+            g->join_events.push_back(e);
+        }
+        if (!g->fork_event) {
+            const hipError_t err = hipEventCreateWithFlags(&g->fork_event, hipEventDisableTiming);
+            if (err != hipSuccess) return (int)err;
+        }
+        hipError_t err = hipEventRecord(g->fork_event, st);
+        for (int k = 0; k < nctx && err == hipSuccess; ++k) err = hipStreamWaitEvent(g->side_streams[k], g->fork_event, 0);
+        if (err != hipSuccess) return (int)err;
+    }
+    int rc = PNP_OK;
+    for (int b = 0; b < n && rc == PNP_OK; ++b) {
+        const int k = b % nctx;
+        const Workspace W = carve(g, (char*)workspace + (int64_t)k * ctx_bytes, t, h, w);
+        rc = forward_sample(g, flat, packed, lrs + (int64_t)b * t * 3 * hw, mvs + (int64_t)b * t * 4 * hw,
+                            par + (int64_t)b * t * 3 * hw, slices + (int64_t)b * t, qps + (int64_t)b * t,
+                            base_qps + (int64_t)b * t, out + (int64_t)b * t * 3 * hw * os * os, W, t, h, w,
+                            nctx > 1 ? g->side_streams[k] : st);
+    }
+    if (nctx > 1) {      // join even after an error: the caller's stream must not run ahead of what was launched
+        for (int k = 0; k < nctx; ++k) {
+            hipError_t err = hipEventRecord(g->join_events[k], g->side_streams[k]);
+            if (err == hipSuccess) err = hipStreamWaitEvent(st, g->join_events[k], 0);
+            if (err != hipSuccess && rc == PNP_OK) rc = (int)err;
+        }
+    }
+    return rc;
+}
+
 int pnp_generator_profile(pnp_generator* g, int enable) {
     if (!g) return PNP_ERR_BAD_ARG;
     g->prof_on = enable != 0;
@@ -954,7 +1011,6 @@ int pnp_conv3x3_f16(int nsrc, const float* const* srcs, const int* src_channels,
         a.src_c[s] = src_channels[s];
         a.wsrc_h[s] = packed_w_f16[s];
     }
-    a.wpar = reinterpret_cast<const float*>(packed_w1x1_f16);   // only its presence is read on this path
     a.wpar_h = packed_w1x1_f16;
     a.par = par;
     a.par_plane = (long)h * w;
@@ -967,7 +1023,7 @@ int pnp_conv3x3_f16(int nsrc, const float* const* srcs, const int* src_channels,
     a.act = act;
     a.out_mode = 0;
     a.dbg = g_conv_dbg;
-    if (a.wpar && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
+    if (a.wpar_h && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
     if (!conv_f16_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_f16(a, 1, (hipStream_t)st);
 }

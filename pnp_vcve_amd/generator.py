@@ -154,11 +154,16 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
                                                        ctypes.c_void_p(packed.data_ptr()), st), 'pnp_generator_pack')
         self._flat, self._packed, self._pack_key = flat, packed, key
 
-    def _get_workspace(self, t, h, w, device):
-        k = (t, h, w, str(device))
+    #: frames below this many pixels cannot fill the chip alone: samples of a batch then run concurrently
+    CONCURRENT_BELOW_PIXELS = 512 * 512
+    MAX_CONTEXTS = 4                       # PNP_MAX_CONTEXTS
+
+    def _get_workspace(self, n, t, h, w, device):
+        ctx = 1 if h * w >= self.CONCURRENT_BELOW_PIXELS else min(n, self.MAX_CONTEXTS)
+        k = (ctx, t, h, w, str(device))
         ws = self._workspace.get(k)
         if ws is None:
-            nbytes = int(_native.lib().pnp_generator_workspace_bytes(self._handle, t, h, w))
+            nbytes = int(_native.lib().pnp_generator_workspace_bytes(self._handle, t, h, w)) * ctx
             self._workspace.clear()        # keep one shape resident
             ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
             self._workspace[k] = ws
@@ -193,7 +198,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             bq_p = ctypes.cast(base + 8 * n * t, fp)
             s = 4 if self.vsr else 1
             out = torch.empty((n, t, 3, h * s, w * s), device=dev, dtype=torch.float32)
-            ws = self._get_workspace(t, h, w, dev)
+            ws = self._get_workspace(n, t, h, w, dev)
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             rc = _native.lib().pnp_generator_forward(
                 self._handle, ctypes.c_void_p(self._flat.data_ptr()), ctypes.c_void_p(self._packed.data_ptr()),
