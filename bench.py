@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--vsr', action='store_true', help='x4 SR heads (generator vsr=True): output is 4h x 4w')
     ap.add_argument('--clips', type=int, default=1,
                     help='clips per GPU per step (one batch; small frames run them concurrently, DESIGN.md section 4)')
+    ap.add_argument('--graphs', action='store_true',
+                    help='replay each clip as one hipGraph (generator.use_graphs; frames below 512x512 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-kernel HIP-event timing')
     args = ap.parse_args()
@@ -127,6 +129,7 @@ def main():
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     m = m.to(dev).eval()
     m.fp16_enabled = args.precision == 'fp16'
+    m.use_graphs = bool(args.graphs)
 
     h, w = WORKLOADS[args.workload]
     T = args.frames
@@ -192,7 +195,7 @@ def main():
             'config': {'workload': f'{args.clips} x {T}x3x{h}x{w} clip per GPU per step '
                                    f'({dict(**{"720p": "BASELINE configs[2] shape", "128": "BASELINE configs[0-1] shape", "lr180": "BASELINE configs[4] LR shape"})[args.workload]}), '
                                    f'full BAE+CAA forward, config HR_davis_LR_128x128 generator, seeded random weights',
-                       'vsr_x4_heads': bool(args.vsr),
+                       'vsr_x4_heads': bool(args.vsr), 'hip_graphs': bool(args.graphs),
                        'parallelism': f'clip-sharded replicas x{world}', 'frames_per_step_per_gpu': T * args.clips},
             'kernel_events': ('none' if args.no_kernel_events else 'inside the timed region' if events_inside
                               else 'separate pass of the same steps after the timed region'),

@@ -77,6 +77,8 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         self._flat = self._packed = None
         self._pack_key = None
         self._workspace = {}
+        self._graphs = {}
+        self._profiling = False
 
     # ---------------------------------------------------------------- precision
     @property
@@ -93,6 +95,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         self._flat = self._packed = None        # images and workspace are sized per precision
         self._pack_key = None
         self._workspace = {}
+        self._graphs = {}
 
     # ---------------------------------------------------------------- parameters
     def _register(self, dotted, param):
@@ -153,6 +156,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         _native.check(_native.lib().pnp_generator_pack(self._handle, ctypes.c_void_p(flat.data_ptr()),
                                                        ctypes.c_void_p(packed.data_ptr()), st), 'pnp_generator_pack')
         self._flat, self._packed, self._pack_key = flat, packed, key
+        self._graphs = {}               # captured launches point into the previous buffers
 
     #: frames below this many pixels cannot fill the chip alone: samples of a batch then run concurrently
     CONCURRENT_BELOW_PIXELS = 512 * 512
@@ -197,16 +201,63 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             qp_p = ctypes.cast(base + 4 * n * t, fp)
             bq_p = ctypes.cast(base + 8 * n * t, fp)
             s = 4 if self.vsr else 1
+            if self.use_graphs and h * w < self.CONCURRENT_BELOW_PIXELS and not self._profiling:
+                return self._forward_graphed(lrs_c, mvs_c, par_c, side, (n, t, 3, h * s, w * s))
             out = torch.empty((n, t, 3, h * s, w * s), device=dev, dtype=torch.float32)
             ws = self._get_workspace(n, t, h, w, dev)
-            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            rc = _native.lib().pnp_generator_forward(
-                self._handle, ctypes.c_void_p(self._flat.data_ptr()), ctypes.c_void_p(self._packed.data_ptr()),
-                ctypes.c_void_p(lrs_c.data_ptr()), ctypes.c_void_p(mvs_c.data_ptr()),
-                ctypes.c_void_p(par_c.data_ptr()), sl_p, qp_p, bq_p, ctypes.c_void_p(out.data_ptr()),
-                ctypes.c_void_p(ws.data_ptr()), ws.numel(), n, t, h, w, st)
-            _native.check(rc, 'pnp_generator_forward')
+            self._launch(lrs_c, mvs_c, par_c, side, out, ws)
         return out
+
+    def _launch(self, lrs_c, mvs_c, par_c, side, out, ws):
+        """One pnp_generator_forward call on torch's current stream."""
+        n, t, _, h, w = lrs_c.shape
+        fp = ctypes.POINTER(ctypes.c_float)
+        base = side.data_ptr()
+        P = lambda x: ctypes.c_void_p(x.data_ptr())   # noqa: E731
+        rc = _native.lib().pnp_generator_forward(
+            self._handle, P(self._flat), P(self._packed), P(lrs_c), P(mvs_c), P(par_c), ctypes.cast(base, fp),
+            ctypes.cast(base + 4 * n * t, fp), ctypes.cast(base + 8 * n * t, fp), P(out), P(ws), ws.numel(), n, t, h, w,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _native.check(rc, 'pnp_generator_forward')
+
+    # ---------------------------------------------------------------- HIP graphs (small frames are launch-bound)
+    #: opt-in: replay the clip's ~700 launches as one hipGraph.  A graph is keyed by everything its launches bake in:
+    #: shape, the side info (QP values are kernel arguments, slice types steer the schedule), precision and the
+    #: packed weights; inputs are copied into the graph's static buffers, the output is copied out.
+    use_graphs = False
+    MAX_GRAPHS = 8
+
+    def _forward_graphed(self, lrs_c, mvs_c, par_c, side, out_shape):
+        n, t, _, h, w = lrs_c.shape
+        dev = lrs_c.device
+        key = (n, t, h, w, str(dev), side.numpy().tobytes(), self._packed.data_ptr(), self._packed_floats)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ctx = min(n, self.MAX_CONTEXTS)
+            nbytes = int(_native.lib().pnp_generator_workspace_bytes(self._handle, t, h, w)) * ctx
+            ent = dict(lrs=torch.empty_like(lrs_c), mvs=torch.empty_like(mvs_c), par=torch.empty_like(par_c),
+                       out=torch.empty(out_shape, device=dev, dtype=torch.float32),
+                       ws=torch.empty(nbytes, device=dev, dtype=torch.uint8), side=side.clone())
+            for k, src in (('lrs', lrs_c), ('mvs', mvs_c), ('par', par_c)):
+                ent[k].copy_(src)
+            cur = torch.cuda.current_stream()
+            warm = torch.cuda.Stream()
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):       # eager once: first-use attribute calls must not land in a capture
+                self._launch(ent['lrs'], ent['mvs'], ent['par'], ent['side'], ent['out'], ent['ws'])
+            cur.wait_stream(warm)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._launch(ent['lrs'], ent['mvs'], ent['par'], ent['side'], ent['out'], ent['ws'])
+            ent['graph'] = graph
+            while len(self._graphs) >= self.MAX_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = ent
+        else:
+            for k, src in (('lrs', lrs_c), ('mvs', mvs_c), ('par', par_c)):
+                ent[k].copy_(src)
+        ent['graph'].replay()
+        return ent['out'].clone()
 
     # ---------------------------------------------------------------- measurement aid
     PROF_KINDS = {'conv_block': 0, 'conv_input': 1, 'conv_head': 2, 'mv_warp': 3, 'dcn': 4}
@@ -214,6 +265,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
     def profile(self, enable=True):
         """Bracket every kernel launch of forward() with HIP events (pnp_generator_profile)."""
         _native.check(_native.lib().pnp_generator_profile(self._handle, int(bool(enable))), 'pnp_generator_profile')
+        self._profiling = bool(enable)
 
     def profile_read(self):
         """-> {kind: dict(ms=total device ms, launches=n, work=FLOPs or bytes)} since profile(True)."""

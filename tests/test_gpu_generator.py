@@ -269,3 +269,28 @@ def test_large_frames_keep_one_context():
     clip = gu.syn.make_clip(seed=64, n=2, t=1, h=512, w=512, slices='IBBBP')
     out = run(m, clip)
     assert out.shape == (2, 1, 3, 512, 512) and next(iter(m._workspace))[0] == 1
+
+
+@pytest.mark.parametrize('fp16', [False, True])
+@pytest.mark.parametrize('n', [1, 3])
+def test_hip_graph_replay_is_bit_identical_to_eager(fp16, n):
+    """use_graphs: the clip's launches are captured once per (shape, side info) and replayed; new pixel data goes
+    through the graph's static buffers.  Different side info = different graph (QP values are kernel arguments)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=71, par_gain=10.0)
+    m = build(cfg, sd_np)
+    m.fp16_enabled = fp16
+    clips = [gu.syn.make_clip(seed=72 + i, n=n, t=4, h=64, w=96, slices='IBBBP', block=4, qp_mode='ipb',
+                              crf=[15, 25, 35][:n] if n > 1 else 25) for i in range(3)]
+    eager = [run(m, c).clone() for c in clips]
+    m.use_graphs = True
+    for rep in range(2):
+        for c, e in zip(clips, eager):
+            assert torch.equal(run(m, c), e)
+    assert len(m._graphs) == 1                 # same shape and side info: one capture, five replays
+    other = gu.syn.make_clip(seed=80, n=n, t=4, h=64, w=96, slices='allP', block=4, qp_mode='ipb',
+                             crf=[15, 25, 35][:n] if n > 1 else 25)
+    g = run(m, other)
+    assert len(m._graphs) == 2
+    m.use_graphs = False
+    assert torch.equal(g, run(m, other))
