@@ -294,3 +294,36 @@ def test_hip_graph_replay_is_bit_identical_to_eager(fp16, n):
     assert len(m._graphs) == 2
     m.use_graphs = False
     assert torch.equal(g, run(m, other))
+
+
+def test_forward_workspace_errors_through_the_raw_abi():
+    """PNP_ERR_WORKSPACE (1003) for a short or misaligned workspace, PNP_ERR_BAD_ARG (1001) for n < 1 -- nothing launched."""
+    import ctypes
+    from pnp_vcve_amd import _native
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=1)
+    m = build(cfg, gu.syn.make_state_dict(cfg, seed=91))
+    clip = gu.syn.make_clip(seed=92, n=1, t=2, h=64, w=64, slices='IBBBP')
+    out = run(m, clip)                                   # packs the weights
+    L = _native.lib()
+    a = {k: torch.from_numpy(v).to(dev()) for k, v in clip.items()}
+    need = int(L.pnp_generator_workspace_bytes(m._handle, 2, 64, 64))
+    ws = torch.empty(need + 512, device=dev(), dtype=torch.uint8)
+    side = torch.stack([a['slices'].reshape(1, 2), a['QPs'].reshape(1, 2), a['base_QPs'].reshape(1, 2)]).float().cpu()
+    fp = ctypes.POINTER(ctypes.c_float)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())      # noqa: E731
+    res = torch.zeros_like(out)
+
+    def call(ws_ptr, ws_bytes, n=1):
+        return L.pnp_generator_forward(m._handle, P(m._flat), P(m._packed), P(a['lq']), P(a['mvs']), P(a['partitions']),
+                                       ctypes.cast(side.data_ptr(), fp), ctypes.cast(side.data_ptr() + 8, fp),
+                                       ctypes.cast(side.data_ptr() + 16, fp), P(res), ctypes.c_void_p(ws_ptr), ws_bytes,
+                                       n, 2, 64, 64, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    assert call(ws.data_ptr(), need - 1) == 1003
+    assert call(ws.data_ptr() + 16, need) == 1003
+    assert call(ws.data_ptr(), need, n=0) == 1001
+    torch.cuda.synchronize()
+    assert float(res.abs().max()) == 0.0
+    assert call(ws.data_ptr(), need) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(res, out)

@@ -64,3 +64,34 @@ def test_no_cpu_fallback():
     s = torch.zeros(1, 2, 1, 1, 1)
     with pytest.raises(RuntimeError):
         m(z, s, s, torch.zeros(1, 2, 4, 64, 64), s, z)
+
+
+def test_c_abi_error_codes_without_a_gpu(lib):
+    """pnp_generator_create / set_precision validate on the host: PNP_ERR_UNSUPPORTED 1002, PNP_ERR_BAD_ARG 1001."""
+    import ctypes
+
+    def create(**over):
+        kw = dict(mid_channels=64, num_blocks=2, num_experts=6, with_cat=1, use_base_qp=1, expert_softmax=1, with_bias=1,
+                  with_se=1, one_layer=1, channel_first=1, align_key=1, vsr=0, deform=0)
+        kw.update(over)
+        h = ctypes.c_void_p()
+        rc = lib.pnp_generator_create(ctypes.byref(_native.GeneratorCfg(**kw)), ctypes.byref(h))
+        return rc, h
+
+    assert create(mid_channels=32)[0] == 1002
+    assert create(num_experts=0)[0] == 1001
+    assert create(num_blocks=0)[0] == 1001
+    assert create(with_bias=0, with_se=1)[0] == 1001
+    assert create(with_bias=1, use_base_qp=0)[0] == 1001
+    assert create(deform=3)[0] == 1001
+    rc, h = create()
+    assert rc == 0 and h.value
+    n32 = lib.pnp_generator_packed_floats(h)
+    ctx = lib.pnp_generator_workspace_bytes(h, 7, 128, 128)
+    assert lib.pnp_generator_get_precision(h) == 0
+    assert lib.pnp_generator_set_precision(h, 7) == 1001
+    assert lib.pnp_generator_set_precision(h, 1) == 0 and lib.pnp_generator_get_precision(h) == 1
+    assert lib.pnp_generator_packed_floats(h) == n32 + n32 // 2          # fp16 mirror of every image
+    assert lib.pnp_generator_workspace_bytes(h, 7, 128, 128) > ctx       # + mirror of the mixed experts
+    assert n32 % 4096 == 0 and ctx % 256 == 0
+    lib.pnp_generator_destroy(h)
