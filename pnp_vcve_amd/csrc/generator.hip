@@ -508,7 +508,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         double kreal = 0;
         for (int s = 0; s < nsrc; ++s) kreal += 9.0 * (sc[s] == 64 ? 64 : 3);
         if (wpar) kreal += 3 * 64;
-        const double nreal = (mode >= 2) ? 3 : 64;
+        const double nreal = (mode == 2 || mode == 3) ? 3 : 64;   // RGB heads; mode 4 (DCN offsets) is 64 per blockIdx.y
         const int kind = (mode != 0) ? PNP_PROF_CONV_HEAD : (nsrc > 1 || sc[0] != 64) ? PNP_PROF_CONV_INPUT
                                                                                      : PNP_PROF_CONV_BLOCK;
         ProfScope ps(g, st, kind, 2.0 * kreal * nreal * (double)H * Wd * gy);
