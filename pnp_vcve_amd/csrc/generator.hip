@@ -274,6 +274,37 @@ struct ProfScope {
     }
 };
 
+// One fused-conv launch of the scheduler, spelled as a chain of named setters instead of 20 positional arguments.
+struct ConvCall {
+    int nsrc = 0;
+    const float* src[4] = {nullptr, nullptr, nullptr, nullptr};
+    int sc[4] = {0, 0, 0, 0};
+    const float* w[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float *bias_ = nullptr, *gamma_ = nullptr, *wpar_ = nullptr, *par_ = nullptr, *residual_ = nullptr, *lr_ = nullptr;
+    float* dst = nullptr;
+    long lr_plane_ = 0, w_ystride_ = 0;
+    int bias_ystride_ = 0, act_ = 0, H, W, mode_ = 0, cfg_, gy_ = 1, io16_ = 0;
+
+    ConvCall(int h, int w, int cfg) : H(h), W(w), cfg_(cfg) {}
+    ConvCall& source(const float* s, int channels, const float* wimg) {   // next member of the virtual concat
+        src[nsrc] = s;
+        sc[nsrc] = channels;
+        w[nsrc++] = wimg;
+        return *this;
+    }
+    ConvCall& bias(const float* b, int ystride = 0) { bias_ = b; bias_ystride_ = ystride; return *this; }
+    ConvCall& gamma(const float* g) { gamma_ = g; return *this; }
+    ConvCall& partition(const float* w1x1, const float* par) { wpar_ = w1x1; par_ = par; return *this; }
+    ConvCall& residual(const float* r) { residual_ = r; return *this; }
+    ConvCall& act(int a) { act_ = a; return *this; }                      // 0 none, 1 relu, 2 leaky-relu(0.1)
+    ConvCall& to(float* d) { dst = d; return *this; }
+    // out_mode of conv_mfma.h with `gy` weight images `w_ystride` floats apart (pixel shuffle: 4, DCN offsets: 7)
+    ConvCall& mode(int m, int gy = 1, long w_ystride = 0) { mode_ = m; gy_ = gy; w_ystride_ = w_ystride; return *this; }
+    ConvCall& rgb(const float* lr, long plane) { lr_ = lr; lr_plane_ = plane; return *this; }
+    // fp16 path: 1 = the output is an fp16 map, 2 = the (single) source is one
+    ConvCall& f16_map(int io16) { io16_ = io16; return *this; }
+};
+
 struct Workspace {
     float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om;
     float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 only
@@ -460,8 +491,6 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     const int os = c.vsr ? 4 : 1;
     int rc;
 
-    // io16: 1 = `dst` is written as an fp16 map, 2 = `src` is one (the intermediate of a BAE block, PNP_PREC_F16 only)
-    int io16 = 0;
     // fp16 mirror of a weight image that lives in `packed` or in the per-clip expert mixtures
     const int64_t n_mix = (int64_t)t * g->ndyn * IMG_WIDE;
     auto twin = [&](const float* p) -> const void* {
@@ -471,55 +500,45 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixh) + (p - W.mixw);
         return nullptr;
     };
-    auto conv = [&](int nsrc, const float* const* srcs, const int* sc, const float* const* ws, const float* bias,
-                    const float* gamma, const float* wpar, const float* parp, const float* residual, int act,
-                    float* dst, int H, int Wd, int mode, int cfgsel, int gy, const float* lrp, long lr_plane,
-                    long w_ystride, int bias_ystride) -> int {
+    auto conv = [&](const ConvCall& q) -> int {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
-        a.nsrc = nsrc;
+        a.nsrc = q.nsrc;
         a.prec = g->prec == PNP_PREC_F16 ? 1 : 0;
-        for (int s = 0; s < nsrc; ++s) {
-            a.src[s] = srcs[s];
-            a.src_c[s] = sc[s];
-            a.wsrc[s] = ws[s];
-            a.wsrc_h[s] = twin(ws[s]);
+        for (int s = 0; s < q.nsrc; ++s) {
+            a.src[s] = q.src[s];
+            a.src_c[s] = q.sc[s];
+            a.wsrc[s] = q.w[s];
+            a.wsrc_h[s] = twin(q.w[s]);
         }
-        a.wpar = wpar;
-        a.wpar_h = twin(wpar);
-        a.par = parp;
-        a.par_plane = (long)H * Wd;
-        a.bias = bias;
-        a.gamma = gamma;
-        a.residual = residual;
-        a.out = dst;
-        a.lr = lrp;
-        a.lr_plane = lr_plane;
-        a.w_ystride = w_ystride;
-        a.bias_ystride = bias_ystride;
-        a.H = H;
-        a.W = Wd;
-        a.act = act;
-        a.out_mode = mode;
+        a.wpar = q.wpar_;
+        a.wpar_h = twin(q.wpar_);
+        a.par = q.par_;
+        a.par_plane = (long)q.H * q.W;
+        a.bias = q.bias_;
+        a.gamma = q.gamma_;
+        a.residual = q.residual_;
+        a.out = q.dst;
+        a.lr = q.lr_;
+        a.lr_plane = q.lr_plane_;
+        a.w_ystride = q.w_ystride_;
+        a.bias_ystride = q.bias_ystride_;
+        a.H = q.H;
+        a.W = q.W;
+        a.act = q.act_;
+        a.out_mode = q.mode_;
         a.out_cstride = 448;
-        a.out_f16 = io16 == 1;
-        a.src_f16 = io16 == 2;
+        a.out_f16 = q.io16_ == 1;
+        a.src_f16 = q.io16_ == 2;
         // algorithmic FLOPs of this launch (reference channel counts, not padded ones)
         double kreal = 0;
-        for (int s = 0; s < nsrc; ++s) kreal += 9.0 * (sc[s] == 64 ? 64 : 3);
-        if (wpar) kreal += 3 * 64;
-        const double nreal = (mode == 2 || mode == 3) ? 3 : 64;   // RGB heads; mode 4 (DCN offsets) is 64 per blockIdx.y
-        const int kind = (mode != 0) ? PNP_PROF_CONV_HEAD : (nsrc > 1 || sc[0] != 64) ? PNP_PROF_CONV_INPUT
-                                                                                     : PNP_PROF_CONV_BLOCK;
-        ProfScope ps(g, st, kind, 2.0 * kreal * nreal * (double)H * Wd * gy);
-        return launch_conv3x3(a, cfgsel, gy, st);
-    };
-    auto conv1src = [&](const float* src, const float* wimg, const float* bias, const float* gamma, const float* wpar,
-                        const float* parp, const float* residual, int act, float* dst) -> int {
-        const float* srcs[1] = {src};
-        const int sc[1] = {64};
-        const float* ws[1] = {wimg};
-        return conv(1, srcs, sc, ws, bias, gamma, wpar, parp, residual, act, dst, h, w, 0, cfg_lr, 1, nullptr, 0, 0, 0);
+        for (int s = 0; s < q.nsrc; ++s) kreal += 9.0 * (q.sc[s] == 64 ? 64 : 3);
+        if (q.wpar_) kreal += 3 * 64;
+        const double nreal = (q.mode_ == 2 || q.mode_ == 3) ? 3 : 64;   // RGB heads; mode 4 (DCN offsets) is 64 per blockIdx.y
+        const int kind = (q.mode_ != 0) ? PNP_PROF_CONV_HEAD
+                                        : (q.nsrc > 1 || q.sc[0] != 64) ? PNP_PROF_CONV_INPUT : PNP_PROF_CONV_BLOCK;
+        ProfScope ps(g, st, kind, 2.0 * kreal * nreal * (double)q.H * q.W * q.gy_);
+        return launch_conv3x3(a, q.cfg_, q.gy_, st);
     };
     const bool f16_maps = g->prec == PNP_PREC_F16 && g_f16_storage;
 
@@ -533,22 +552,15 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         }
         r = launch_pack_flow4(fxp, fyp, W.flow4, h, w, st);
         if (r) return r;
-        {   // conv_offset[0] + LeakyReLU over cat([ref_warped | ref_unwarped, flow])
-            const float* srcs[2] = {W.flow4, c.deform == 1 ? W.tmp0 : feat};
-            const int sc[2] = {4, 64};
-            const float* ws[2] = {packed + g->off0_flow_img, packed + g->off0_feat_img};
-            r = conv(2, srcs, sc, ws, flat + g->f_off0_b, nullptr, nullptr, nullptr, nullptr, 2, W.tmp1, h, w, 0, cfg_lr, 1,
-                     nullptr, 0, 0, 0);
-            if (r) return r;
-        }
-        {   // conv_offset[2]: 64 -> 432 (7 blocks of 64 permuted channels), no activation
-            const float* srcs[1] = {W.tmp1};
-            const int sc[1] = {64};
-            const float* ws[1] = {packed + g->off2_img};
-            r = conv(1, srcs, sc, ws, packed + g->off2_bias, nullptr, nullptr, nullptr, nullptr, 0, W.om, h, w, 4, cfg_lr, 7,
-                     nullptr, 0, IMG_WIDE, 64);
-            if (r) return r;
-        }
+        // conv_offset[0] + LeakyReLU over cat([ref_warped | ref_unwarped, flow])
+        r = conv(ConvCall(h, w, cfg_lr).source(W.flow4, 4, packed + g->off0_flow_img)
+                     .source(c.deform == 1 ? W.tmp0 : feat, 64, packed + g->off0_feat_img)
+                     .bias(flat + g->f_off0_b).act(2).to(W.tmp1));
+        if (r) return r;
+        // conv_offset[2]: 64 -> 432 (7 blocks of 64 permuted channels), no activation
+        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, packed + g->off2_img).bias(packed + g->off2_bias, 64)
+                     .mode(4, 7, IMG_WIDE).to(W.om));
+        if (r) return r;
         DcnArgs d;
         d.x = feat;
         d.om = W.om;
@@ -642,15 +654,14 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         for (int i = 0; i < t; ++i) key[i] = (sl[i] == 73.0f) || (sl[i] == 80.0f);
         key[0] = key[t - 1] = 1;
 
-        auto run_branch = [&](int brid, int i, int nsrc, const float* const* srcs, const int* sc,
-                              const float* const* ws) -> int {
+        // input conv over the virtual concat `in` (sources already added), then the BAE blocks
+        auto run_branch = [&](int brid, int i, ConvCall in) -> int {
             const BranchPk& B = g->br[brid];
             const float* gam = (c.with_bias && c.with_se) ? W.gamma + (int64_t)i * 64 : nullptr;
             const float* parp = par_b + (int64_t)i * 3 * hw;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
-            int r = conv(nsrc, srcs, sc, ws, flat + B.in_bias, nullptr, nullptr, nullptr, nullptr, 2, W.tmp0, h, w, 0,
-                         cfg_lr, 1, nullptr, 0, 0, 0);
+            int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0));
             if (r) return r;
             const float* x = W.tmp0;
             for (int k = 0; k < c.num_blocks; ++k) {
@@ -663,18 +674,20 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 const float* b1 = c.one_layer ? flat + K.conv1_bias
                                               : W.mixb + ((int64_t)u * g->ndyn + K.dyn_conv1) * 64;
                 const float* g1 = c.one_layer ? nullptr : gam;
+                // the map between the two halves is read only as an MFMA A operand: an fp16 map on the fp16 path
+                const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
-                    io16 = f16_maps ? 1 : 0;
-                    r = conv1src(x, w2, b2, gam, packed + K.w1x1, parp, nullptr, 1, W.tmp1);
-                    io16 = f16_maps ? 2 : 0;
-                    if (!r) r = conv1src(W.tmp1, w1, b1, g1, nullptr, nullptr, x, 0, dst);
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).bias(b2).gamma(gam).partition(packed + K.w1x1, parp)
+                                 .act(1).to(W.tmp1).f16_map(o16));
+                    if (!r)
+                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).residual(x).to(dst)
+                                     .f16_map(s16));
                 } else {                 // sr_backbone_utils.py:314-327
-                    io16 = f16_maps ? 1 : 0;
-                    r = conv1src(x, w1, b1, g1, nullptr, nullptr, nullptr, 1, W.tmp1);
-                    io16 = f16_maps ? 2 : 0;
-                    if (!r) r = conv1src(W.tmp1, w2, b2, gam, packed + K.w1x1, parp, x, 0, dst);
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).bias(b1).gamma(g1).act(1).to(W.tmp1).f16_map(o16));
+                    if (!r)
+                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(gam)
+                                     .partition(packed + K.w1x1, parp).residual(x).to(dst).f16_map(s16));
                 }
-                io16 = 0;
                 if (r) return r;
                 x = dst;
             }
@@ -684,100 +697,62 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         // ---- backward sweep (iconvsr_ipb_par.py:71-100)
         for (int i = t - 1; i >= 0; --i) {
             const BranchPk& B = g->br[0];
-            const float* srcs[4];
-            int sc[4];
-            const float* ws[4];
-            int ns = 0;
-            srcs[ns] = W.lr4 + (int64_t)i * hw * 4;
-            sc[ns] = 4;
-            ws[ns++] = packed + B.in_lr;
+            ConvCall in(h, w, cfg_lr);
+            in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr);
             if (i < t - 1) {
                 int k = i + 1;
                 while (!key[k]) ++k;
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw, mv_b + ((int64_t)i * 4 + 3) * hw);
                 if (rc) return rc;
-                srcs[ns] = W.kw;
-                sc[ns] = 64;
-                ws[ns++] = packed + B.in_wide[0];
-                if (c.with_cat) {
-                    srcs[ns] = (c.align_key && k == i + 1) ? W.kw : W.slots + (int64_t)(i + 1) * fm;
-                    sc[ns] = 64;
-                    ws[ns++] = packed + B.in_wide[1];
-                }
+                in.source(W.kw, 64, packed + B.in_wide[0]);
+                if (c.with_cat)
+                    in.source((c.align_key && k == i + 1) ? W.kw : W.slots + (int64_t)(i + 1) * fm, 64, packed + B.in_wide[1]);
             }
-            rc = run_branch(0, i, ns, srcs, sc, ws);
+            rc = run_branch(0, i, in);
             if (rc) return rc;
         }
         // ---- forward sweep + heads (iconvsr_ipb_par.py:103-147)
         for (int i = 0; i < t; ++i) {
             const BranchPk& B = g->br[1];
-            const float* srcs[4];
-            int sc[4];
-            const float* ws[4];
-            int ns = 0;
-            srcs[ns] = W.lr4 + (int64_t)i * hw * 4;
-            sc[ns] = 4;
-            ws[ns++] = packed + B.in_lr;
+            ConvCall in(h, w, cfg_lr);
+            in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr);
             if (i > 0) {
                 int k = i - 1;
                 while (!key[k]) --k;
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw, mv_b + ((int64_t)i * 4 + 1) * hw);
                 if (rc) return rc;
-                srcs[ns] = W.kw;
-                sc[ns] = 64;
-                ws[ns++] = packed + B.in_wide[0];
-                if (c.with_cat) {
-                    srcs[ns] = (c.align_key && k == i - 1) ? W.kw : W.slots + (int64_t)(i - 1) * fm;
-                    sc[ns] = 64;
-                    ws[ns++] = packed + B.in_wide[1];
-                }
+                in.source(W.kw, 64, packed + B.in_wide[0]);
+                if (c.with_cat)
+                    in.source((c.align_key && k == i - 1) ? W.kw : W.slots + (int64_t)(i - 1) * fm, 64, packed + B.in_wide[1]);
             }
-            srcs[ns] = W.slots + (int64_t)i * fm;   // backward feature of this frame
-            sc[ns] = 64;
-            ws[ns++] = packed + B.in_wide[B.n_wide - 1];
-            rc = run_branch(1, i, ns, srcs, sc, ws);
+            in.source(W.slots + (int64_t)i * fm, 64, packed + B.in_wide[B.n_wide - 1]);   // backward feature of this frame
+            rc = run_branch(1, i, in);
             if (rc) return rc;
 
             const float* feat = W.slots + (int64_t)i * fm;
             const float* lr_i = lr_b + (int64_t)i * 3 * hw;
             float* out_i = out_b + (int64_t)i * 3 * hw * os * os;
-            const float* s1[1];
-            const int c1[1] = {64};
-            const float* w1[1];
-            if (!c.vsr) {   // :144-146; conv_hr's output feeds only conv_last: an fp16 map on the fp16 path
-                io16 = f16_maps ? 1 : 0;
-                rc = conv1src(feat, packed + g->hr_img, flat + g->hr_bias, nullptr, nullptr, nullptr, nullptr, 2, W.tmp1);
-                s1[0] = W.tmp1;
-                w1[0] = packed + g->last_img;
-                io16 = f16_maps ? 2 : 0;
+            // conv_hr's output feeds only conv_last: an fp16 map on the fp16 path
+            const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
+            if (!c.vsr) {   // :144-146
+                rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->hr_img).bias(flat + g->hr_bias).act(2)
+                              .to(W.tmp1).f16_map(o16));
                 if (!rc)
-                    rc = conv(1, s1, c1, w1, packed + g->last_bias, nullptr, nullptr, nullptr, nullptr, 0, out_i, h, w, 2,
-                              CONV_CFG_RGB, 1, lr_i, hw, 0, 0);
-                io16 = 0;
+                    rc = conv(ConvCall(h, w, CONV_CFG_RGB).source(W.tmp1, 64, packed + g->last_img).bias(packed + g->last_bias)
+                                  .mode(2).rgb(lr_i, hw).to(out_i).f16_map(s16));
                 if (rc) return rc;
-            } else {        // :135-142
-                s1[0] = feat;
-                w1[0] = packed + g->up_img[0];
-                rc = conv(1, s1, c1, w1, packed + g->up_bias[0], nullptr, nullptr, nullptr, nullptr, 2, W.u1, h, w, 1,
-                          cfg_lr, 4, nullptr, 0, IMG_WIDE, 64);
-                if (rc) return rc;
-                s1[0] = W.u1;
-                w1[0] = packed + g->up_img[1];
-                rc = conv(1, s1, c1, w1, packed + g->up_bias[1], nullptr, nullptr, nullptr, nullptr, 2, W.u2, 2 * h,
-                          2 * w, 1, conv_pick_cfg(2 * h, 2 * w), 4, nullptr, 0, IMG_WIDE, 64);
-                if (rc) return rc;
-                s1[0] = W.u2;
-                w1[0] = packed + g->hr_img;
-                io16 = f16_maps ? 1 : 0;
-                rc = conv(1, s1, c1, w1, flat + g->hr_bias, nullptr, nullptr, nullptr, nullptr, 2, W.u3, 4 * h, 4 * w, 0,
-                          conv_pick_cfg(4 * h, 4 * w), 1, nullptr, 0, 0, 0);
-                s1[0] = W.u3;
-                w1[0] = packed + g->last_img;
-                io16 = f16_maps ? 2 : 0;
+            } else {        // :135-142: two PixelShufflePack(2) convs (4 sub-pixel weight images each), conv_hr, conv_last + x4 bilinear lr
+                rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->up_img[0]).bias(packed + g->up_bias[0], 64)
+                              .act(2).mode(1, 4, IMG_WIDE).to(W.u1));
                 if (!rc)
-                    rc = conv(1, s1, c1, w1, packed + g->last_bias, nullptr, nullptr, nullptr, nullptr, 0, out_i, 4 * h,
-                              4 * w, 3, CONV_CFG_RGB, 1, lr_i, hw, 0, 0);
-                io16 = 0;
+                    rc = conv(ConvCall(2 * h, 2 * w, conv_pick_cfg(2 * h, 2 * w)).source(W.u1, 64, packed + g->up_img[1])
+                                  .bias(packed + g->up_bias[1], 64).act(2).mode(1, 4, IMG_WIDE).to(W.u2));
+                if (!rc)
+                    rc = conv(ConvCall(4 * h, 4 * w, conv_pick_cfg(4 * h, 4 * w)).source(W.u2, 64, packed + g->hr_img)
+                                  .bias(flat + g->hr_bias).act(2).to(W.u3).f16_map(o16));
+                if (!rc)
+                    rc = conv(ConvCall(4 * h, 4 * w, CONV_CFG_RGB).source(W.u3, 64, packed + g->last_img)
+                                  .bias(packed + g->last_bias).mode(3).rgb(lr_i, hw).to(out_i).f16_map(s16));
                 if (rc) return rc;
             }
         }
