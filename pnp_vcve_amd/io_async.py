@@ -1,0 +1,71 @@
+"""Asynchronous PNG write-back (overlap the write-back with compute).
+
+The reference saves every enhanced frame synchronously inside forward_test (basicvsr.py:205-231:
+tensor2img -> mmcv.imwrite), i.e. a full-precision D2H copy and a PNG encode per frame on the critical
+path -- 50-80 ms per 720p frame against 24 ms of GPU time here.  FrameWriter takes the frames as uint8
+(converted on the device with tensor2img's arithmetic, 4x fewer bytes over PCIe) and encodes them on a
+small thread pool while the next clip is being enhanced; close() waits and re-raises the first error.
+"""
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+
+def frames_to_uint8_hwc(frames):
+    """(T,3,H,W) or (3,H,W) float tensor in [0,1] (any device) -> uint8 (T,H,W,3) RGB on the host, with
+    tensor2img's arithmetic (mmedit/core/misc.py:51-71: clamp, * 255, round half to even)."""
+    if frames.dim() == 3:
+        frames = frames.unsqueeze(0)
+    q = (frames.detach().float().clamp(0, 1) * 255.0).round().to(torch.uint8)
+    return q.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+
+
+class FrameWriter:
+    def __init__(self, max_workers=4, max_pending=64):
+        self._pool = ThreadPoolExecutor(max_workers=max_workers, thread_name_prefix='pnp-png')
+        self._slots = threading.Semaphore(max_pending)       # bounds the host memory held by queued frames
+        self._futures = []
+        self._lock = threading.Lock()
+
+    @staticmethod
+    def _write(path, rgb):
+        from PIL import Image
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        Image.fromarray(rgb).save(path)
+
+    def submit(self, path, rgb_uint8_hwc):
+        self._slots.acquire()
+
+        def job():
+            try:
+                self._write(path, rgb_uint8_hwc)
+            finally:
+                self._slots.release()
+
+        fut = self._pool.submit(job)
+        with self._lock:
+            self._futures.append(fut)
+        return fut
+
+    def close(self):
+        """Wait for every queued frame; raise the first failure."""
+        with self._lock:
+            futs, self._futures = self._futures, []
+        err = None
+        for f in futs:
+            try:
+                f.result()
+            except BaseException as e:      # noqa: BLE001 -- surfaced to the caller below
+                err = err or e
+        self._pool.shutdown(wait=True)
+        if err is not None:
+            raise err
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

@@ -135,20 +135,27 @@ class BasicVSR(nn.Module):
             if gt is not None:
                 results['gt'] = gt.cpu()
         if save_image:
-            from PIL import Image
-            import os
-            if output.ndim == 5:
-                folder_name = meta[0]['key'].split('/')[0]
-                for i in range(output.size(1)):
-                    name = f'{i:08d}.png' if iteration is None else f'{i:08d}-{iteration + 1:06d}.png'
-                    p = osp.join(save_path, folder_name, name)
-                    os.makedirs(osp.dirname(p), exist_ok=True)
-                    Image.fromarray(tensor2img(output[:, i])[..., ::-1]).save(p)
-            else:
-                img_name = meta[0]['key'].replace('/', '_')
-                p = osp.join(save_path, f'{img_name}.png' if iteration is None else f'{img_name}-{iteration + 1:06d}.png')
-                os.makedirs(osp.dirname(p), exist_ok=True)
-                Image.fromarray(tensor2img(output)[..., ::-1]).save(p)
+            # frames leave the device as uint8 (tensor2img's arithmetic); with a FrameWriter attached
+            # (`model.frame_writer`, tools/test.py) the PNG encode overlaps the next clip's compute
+            from .io_async import FrameWriter, frames_to_uint8_hwc
+            writer = getattr(self, 'frame_writer', None)
+            own = writer is None
+            if own:
+                writer = FrameWriter(max_workers=1)
+            try:
+                if output.ndim == 5:
+                    folder_name = meta[0]['key'].split('/')[0]
+                    rgb = frames_to_uint8_hwc(output[0])
+                    for i in range(rgb.shape[0]):
+                        name = f'{i:08d}.png' if iteration is None else f'{i:08d}-{iteration + 1:06d}.png'
+                        writer.submit(osp.join(save_path, folder_name, name), rgb[i])
+                else:
+                    img_name = meta[0]['key'].replace('/', '_')
+                    name = f'{img_name}.png' if iteration is None else f'{img_name}-{iteration + 1:06d}.png'
+                    writer.submit(osp.join(save_path, name), frames_to_uint8_hwc(output[0])[0])
+            finally:
+                if own:
+                    writer.close()
         return results
 
 

@@ -220,3 +220,31 @@ def test_wrap_fp16_model_flips_only_modules_that_carry_the_switch():
     wrap_fp16_model(m)
     assert m[0].fp16_enabled is True and m[2][0].fp16_enabled is True
     assert not hasattr(m[1], 'fp16_enabled')
+
+
+def test_async_frame_writer_matches_tensor2img_and_surfaces_errors(tmp_path):
+    """io_async: uint8 conversion == the reference's tensor2img (core/misc.py:51-71) incl. clamping and round-half-even
+    ties; files written by the pool are pixel-identical to a synchronous save; a failed write is raised by close()."""
+    import numpy as np
+    from PIL import Image
+    from pnp_vcve_amd.io_async import FrameWriter, frames_to_uint8_hwc
+    from pnp_vcve_amd.metrics import tensor2img
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 3, 20, 24, generator=g) * 1.2 - 0.1            # some values outside [0, 1]
+    x[0, 0, 0, :8] = torch.tensor([0.5, 1.5, 2.5, 3.5, 126.5, 127.5, 253.5, 254.5]) / 255.0      # exact ties
+    q = frames_to_uint8_hwc(x)
+    assert q.shape == (3, 20, 24, 3) and q.dtype == np.uint8
+    for i in range(3):
+        ref = tensor2img(x[i])[..., ::-1]                              # BGR (cv2 convention) -> RGB
+        assert np.array_equal(q[i], ref)
+    with FrameWriter(max_workers=3) as w:
+        for i in range(3):
+            w.submit(str(tmp_path / 'clip' / f'{i:08d}.png'), q[i])
+    for i in range(3):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / 'clip' / f'{i:08d}.png')), q[i])
+    blocker = tmp_path / 'file'
+    blocker.write_text('x')
+    w = FrameWriter(max_workers=1)
+    w.submit(str(blocker / 'sub' / 'a.png'), q[0])                     # parent is a file: makedirs fails in the worker
+    with pytest.raises(OSError):
+        w.close()

@@ -68,8 +68,16 @@ def main():
     if cfg.get('fp16', None) is not None or args.fp16:      # mmcv idiom: `fp16 = dict(...)` in the config
         from pnp_vcve_amd.restorer import wrap_fp16_model
         wrap_fp16_model(model)
-    outputs = multi_gpu_test(model, dataset, save_image=args.save_path is not None, save_path=args.save_path,
-                             device=dev, metrics=tuple(cfg.test_cfg['metrics']))
+    if args.save_path is not None:      # PNG encode off the critical path (pnp_vcve_amd/io_async.py)
+        from pnp_vcve_amd.io_async import FrameWriter
+        model.frame_writer = FrameWriter(max_workers=4)
+    try:
+        outputs = multi_gpu_test(model, dataset, save_image=args.save_path is not None, save_path=args.save_path,
+                                 device=dev, metrics=tuple(cfg.test_cfg['metrics']))
+    finally:
+        if getattr(model, 'frame_writer', None) is not None:
+            model.frame_writer.close()
+            model.frame_writer = None
     if rank == 0:
         stats = dataset.evaluate(outputs)
         for k, v in stats.items():
