@@ -156,6 +156,10 @@ int pnp_conv3x3_f16(int nsrc, const float* const* srcs_dev, const int* src_chann
 int pnp_psnr_sse_f32(const float* a_dev, const float* b_dev, unsigned long long* sse_dev, int frames,
                      int c, int h, int w, int crop_border, void* stream);
 
+/* tensor2img for the PNG write-back (mmedit/core/misc.py:51-71, basicvsr.py:205-231): frames (n,3,h,w) fp32 ->
+ * out (n,h,w,3) uint8 RGB = round_half_even(clamp(x,0,1) * 255); a quarter of the D2H bytes of the fp32 frames. */
+int pnp_frames_to_rgb8(const float* frames_dev, unsigned char* out_dev, int nframes, int h, int w, void* stream);
+
 /* SSIM statistic (mmedit/core/evaluation/metrics.py:266-355: per channel, 11x11 Gaussian sigma 1.5, 'valid'
  * window, fp64, on the uint8-rounded frames).  Writes one partial sum of the SSIM map per 16x32 tile:
  * partials_dev [frames*c][pnp_ssim_blocks(h,w,crop)] doubles; SSIM(frame) = mean over channels of

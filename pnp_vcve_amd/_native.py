@@ -50,6 +50,7 @@ SIGNATURES = {
     'pnp_packed_conv_floats': (c_int64, [c_int]),
     'pnp_pack_conv3x3_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'pnp_pack_conv1x1_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'pnp_frames_to_rgb8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'pnp_psnr_sse_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_rasterise_side_info_f32': (c_int, [c_void_p, c_void_p, ctypes.c_long, POINTER(c_float), c_int, c_int, c_int,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),

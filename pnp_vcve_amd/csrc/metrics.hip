@@ -171,3 +171,28 @@ extern "C" int pnp_psnr_sse_f32(const float* a, const float* b, unsigned long lo
     hipLaunchKernelGGL(psnr_sse_kernel, dim3((unsigned)bx, frames), dim3(256), 0, st, a, b, sse, c, h, w, crop_border);
     return (int)hipGetLastError();
 }
+
+// tensor2img for the write-back (mmedit/core/misc.py:51-71 + mmcv.imwrite, basicvsr.py:205-231): (frames,3,h,w) fp32
+// planes -> (frames,h,w,3) uint8 RGB, clamp to [0,1], * 255, round half to even -- a quarter of the D2H bytes.
+namespace {
+__global__ __launch_bounds__(256) void frames_to_rgb8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out,
+                                                             long hw, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // over frames * hw pixels
+    if (i >= total) return;
+    const long f = i / hw, p = i - f * hw;
+    const float* s = x + f * 3 * hw + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = fminf(fmaxf(s[c * hw], 0.f), 1.f) * 255.0f;
+        out[i * 3 + c] = (unsigned char)rintf(v);
+    }
+}
+}  // namespace
+
+extern "C" int pnp_frames_to_rgb8(const float* frames, unsigned char* out, int nframes, int h, int w, void* stream) {
+    if (nframes < 1 || h < 1 || w < 1 || !frames || !out) return PNP_ERR_BAD_ARG;
+    const long hw = (long)h * w, total = hw * nframes;
+    hipLaunchKernelGGL(frames_to_rgb8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       frames, out, hw, total);
+    return (int)hipGetLastError();
+}

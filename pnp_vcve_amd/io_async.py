@@ -18,8 +18,11 @@ def frames_to_uint8_hwc(frames):
     tensor2img's arithmetic (mmedit/core/misc.py:51-71: clamp, * 255, round half to even)."""
     if frames.dim() == 3:
         frames = frames.unsqueeze(0)
+    if frames.is_cuda:                       # HIP kernel (pnp_frames_to_rgb8), then a uint8 D2H copy
+        from .ops import frames_to_rgb8
+        return frames_to_rgb8(frames.detach().float().contiguous()).cpu().numpy()
     q = (frames.detach().float().clamp(0, 1) * 255.0).round().to(torch.uint8)
-    return q.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+    return q.permute(0, 2, 3, 1).contiguous().numpy()
 
 
 class FrameWriter:

@@ -164,6 +164,18 @@ def _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act):
     return out
 
 
+def frames_to_rgb8(frames):
+    """(n,3,h,w) fp32 CUDA frames -> (n,h,w,3) uint8 RGB CUDA tensor with tensor2img's arithmetic."""
+    frames = _chk(frames, 'frames')
+    if frames.dim() != 4 or frames.shape[1] != 3:
+        raise ValueError('frames must be (n,3,h,w)')
+    n, _, h, w = frames.shape
+    out = torch.empty((n, h, w, 3), device=frames.device, dtype=torch.uint8)
+    _native.check(_native.lib().pnp_frames_to_rgb8(_ptr(frames), ctypes.c_void_p(out.data_ptr()), n, h, w, _stream()),
+                  'pnp_frames_to_rgb8')
+    return out
+
+
 def psnr_frames(a, b, crop_border=0):
     """Per-frame PSNR with the reference's definition (uint8-rounded frames), computed on the GPU.
     a, b: (..., c, h, w) with any leading dims; returns a float64 CPU tensor of the leading shape."""

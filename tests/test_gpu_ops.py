@@ -348,3 +348,14 @@ def test_ssim_on_device_matches_host_definition(crop):
         ref = ssim(tensor2img(a[i]), tensor2img(b[i]), crop)
         assert abs(float(got[i]) - ref) < 1e-10, (i, float(got[i]), ref)
     assert abs(float(got[2]) - 1.0) < 1e-12
+
+
+def test_frames_to_rgb8_matches_tensor2img():
+    """write-back conversion on the device == the reference's tensor2img (core/misc.py:51-71), incl. ties and clamping"""
+    from pnp_vcve_amd import ops
+    from pnp_vcve_amd.metrics import tensor2img
+    x = torch.from_numpy(gu.syn.uniform(31, 'img', (4, 3, 37, 53), -0.1, 1.1))
+    x[0, 0, 0, :8] = torch.tensor([0.5, 1.5, 2.5, 3.5, 126.5, 127.5, 253.5, 254.5]) / 255.0
+    q = ops.frames_to_rgb8(x.to(dev())).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(q[i], tensor2img(x[i])[..., ::-1])
