@@ -65,7 +65,11 @@ def flow_warp(x, flow):
 # modulated_deform_conv_*; not vendored in the reference -> PARITY UNPINNED).
 # --------------------------------------------------------------------------
 def modulated_deform_conv2d(x, offset, mask, weight, bias, deform_groups=16):
-    """3x3, stride 1, pad 1, dilation 1, groups 1.
+    """mmcv.ops.modulated_deform_conv2d as called by backbones/sr_backbones/iconvsr_mv.py:39-41,82-84
+    (ModulatedDeformConv2d subclass, :21-30,52-61).  mmcv-full 1.x is NOT vendored in /root/reference: this restates
+    its published CUDA semantics (modulated_deform_conv_cuda_kernel.cuh: modulated_deformable_im2col +
+    dmcn_im2col_bilinear) -- PARITY UNPINNED against mmcv itself.
+    3x3, stride 1, pad 1, dilation 1, groups 1.
     offset (n, dg*2*9, h, w) interleaved (dy, dx) per tap per deform group;
     mask (n, dg*9, h, w) already sigmoid-ed.  Bilinear taps outside the image
     contribute zero (mmcv dmcn_im2col_bilinear: sample is 0 unless
@@ -385,5 +389,6 @@ def rasterise_side_info(records, rec_frame, slices, h, w):
     return mvs, parts
 
 
+# test plumbing (no reference counterpart): numpy state dict -> torch tensors
 def to_torch_state(sd_np):
     return {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
