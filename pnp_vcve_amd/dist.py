@@ -55,6 +55,8 @@ def gather_clip_metrics(local, n_total, device=None):
     """local: list (this rank's clips, in shard order) of K-float lists.  Returns, on every rank,
     the [n_total, K] float64 tensor in dataset order."""
     rank, world = get_dist_info()
+    if world > 1 and dist.get_backend() != 'nccl':
+        device = None                               # gloo (CPU tests, dry runs): the payload stays on the host
     t = torch.tensor(local, dtype=torch.float64, device=device).reshape(len(local), -1)
     if world == 1:
         return t[:n_total].cpu()

@@ -97,3 +97,22 @@ def test_folder_dataset_end_to_end_with_gpu_rasteriser(tmp_path):
                                         item['slices'][None], torch.from_numpy(mvs)[None], item['base_QPs'][None],
                                         torch.from_numpy(par)[None])
     assert abs(out[0]['eval_result']['PSNR'] - cpu_ref.clip_psnr(ref, item['gt'][None])) < 0.01
+
+
+def test_dist_test_driver_two_ranks_equals_one_rank():
+    """tools/dist_test.sh with 2 ranks (both on cuda:0, gloo for the metric all-gather -- RCCL needs one GPU per rank):
+    clip sharding, per-rank GPU forward, gather and re-interleave give exactly the single-process numbers."""
+    import re
+    common = ['--seed', '0', '--cfg-options', 'data.test.num_clips=5', 'data.test.num_input_frames=3',
+              'data.test.height=64', 'data.test.width=64']
+    cfgp = os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128_IPB.py')
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), cfgp, 'none'] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    env = dict(os.environ, PORT='29533')
+    two = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'dist_test.sh'), cfgp, 'none', '2'] + common +
+                         ['dist_params.backend=gloo'], capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, two.stdout + two.stderr
+    get = lambda s, k: re.search(rf'Eval-{k}: ([0-9.]+)', s).group(1)      # noqa: E731
+    assert 'world 2' in two.stdout and 'world 1' in one.stdout
+    assert get(one.stdout, 'PSNR') == get(two.stdout, 'PSNR') and get(one.stdout, 'SSIM') == get(two.stdout, 'SSIM')

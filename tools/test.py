@@ -62,7 +62,7 @@ def main():
     model = build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     if args.checkpoint.lower() != 'none':
         load_checkpoint(model, args.checkpoint, map_location='cpu')
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     model = model.to(dev)          # no DDP wrap: inference replicas share nothing
     if cfg.get('fp16', None) is not None or args.fp16:      # mmcv idiom: `fp16 = dict(...)` in the config
