@@ -139,6 +139,12 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_chann
                     const float* packed_w1x1_dev, const float* par_dev, const float* residual_dev,
                     int act, float* out_dev, int h, int w, void* stream);
 
+/* Which of the three 1x1 partition branches (sr_backbone_utils.py:310-311, Sum_j par_j * conv1x1_j(x)) an 8x16 pixel tile
+ * needs at all: par_dev (3,h,w) -> flags_dev[((w+15)/16) * ((h+7)/8)] ints, bit j set iff plane j is nonzero somewhere in
+ * the tile.  pnp_generator_forward computes these once per frame; its persistent conv kernel skips a branch on tiles
+ * where the plane is zero (exact zeros: bit-identical result).  Codec partition maps are one-hot per >= 8x8 block. */
+int pnp_par_tile_flags_f32(const float* par_dev, int* flags_dev, int h, int w, void* stream);
+
 /* The same op with fp16 MFMA operands (fp32 sources, accumulation and output): packed_w_f16 are fp16 images
  * made by pnp_f16_image_from_f32 from the fp32 images above (nchunks = 9 per 64-channel source, 1 per RGB0
  * source, 3 for the 1x1 branches; same element count, so nchunks * 8192 bytes).  At least one source must

@@ -14,6 +14,9 @@ struct ConvArgs {
     int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
     int src_f16, out_f16;   // prec 1, single source, out_mode 0: src[0] / out is an fp16 NHWC64 map
     const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
+    const int* par_flags;   // optional, one int per 8x16 tile (row-major): bit j set <=> plane j has a nonzero value in
+                            // the tile (launch_par_tile_flags).  The persistent kernel skips the 1x1 branches whose
+                            // plane is zero over its whole tile -- exact zeros, bit-identical result.  nullptr: none skipped
     long par_plane;         // floats between planes
     const float* bias;      // [N] or nullptr
     const float* gamma;     // [N] channel gain applied to (conv + bias) BEFORE the 1x1 branches, or nullptr
@@ -44,6 +47,9 @@ int conv_pick_cfg(int H, int W);
 int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t stream);
 bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y);
 int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream);
+
+// per-tile summary of a partition map for ConvArgs::par_flags (conv_persist.hip); flags: ((W+15)/16) * ((H+7)/8) ints
+int launch_par_tile_flags(const float* par, long par_plane, int* flags, int H, int W, hipStream_t stream);
 
 // persistent single-source variant (conv_persist.hip)
 bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y);

@@ -275,14 +275,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
         run_chunk(K0{}, T<6>{}, T<7>{}, T<0>{}, 1.f, wb + 7L * CH4);
         run_chunk(K0{}, T<7>{}, T<8>{}, T<0>{}, 1.f, wb + 8L * CH4);
         if constexpr (PAR) {
-            run_chunk(K0{}, T<8>{}, T<4>{}, T<0>{}, 1.f, wp);
+            // The 1x1 partition branches are a K extension whose A operand is x scaled by the branch's plane: a branch
+            // whose plane is zero over the whole tile contributes exact zeros and is skipped (codec partition maps are
+            // one-hot per >= 8x8 block, so an 8x16 tile needs 0..2 of the 3 branches; a P/B frame of random blocks 1.67).
+            const int need = a.par_flags ? a.par_flags[tile] : 7;                 // block-uniform (scalar load)
+            const int cnt = (need & 1) + ((need >> 1) & 1) + ((need >> 2) & 1);
+            const int j0 = (need & 1) ? 0 : ((need & 2) ? 1 : 2);                 // first needed branch (branch 2 with an
+            const int j1 = ((need & 3) == 3) ? 1 : 2;                             // all-zero plane if none); second; third = 2
+            run_chunk(K0{}, T<8>{}, T<4>{}, T<0>{}, 1.f, wp + (long)j0 * CH4);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
-            run_chunk(K2{}, T<4>{}, T<4>{}, T<0>{}, pv[0], wp + 1L * CH4);
-            run_chunk(K2{}, T<4>{}, T<4>{}, T<0>{}, pv[1], wp + 2L * CH4);
-            run_chunk(K2{}, T<4>{}, T<-1>{}, T<1>{}, pv[2], wrap);
+            // the tile's last chunk is always a branch chunk (it carries the next halo request): a tile that needs no
+            // branch still runs one, on a plane of zeros
+            int cur = j0;
+            for (int i = 0; i + 1 < cnt; ++i) {
+                const int nxt = i == 0 ? j1 : 2;
+                run_chunk(K2{}, T<4>{}, T<4>{}, T<0>{}, cur == 0 ? pv[0] : (cur == 1 ? pv[1] : pv[2]), wp + (long)nxt * CH4);
+                cur = nxt;
+            }
+            run_chunk(K2{}, T<4>{}, T<-1>{}, T<1>{}, cur == 0 ? pv[0] : (cur == 1 ? pv[1] : pv[2]), wrap);
         } else {
             run_chunk(K0{}, T<8>{}, T<-1>{}, T<1>{}, 1.f, wrap);
 #pragma unroll
@@ -374,6 +387,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
 }
 
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __restrict__ par, long plane, int* __restrict__ flags,
+                                                             int H, int W, int tiles_x) {
+    const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int gy = ty * TH + (threadIdx.x >> 4), gx = tx * TW + (threadIdx.x & 15);
+    const bool in = gy < H && gx < W;
+    int bits = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float v = in ? par[j * plane + (long)gy * W + gx] : 0.f;
+        if (__syncthreads_or(v != 0.f)) bits |= 1 << j;
+    }
+    if (threadIdx.x == 0) flags[tile] = bits;
+}
+}  // namespace
+
+int launch_par_tile_flags(const float* par, long par_plane, int* flags, int H, int W, hipStream_t stream) {
+    const int tiles_x = (W + TW - 1) / TW, tiles = tiles_x * ((H + TH - 1) / TH);
+    hipLaunchKernelGGL(par_tile_flags_kernel, dim3(tiles), dim3(128), 0, stream, par, par_plane, flags, H, W, tiles_x);
+    return (int)hipGetLastError();
+}
 
 static int g_persist_mode = -1;      // -1: from the environment (PNP_NO_PERSIST), 0 off, 1 on
 // Diagnostic switch (not part of include/pnpvcve.h): lets tests compare the two kernels bit for bit.

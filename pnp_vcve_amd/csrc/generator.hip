@@ -28,6 +28,7 @@
 namespace {
 
 bool g_f16_storage = true;             // pnp_debug_set_f16_storage
+bool g_par_skip = true;                // pnp_debug_set_par_skip
 
 constexpr int64_t IMG_WIDE = 9 * 4096;   // floats: 9 chunks, 64 output channels
 constexpr int64_t IMG_CHUNK = 4096;      // 1 chunk, 64 output channels
@@ -294,7 +295,13 @@ struct ConvCall {
     }
     ConvCall& bias(const float* b, int ystride = 0) { bias_ = b; bias_ystride_ = ystride; return *this; }
     ConvCall& gamma(const float* g) { gamma_ = g; return *this; }
-    ConvCall& partition(const float* w1x1, const float* par) { wpar_ = w1x1; par_ = par; return *this; }
+    const int* par_flags_ = nullptr;
+    ConvCall& partition(const float* w1x1, const float* par, const int* tile_flags = nullptr) {
+        wpar_ = w1x1;
+        par_ = par;
+        par_flags_ = tile_flags;
+        return *this;
+    }
     ConvCall& residual(const float* r) { residual_ = r; return *this; }
     ConvCall& act(int a) { act_ = a; return *this; }                      // 0 none, 1 relu, 2 leaky-relu(0.1)
     ConvCall& to(float* d) { dst = d; return *this; }
@@ -308,6 +315,7 @@ struct ConvCall {
 struct Workspace {
     float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om;
     float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 only
+    int* parflags;    // per frame, per 8x16 tile: which partition planes are nonzero there (ConvArgs::par_flags)
     int64_t bytes;
 };
 
@@ -345,6 +353,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     W.mixw = take((int64_t)t * g->ndyn * IMG_WIDE);
     W.mixb = take((int64_t)t * g->ndyn * 64);
     W.mixh = g->prec == PNP_PREC_F16 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
+    W.parflags = reinterpret_cast<int*>(take((int64_t)t * ((w + 15) / 16) * ((h + 7) / 8)));
     W.bytes = off;
     return W;
 }
@@ -514,6 +523,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.wpar = q.wpar_;
         a.wpar_h = twin(q.wpar_);
         a.par = q.par_;
+        a.par_flags = q.par_flags_;
         a.par_plane = (long)q.H * q.W;
         a.bias = q.bias_;
         a.gamma = q.gamma_;
@@ -580,6 +590,12 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
 
         rc = launch_pack_lr(lr_b, W.lr4, t, h, w, st);
         if (rc) return rc;
+        // which 1x1 partition branches each 8x16 tile of each frame needs at all (32 front-half launches per frame use it)
+        const int64_t ntile = (int64_t)((w + 15) / 16) * ((h + 7) / 8);
+        for (int i = 0; i < t && g_par_skip; ++i) {
+            rc = launch_par_tile_flags(par_b + (int64_t)i * 3 * hw, hw, W.parflags + i * ntile, h, w, st);
+            if (rc) return rc;
+        }
         // ---- CAA hyper-network (iconvsr_ipb_par.py:45-48)
         for (int t0 = 0; t0 < t; t0 += 32) {
             CaaArgs a;
@@ -659,6 +675,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const BranchPk& B = g->br[brid];
             const float* gam = (c.with_bias && c.with_se) ? W.gamma + (int64_t)i * 64 : nullptr;
             const float* parp = par_b + (int64_t)i * 3 * hw;
+            const int* pflags = g_par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
             int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0));
@@ -677,7 +694,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 // the map between the two halves is read only as an MFMA A operand: an fp16 map on the fp16 path
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
-                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).bias(b2).gamma(gam).partition(packed + K.w1x1, parp)
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).bias(b2).gamma(gam).partition(packed + K.w1x1, parp, pflags)
                                  .act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).residual(x).to(dst)
@@ -686,7 +703,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                     r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).bias(b1).gamma(g1).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(gam)
-                                     .partition(packed + K.w1x1, parp).residual(x).to(dst).f16_map(s16));
+                                     .partition(packed + K.w1x1, parp, pflags).residual(x).to(dst).f16_map(s16));
                 }
                 if (r) return r;
                 x = dst;
@@ -936,6 +953,10 @@ int pnp_pack_conv1x1_f32(const float* w, float* dst, void* st) {
 // compare the two bit for bit).
 void pnp_debug_set_f16_storage(int on) { g_f16_storage = on != 0; }
 
+// Diagnostic only (not part of include/pnpvcve.h): 0 makes every tile run all three 1x1 partition branches (tests compare
+// the two bit for bit).
+void pnp_debug_set_par_skip(int on) { g_par_skip = on != 0; }
+
 // Diagnostic only (not part of include/pnpvcve.h): per-block shader-clock timeline of the next
 // pnp_conv3x3_f32 launches, 8 u64 per block.  Used by tools/trace_conv.py.
 static unsigned long long* g_conv_dbg = nullptr;
@@ -966,6 +987,11 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels,
     a.out_mode = 0;
     a.dbg = g_conv_dbg;
     return launch_conv3x3(a, conv_pick_cfg(h, w), 1, (hipStream_t)st);
+}
+
+int pnp_par_tile_flags_f32(const float* par, int* flags, int h, int w, void* st) {
+    if (!par || !flags || h < 1 || w < 1) return PNP_ERR_BAD_ARG;
+    return launch_par_tile_flags(par, (long)h * w, flags, h, w, (hipStream_t)st);
 }
 
 int pnp_f16_image_from_f32(const float* packed_w, void* dst, int nchunks, void* st) {

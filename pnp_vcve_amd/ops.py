@@ -115,6 +115,18 @@ def pack_conv1x1(weights):
     return dst
 
 
+def par_tile_flags(par):
+    """(3,h,w) partition planes -> int32 (tiles_y, tiles_x) of 8x16 tiles: bit j set iff plane j is nonzero in the tile."""
+    par = _chk(par, 'par')
+    if par.dim() != 3 or par.shape[0] != 3:
+        raise ValueError('par must be (3,h,w)')
+    h, w = par.shape[1:]
+    out = torch.empty(((h + 7) // 8, (w + 15) // 16), device=par.device, dtype=torch.int32)
+    _native.check(_native.lib().pnp_par_tile_flags_f32(_ptr(par), ctypes.c_void_p(out.data_ptr()), h, w, _stream()),
+                  'pnp_par_tile_flags_f32')
+    return out
+
+
 def f16_image(packed):
     """fp32 packed weight image (whole chunks) -> fp16 image for conv3x3(..., fp16=True)."""
     packed = _chk(packed, 'packed')

@@ -327,3 +327,36 @@ def test_forward_workspace_errors_through_the_raw_abi():
     assert call(ws.data_ptr(), need) == 0
     torch.cuda.synchronize()
     assert torch.equal(res, out)
+
+
+@pytest.mark.parametrize('par_kind', ['one_hot_blocks', 'dense_float', 'all_zero'])
+def test_partition_branch_skipping_is_bit_identical(par_kind):
+    """The persistent kernel (frames of >= 1024 tiles) skips a 1x1 partition branch on tiles where its plane is zero
+    (per-tile flags, pnp_par_tile_flags): exact zeros dropped, so the clip must not change by a single bit."""
+    import ctypes
+    from pnp_vcve_amd import _native
+    L = _native.lib()
+    L.pnp_debug_set_par_skip.argtypes = [ctypes.c_int]
+    L.pnp_debug_set_par_skip.restype = None
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    sd_np = gu.syn.make_state_dict(cfg, seed=95, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=96, n=1, t=3, h=256, w=512, slices='IBBBP', block=8,
+                            par_scale=1.0 if par_kind == 'dense_float' else 1 / 255.0)
+    if par_kind == 'dense_float':
+        clip['partitions'] = gu.syn.uniform(97, 'pf', clip['partitions'].shape, 0.0, 1.0)
+    elif par_kind == 'all_zero':
+        clip['partitions'] = np.zeros_like(clip['partitions'])
+    else:
+        planes = (clip['partitions'][0, 1:] != 0).sum(1)             # P/B frames: at most one plane per pixel
+        assert planes.max() == 1 and planes.mean() > 0.5 and float(np.abs(clip['partitions'][0, 0]).max()) == 0.0
+    m = build(cfg, sd_np)
+    try:
+        L.pnp_debug_set_par_skip(0)
+        ref = run(m, clip).clone()
+    finally:
+        L.pnp_debug_set_par_skip(1)
+    out = run(m, clip)
+    assert torch.equal(out, ref)
+    if par_kind == 'one_hot_blocks':          # and the branch is live: zeroing the map changes the result
+        clip0 = dict(clip, partitions=np.zeros_like(clip['partitions']))
+        assert float((run(m, clip0) - out).abs().max()) > 1e-5

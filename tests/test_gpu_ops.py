@@ -359,3 +359,22 @@ def test_frames_to_rgb8_matches_tensor2img():
     q = ops.frames_to_rgb8(x.to(dev())).cpu().numpy()
     for i in range(4):
         assert np.array_equal(q[i], tensor2img(x[i])[..., ::-1])
+
+
+def test_par_tile_flags_vs_numpy():
+    from pnp_vcve_amd import ops
+    h, w = 100, 150                                        # ragged: 13 x 10 tiles
+    par = np.zeros((3, h, w), np.float32)
+    par[0, 0:8, 0:16] = 1 / 255.0                          # tile (0,0): plane 0
+    par[1, 8:16, 16:32] = 0.5                              # tile (1,1): plane 1
+    par[2, 95:100, 140:150] = 1e-30                        # last (ragged) tile: plane 2, tiny but nonzero
+    par[0, 40, 70] = -0.0                                  # negative zero is zero
+    par[1, 17, 5] = 1.0
+    par[2, 17, 6] = 1.0                                    # tile (2,0): planes 1 and 2
+    got = ops.par_tile_flags(G(par)).cpu().numpy()
+    exp = np.zeros(((h + 7) // 8, (w + 15) // 16), np.int32)
+    for ty in range(exp.shape[0]):
+        for tx in range(exp.shape[1]):
+            blk = par[:, ty * 8:ty * 8 + 8, tx * 16:tx * 16 + 16]
+            exp[ty, tx] = sum(int((blk[j] != 0).any()) << j for j in range(3))
+    assert np.array_equal(got, exp) and got[0, 0] == 1 and got[1, 1] == 2 and got[2, 0] == 6 and got[-1, -1] == 4
