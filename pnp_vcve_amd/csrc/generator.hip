@@ -50,6 +50,8 @@ struct BlockPk {
 struct BranchPk {
     int64_t in_lr = -1;           // packed, 1 chunk
     int64_t in_wide[3] = {-1, -1, -1};
+    int64_t in_wide01 = -1;       // packed: in_wide[0] + in_wide[1] (align_key with an adjacent key frame: both are the
+                                  // same warped tensor, conv(x, W0) + conv(x, W1) = conv(x, W0 + W1))
     int n_wide = 0;
     int64_t in_bias = -1;         // flat
     std::vector<BlockPk> blocks;
@@ -81,6 +83,7 @@ struct pnp_generator {
     int64_t dyn_w = 0, dyn_b = 0;     // flat offsets of the dynamic conv banks
     BranchPk br[2];                   // 0 backward, 1 forward
     int64_t hr_img = -1, hr_bias = -1, last_img = -1, last_bias = -1;       // last_bias packed (32)
+    int64_t ones2 = -1;                                                     // packed: {1, 1}
     int64_t up_img[2] = {-1, -1}, up_bias[2] = {-1, -1};                    // packed
     // deform = 'basic' | 'fvc' (iconvsr_mv.py:21-84): flat offsets of the aligner's parameters, packed images
     int64_t f_dcn_w = -1, f_dcn_b = -1, f_off0_w = -1, f_off0_b = -1, f_off2_w = -1, f_off2_b = -1;
@@ -169,6 +172,7 @@ int build_layout(pnp_generator* g) {
         B.in_bias = g->add_param(std::string(brn[b]) + ".input_conv.0.bias", {64});
         B.in_lr = g->add_packed(IMG_CHUNK);
         for (int s = 0; s < B.n_wide; ++s) B.in_wide[s] = g->add_packed(IMG_WIDE);
+        if (c.with_cat && c.align_key) B.in_wide01 = g->add_packed(IMG_WIDE);
         g->f_conv1_w[b].assign(nb, -1);
         g->f_1x1_w[b].assign(nb * 3, -1);
         for (int i = 0; i < nb; ++i) {
@@ -196,6 +200,7 @@ int build_layout(pnp_generator* g) {
         g->off2_img = g->add_packed(7 * IMG_WIDE);
         g->off2_bias = g->add_packed(448);
     }
+    g->ones2 = g->add_packed(64);
     g->f_hr_w = g->add_param("conv_hr.weight", {64, 64, 3, 3});
     g->hr_bias = g->add_param("conv_hr.bias", {64});
     g->hr_img = g->add_packed(IMG_WIDE);
@@ -213,6 +218,10 @@ int build_layout(pnp_generator* g) {
         }
     }
     return PNP_OK;
+}
+
+__global__ void fill_kernel(float* dst, float v, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v;
 }
 
 __global__ void small_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_valid, int n_total,
@@ -416,6 +425,15 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
         for (int s = 0; s < B.n_wide; ++s) {
             rc = launch_pack_weights(
                 plain_pack(flat + g->f_in_w[b], cin, 9, PACK_WIDE, 3 + 64 * s, 2, 64, packed + B.in_wide[s]), 1, st);
+            if (rc) return rc;
+        }
+        if (B.in_wide01 >= 0) {       // the "expert" mechanism with weights (1, 1) over the two 64-channel input ranges
+            hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, packed + g->ones2, 1.0f, 2);
+            PackArgs a = plain_pack(flat + g->f_in_w[b], cin, 9, PACK_WIDE, 3, 2, 64, packed + B.in_wide01);
+            a.ew = packed + g->ones2;
+            a.E = 2;
+            a.e_stride = 64 * 9;
+            rc = launch_pack_weights(a, 1, st);
             if (rc) return rc;
         }
         for (int i = 0; i < c.num_blocks; ++i) {
@@ -721,9 +739,12 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 while (!key[k]) ++k;
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw, mv_b + ((int64_t)i * 4 + 3) * hw);
                 if (rc) return rc;
-                in.source(W.kw, 64, packed + B.in_wide[0]);
-                if (c.with_cat)
-                    in.source((c.align_key && k == i + 1) ? W.kw : W.slots + (int64_t)(i + 1) * fm, 64, packed + B.in_wide[1]);
+                if (c.with_cat && c.align_key && k == i + 1) {     // neighbour == key frame: one source, summed weights
+                    in.source(W.kw, 64, packed + B.in_wide01);
+                } else {
+                    in.source(W.kw, 64, packed + B.in_wide[0]);
+                    if (c.with_cat) in.source(W.slots + (int64_t)(i + 1) * fm, 64, packed + B.in_wide[1]);
+                }
             }
             rc = run_branch(0, i, in);
             if (rc) return rc;
@@ -738,9 +759,12 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 while (!key[k]) --k;
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw, mv_b + ((int64_t)i * 4 + 1) * hw);
                 if (rc) return rc;
-                in.source(W.kw, 64, packed + B.in_wide[0]);
-                if (c.with_cat)
-                    in.source((c.align_key && k == i - 1) ? W.kw : W.slots + (int64_t)(i - 1) * fm, 64, packed + B.in_wide[1]);
+                if (c.with_cat && c.align_key && k == i - 1) {
+                    in.source(W.kw, 64, packed + B.in_wide01);
+                } else {
+                    in.source(W.kw, 64, packed + B.in_wide[0]);
+                    if (c.with_cat) in.source(W.slots + (int64_t)(i - 1) * fm, 64, packed + B.in_wide[1]);
+                }
             }
             in.source(W.slots + (int64_t)i * fm, 64, packed + B.in_wide[B.n_wide - 1]);   // backward feature of this frame
             rc = run_branch(1, i, in);
