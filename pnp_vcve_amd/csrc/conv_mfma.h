@@ -16,7 +16,8 @@ struct ConvArgs {
     const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
     const int* par_flags;   // optional, one int per 8x16 tile (row-major): bit j set <=> plane j has a nonzero value in
                             // the tile (launch_par_tile_flags).  The persistent kernel skips the 1x1 branches whose
-                            // plane is zero over its whole tile -- exact zeros, bit-identical result.  nullptr: none skipped
+                            // plane is zero over its whole tile -- exact zeros, bit-identical result for finite activations (a skipped
+                            // 0 * inf would have been NaN).  nullptr: none skipped
     long par_plane;         // floats between planes
     const float* bias;      // [N] or nullptr
     const float* gamma;     // [N] channel gain applied to (conv + bias) BEFORE the 1x1 branches, or nullptr
