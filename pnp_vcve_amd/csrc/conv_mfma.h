@@ -9,6 +9,7 @@ struct ConvArgs {
     int src_c[4];           // 64 or 4
     int nsrc;
     const float* wpar;      // 3 chunks (conv16x16, conv16x8, conv8x8) or nullptr
+    const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
     const void* wsrc_h[4];  // fp16 twins of wsrc / wpar (conv_f16.hip), read only when prec == 1
     const void* wpar_h;
     int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
@@ -51,6 +52,11 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream);
 
 // per-tile summary of a partition map for ConvArgs::par_flags (conv_persist.hip); flags: ((W+15)/16) * ((H+7)/8) ints
 int launch_par_tile_flags(const float* par, long par_plane, int* flags, int H, int W, hipStream_t stream);
+
+// conv_last on the vector ALUs (conv_last.hip): OIHW (3,64,3,3) -> [9][64][4]; 2304 floats
+int launch_pack_last_valu(const float* w_oihw, float* dst, hipStream_t stream);
+bool conv_last_valu_eligible(const ConvArgs& a, int cfg, int grid_y);
+int launch_conv_last_valu(const ConvArgs& a, hipStream_t stream);
 
 // persistent single-source variant (conv_persist.hip)
 bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y);

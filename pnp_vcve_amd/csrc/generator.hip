@@ -29,6 +29,7 @@ namespace {
 
 bool g_f16_storage = true;             // pnp_debug_set_f16_storage
 bool g_par_skip = true;                // pnp_debug_set_par_skip
+bool g_conv_last_valu = true;          // pnp_debug_set_conv_last_valu
 
 constexpr int64_t IMG_WIDE = 9 * 4096;   // floats: 9 chunks, 64 output channels
 constexpr int64_t IMG_CHUNK = 4096;      // 1 chunk, 64 output channels
@@ -84,6 +85,7 @@ struct pnp_generator {
     BranchPk br[2];                   // 0 backward, 1 forward
     int64_t hr_img = -1, hr_bias = -1, last_img = -1, last_bias = -1;       // last_bias packed (32)
     int64_t ones2 = -1;                                                     // packed: {1, 1}
+    int64_t last_valu = -1;                                                 // packed: conv_last weights [9][64][4]
     int64_t up_img[2] = {-1, -1}, up_bias[2] = {-1, -1};                    // packed
     // deform = 'basic' | 'fvc' (iconvsr_mv.py:21-84): flat offsets of the aligner's parameters, packed images
     int64_t f_dcn_w = -1, f_dcn_b = -1, f_off0_w = -1, f_off0_b = -1, f_off2_w = -1, f_off2_b = -1;
@@ -208,6 +210,7 @@ int build_layout(pnp_generator* g) {
     g->f_last_b = g->add_param("conv_last.bias", {3});
     g->last_img = g->add_packed(IMG_RGB);
     g->last_bias = g->add_packed(32);
+    g->last_valu = g->add_packed(9 * 64 * 4);
     if (c.vsr) {
         for (int u = 0; u < 2; ++u) {
             const std::string p = "upsample" + std::to_string(u + 1) + ".upsample_conv.";
@@ -316,7 +319,14 @@ struct ConvCall {
     ConvCall& to(float* d) { dst = d; return *this; }
     // out_mode of conv_mfma.h with `gy` weight images `w_ystride` floats apart (pixel shuffle: 4, DCN offsets: 7)
     ConvCall& mode(int m, int gy = 1, long w_ystride = 0) { mode_ = m; gy_ = gy; w_ystride_ = w_ystride; return *this; }
-    ConvCall& rgb(const float* lr, long plane) { lr_ = lr; lr_plane_ = plane; return *this; }
+    const float* wvalu_ = nullptr;
+    // conv_last: the frame to add (3 NCHW planes) and the weights in the vector-ALU kernel's layout
+    ConvCall& rgb(const float* lr, long plane, const float* wvalu = nullptr) {
+        lr_ = lr;
+        lr_plane_ = plane;
+        wvalu_ = wvalu;
+        return *this;
+    }
     // fp16 path: 1 = the output is an fp16 map, 2 = the (single) source is one
     ConvCall& f16_map(int io16) { io16_ = io16; return *this; }
 };
@@ -475,6 +485,8 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
     rc = launch_pack_weights(plain_pack(flat + g->f_last_w, 64, 9, PACK_WIDE, 0, 1, 3, packed + g->last_img), 1, st);
     if (rc) return rc;
     hipLaunchKernelGGL(small_copy_kernel, dim3(1), dim3(64), 0, st, flat + g->f_last_b, packed + g->last_bias, 3, 32, 0);
+    rc = launch_pack_last_valu(flat + g->f_last_w, packed + g->last_valu, st);
+    if (rc) return rc;
     if (c.vsr) {
         for (int u = 0; u < 2; ++u) {
             for (int sub = 0; sub < 4; ++sub) {
@@ -549,6 +561,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.out = q.dst;
         a.lr = q.lr_;
         a.lr_plane = q.lr_plane_;
+        a.wvalu = g_conv_last_valu ? q.wvalu_ : nullptr;
         a.w_ystride = q.w_ystride_;
         a.bias_ystride = q.bias_ystride_;
         a.H = q.H;
@@ -780,7 +793,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                               .to(W.tmp1).f16_map(o16));
                 if (!rc)
                     rc = conv(ConvCall(h, w, CONV_CFG_RGB).source(W.tmp1, 64, packed + g->last_img).bias(packed + g->last_bias)
-                                  .mode(2).rgb(lr_i, hw).to(out_i).f16_map(s16));
+                                  .mode(2).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));
                 if (rc) return rc;
             } else {        // :135-142: two PixelShufflePack(2) convs (4 sub-pixel weight images each), conv_hr, conv_last + x4 bilinear lr
                 rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->up_img[0]).bias(packed + g->up_bias[0], 64)
@@ -793,7 +806,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                                   .bias(flat + g->hr_bias).act(2).to(W.u3).f16_map(o16));
                 if (!rc)
                     rc = conv(ConvCall(4 * h, 4 * w, CONV_CFG_RGB).source(W.u3, 64, packed + g->last_img)
-                                  .bias(packed + g->last_bias).mode(3).rgb(lr_i, hw).to(out_i).f16_map(s16));
+                                  .bias(packed + g->last_bias).mode(3).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));
                 if (rc) return rc;
             }
         }
@@ -980,6 +993,9 @@ void pnp_debug_set_f16_storage(int on) { g_f16_storage = on != 0; }
 // Diagnostic only (not part of include/pnpvcve.h): 0 makes every tile run all three 1x1 partition branches (tests compare
 // the two bit for bit).
 void pnp_debug_set_par_skip(int on) { g_par_skip = on != 0; }
+
+// Diagnostic only (not part of include/pnpvcve.h): 0 sends conv_last back to the MFMA kernel (tests compare the two).
+void pnp_debug_set_conv_last_valu(int on) { g_conv_last_valu = on != 0; }
 
 // Diagnostic only (not part of include/pnpvcve.h): per-block shader-clock timeline of the next
 // pnp_conv3x3_f32 launches, 8 u64 per block.  Used by tools/trace_conv.py.

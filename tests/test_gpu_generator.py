@@ -360,3 +360,26 @@ def test_partition_branch_skipping_is_bit_identical(par_kind):
     if par_kind == 'one_hot_blocks':          # and the branch is live: zeroing the map changes the result
         clip0 = dict(clip, partitions=np.zeros_like(clip['partitions']))
         assert float((run(m, clip0) - out).abs().max()) > 1e-5
+
+
+@pytest.mark.parametrize('vsr', [False, True])
+def test_conv_last_on_the_vector_alus_matches_the_mfma_kernel(vsr):
+    """conv_last (64 -> 3) runs on the VALUs with scalar weights (conv_last.hip); against the MFMA kernel it replaces
+    (same fp32 products, different summation order) on a ragged frame, both output modes."""
+    import ctypes
+    from pnp_vcve_amd import _native
+    L = _native.lib()
+    L.pnp_debug_set_conv_last_valu.argtypes = [ctypes.c_int]
+    L.pnp_debug_set_conv_last_valu.restype = None
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=1, vsr=vsr)
+    sd_np = gu.syn.make_state_dict(cfg, seed=101, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=102, n=1, t=2, h=68, w=100, slices='IBBBP', block=4)
+    m = build(cfg, sd_np)
+    try:
+        L.pnp_debug_set_conv_last_valu(0)
+        ref = run(m, clip).clone()
+    finally:
+        L.pnp_debug_set_conv_last_valu(1)
+    out = run(m, clip)
+    d = float((out - ref).abs().max())
+    assert out.shape == ref.shape and 0.0 < d < 2e-6, d
