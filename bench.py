@@ -102,7 +102,7 @@ def main():
     ap.add_argument('--clips', type=int, default=1,
                     help='clips per GPU per step (one batch; small frames run them concurrently, DESIGN.md section 4)')
     ap.add_argument('--graphs', action='store_true',
-                    help='replay each clip as one hipGraph (generator.use_graphs; frames below 512x512 only)')
+                    help='replay each clip as one hipGraph (generator.use_graphs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-kernel HIP-event timing')
     args = ap.parse_args()

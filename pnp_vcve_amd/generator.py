@@ -201,7 +201,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             qp_p = ctypes.cast(base + 4 * n * t, fp)
             bq_p = ctypes.cast(base + 8 * n * t, fp)
             s = 4 if self.vsr else 1
-            if self.use_graphs and h * w < self.CONCURRENT_BELOW_PIXELS and not self._profiling:
+            if self.use_graphs and not self._profiling:
                 return self._forward_graphed(lrs_c, mvs_c, par_c, side, (n, t, 3, h * s, w * s))
             out = torch.empty((n, t, 3, h * s, w * s), device=dev, dtype=torch.float32)
             ws = self._get_workspace(n, t, h, w, dev)
@@ -233,7 +233,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         key = (n, t, h, w, str(dev), side.numpy().tobytes(), self._packed.data_ptr(), self._packed_floats)
         ent = self._graphs.get(key)
         if ent is None:
-            ctx = min(n, self.MAX_CONTEXTS)
+            ctx = 1 if h * w >= self.CONCURRENT_BELOW_PIXELS else min(n, self.MAX_CONTEXTS)
             nbytes = int(_native.lib().pnp_generator_workspace_bytes(self._handle, t, h, w)) * ctx
             ent = dict(lrs=torch.empty_like(lrs_c), mvs=torch.empty_like(mvs_c), par=torch.empty_like(par_c),
                        out=torch.empty(out_shape, device=dev, dtype=torch.float32),
