@@ -116,3 +116,25 @@ def test_dist_test_driver_two_ranks_equals_one_rank():
     get = lambda s, k: re.search(rf'Eval-{k}: ([0-9.]+)', s).group(1)      # noqa: E731
     assert 'world 2' in two.stdout and 'world 1' in one.stdout
     assert get(one.stdout, 'PSNR') == get(two.stdout, 'PSNR') and get(one.stdout, 'SSIM') == get(two.stdout, 'SSIM')
+
+
+def test_bench_emits_the_contract_line():
+    """bench.py on a tiny workload: ONE JSON line with the driver's keys, the roofline / cpu_baseline / parity objects."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', '128', '--frames', '3',
+                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['dtype'] == 'f32' and d['vs_baseline'] is None
+    assert d['value'] > 0 and abs(d['value'] - 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
+    assert d['parity']['max_abs_diff_vs_cpu'] < d['parity']['gate']
+    assert 'workload' in d['config'] and 'model' not in d['config']
