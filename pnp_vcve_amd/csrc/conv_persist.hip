@@ -288,7 +288,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
             // the tile's last chunk is always a branch chunk (it carries the next halo request): a tile that needs no
-            // branch still runs one, on a plane of zeros
+            // branch still runs one, on a plane of zeros.  (Measured and rejected: a second, branch-free tile body for
+            // frames without any record -- I frames -- selected by a per-frame flag: the merged kernel spills 31 instead
+            // of 8 registers and the plain kernel grows from 205 to 231, which costs what the 32 dummy chunks saved.)
             int cur = j0;
             for (int i = 0; i + 1 < cnt; ++i) {
                 const int nxt = i == 0 ? j1 : 2;
