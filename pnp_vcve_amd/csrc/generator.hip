@@ -840,6 +840,9 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
     if (n < 1 || t < 1) return PNP_ERR_BAD_ARG;
     if (h < 64 || w < 64) return PNP_ERR_SIZE_ASSERT;
     if ((h % 4) || (w % 4)) return PNP_ERR_SIZE_VALUE;
+    // the kernels address a feature map with 32-bit byte offsets: the largest one (x16 pixels with the x4 heads) must
+    // stay below 4 GiB (2160p, or 720p -> 2880p with vsr, still fit)
+    if ((int64_t)h * w * 256 * (g->cfg.vsr ? 16 : 1) >= (int64_t)1 << 32) return PNP_ERR_UNSUPPORTED;
     const int64_t ctx_bytes = carve(g, nullptr, t, h, w).bytes;
     if (workspace_bytes < ctx_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255)) return PNP_ERR_WORKSPACE;
     const int64_t hw = (int64_t)h * w;

@@ -251,3 +251,27 @@ def test_f16_randomised_configs_track_the_fp32_path():
         print(f'trial {trial}: deform={cfg["deform"]} vsr={cfg["vsr"]} {n}x{t}x{h}x{w}  max|fp16-fp32|/scale = {d:.3e}')
         assert 0.0 < d < TOL_F16_PATH, (trial, cfg, (n, t, h, w), d, scale)
     print('worst', worst)
+
+
+def test_f16_full_width_720p_tracks_fp32():
+    """Full-size frame (all 7200 tiles incl. every image edge, the persistent fp16 kernels, the RGB head): the fp16 path
+    against the fp32 path of the same build on a 2-frame 720p clip -- PSNR statistic and max-abs."""
+    import pnp_vcve_amd as P
+    from pnp_vcve_amd import ops
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    sd_np = gu.syn.make_state_dict(cfg, seed=111, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=112, n=1, t=2, h=720, w=1280, slices='IBBBP')
+    m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+    m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
+    m = m.to(dev()).eval()
+    a = {k: G(v) for k, v in clip.items()}
+    outs = []
+    for f16 in (False, True):
+        m.fp16_enabled = f16
+        with torch.no_grad():
+            outs.append(m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']))
+    d = float((outs[0] - outs[1]).abs().max())
+    p32 = float(ops.psnr_frames(outs[0][0], a['gt'][0]).mean())
+    p16 = float(ops.psnr_frames(outs[1][0], a['gt'][0]).mean())
+    print(f'720p: max|fp16 - fp32| = {d:.3e}, PSNR {p32:.5f} vs {p16:.5f} dB')
+    assert 0.0 < d < TOL_F16_PATH and abs(p32 - p16) < 1e-3

@@ -95,3 +95,20 @@ def test_c_abi_error_codes_without_a_gpu(lib):
     assert lib.pnp_generator_workspace_bytes(h, 7, 128, 128) > ctx       # + mirror of the mixed experts
     assert n32 % 4096 == 0 and ctx % 256 == 0
     lib.pnp_generator_destroy(h)
+
+
+def test_forward_refuses_maps_beyond_32_bit_offsets_before_touching_memory(lib):
+    """Feature maps are addressed with 32-bit byte offsets: a frame whose largest map reaches 4 GiB is PNP_ERR_UNSUPPORTED
+    (1002), decided on the host before any launch (so this runs without a GPU, with null buffers)."""
+    import ctypes
+    kw = dict(mid_channels=64, num_blocks=1, num_experts=2, with_cat=1, use_base_qp=1, expert_softmax=1, with_bias=1,
+              with_se=1, one_layer=1, channel_first=1, align_key=1, vsr=0, deform=0)
+    for vsr, hw, rc_exp in ((0, (4096, 4096), 1002), (1, (1024, 1024), 1002), (0, (60, 64), 1004), (0, (66, 64), 1005)):
+        kw['vsr'] = vsr
+        h = ctypes.c_void_p()
+        assert lib.pnp_generator_create(ctypes.byref(_native.GeneratorCfg(**kw)), ctypes.byref(h)) == 0
+        side = (ctypes.c_float * 1)(73.0)
+        rc = lib.pnp_generator_forward(h, None, None, None, None, None, side, side, side, None, None, 0, 1, 1, hw[0], hw[1],
+                                       None)
+        assert rc == rc_exp, (vsr, hw, rc)
+        lib.pnp_generator_destroy(h)
