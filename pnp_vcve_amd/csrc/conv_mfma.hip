@@ -289,6 +289,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     if (!rgb0) stage_wide_store();
     store_b(0);
 
+    // ---- which 1x1 partition branches this tile needs (flags are per 8x16 tile; a 4x16 tile uses its parent's)
+    int par_need = a.wpar ? 7 : 0;
+    if (a.wpar && a.par_flags) par_need = a.par_flags[(ty0 >> 3) * ((W + 15) >> 4) + (tx0 >> 4)];
+    const int par_cnt = (par_need & 1) + ((par_need >> 1) & 1) + ((par_need >> 2) & 1);
+    const int par_j0 = (par_need & 1) ? 0 : ((par_need & 2) ? 1 : 2);
+    const int par_j1 = ((par_need & 3) == 3) ? 1 : 2;
+
     // ---- sources (only source 0 may be the 4-channel frame); chunk images are 9 (wide) or 1 (rgb)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             const f32x4* wb = reinterpret_cast<const f32x4*>(a.wsrc[s] + yoff);
             const f32x4* after = nullptr;      // first chunk after this source
             if (s + 1 < a.nsrc) after = reinterpret_cast<const f32x4*>(a.wsrc[s + 1 < 4 ? s + 1 : 3] + yoff);
-            else if (a.wpar) after = reinterpret_cast<const f32x4*>(a.wpar + yoff);
+            else if (par_cnt) after = reinterpret_cast<const f32x4*>(a.wpar + yoff) + (long)par_j0 * CH4;
             // sA is free here: every wave passed the last chunk's barrier after its final A read
             if (s > 0) {
                 __builtin_amdgcn_s_setprio(3);
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             if (is_rgb) {
                 run_chunk(K1{}, Q5{}, T<0>{}, T<-1>{}, 1.f, after);
             } else {
-                const bool par_next = (s + 1 >= a.nsrc) && a.wpar;
+                const bool par_next = (s + 1 >= a.nsrc) && par_cnt;
                 run_chunk(K0{}, Q8{}, T<0>{}, T<1>{}, 1.f, wb + 1L * CH4);
                 run_chunk(K0{}, Q8{}, T<1>{}, T<2>{}, 1.f, wb + 2L * CH4);
                 run_chunk(K0{}, Q8{}, T<2>{}, T<3>{}, 1.f, wb + 3L * CH4);
@@ -333,11 +340,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
-    if (a.wpar) {
+    if (par_cnt) {      // only the branches whose plane is nonzero somewhere in the tile (ConvArgs::par_flags)
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpar + yoff);
-        run_chunk(K2{}, Q8{}, T<4>{}, T<4>{}, pv[0], wp + 1L * CH4);
-        run_chunk(K2{}, Q8{}, T<4>{}, T<4>{}, pv[1], wp + 2L * CH4);
-        run_chunk(K2{}, Q8{}, T<4>{}, T<-1>{}, pv[2], nullptr);
+        int cur = par_j0;
+        for (int i = 0; i + 1 < par_cnt; ++i) {
+            const int nxt = i == 0 ? par_j1 : 2;
+            run_chunk(K2{}, Q8{}, T<4>{}, T<4>{}, cur == 0 ? pv[0] : (cur == 1 ? pv[1] : pv[2]), wp + (long)nxt * CH4);
+            cur = nxt;
+        }
+        run_chunk(K2{}, Q8{}, T<4>{}, T<-1>{}, cur == 0 ? pv[0] : (cur == 1 ? pv[1] : pv[2]), nullptr);
     }
     if (a.dbg) dbg_t2 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_setprio(3);

@@ -329,10 +329,11 @@ def test_forward_workspace_errors_through_the_raw_abi():
     assert torch.equal(res, out)
 
 
+@pytest.mark.parametrize('hw', [(256, 512), (72, 96)], ids=['persistent_kernel', 'tile_kernel_4x16'])
 @pytest.mark.parametrize('par_kind', ['one_hot_blocks', 'dense_float', 'all_zero'])
-def test_partition_branch_skipping_is_bit_identical(par_kind):
-    """The persistent kernel (frames of >= 1024 tiles) skips a 1x1 partition branch on tiles where its plane is zero
-    (per-tile flags, pnp_par_tile_flags): exact zeros dropped, so the clip must not change by a single bit."""
+def test_partition_branch_skipping_is_bit_identical(par_kind, hw):
+    """Both conv kernels skip a 1x1 partition branch on tiles where its plane is zero (per-tile flags,
+    pnp_par_tile_flags_f32): exact zeros dropped, so the clip must not change by a single bit."""
     import ctypes
     from pnp_vcve_amd import _native
     L = _native.lib()
@@ -340,7 +341,7 @@ def test_partition_branch_skipping_is_bit_identical(par_kind):
     L.pnp_debug_set_par_skip.restype = None
     cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
     sd_np = gu.syn.make_state_dict(cfg, seed=95, par_gain=10.0)
-    clip = gu.syn.make_clip(seed=96, n=1, t=3, h=256, w=512, slices='IBBBP', block=8,
+    clip = gu.syn.make_clip(seed=96, n=1, t=3, h=hw[0], w=hw[1], slices='IBBBP', block=8,
                             par_scale=1.0 if par_kind == 'dense_float' else 1 / 255.0)
     if par_kind == 'dense_float':
         clip['partitions'] = gu.syn.uniform(97, 'pf', clip['partitions'].shape, 0.0, 1.0)
