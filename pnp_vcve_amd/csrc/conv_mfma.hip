@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    // MFMA row m of the wave's 2 x 16 pixel slice: row 1 is rotated by two pixels (m = 16 + i is pixel (i - 2) mod 16) so
+    // that the two rows of a ds_read_b128 lane group fall on disjoint banks (see conv_persist.hip)
+    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = my ? ((m + 14) & 15) : (m & 15);
     const int H = a.H, W = a.W;
 
     // ---- tile id, remapped so that each XCD (blocks b, b+8, ...) walks a contiguous band
@@ -365,7 +367,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             for (int r = 0; r < 16; ++r) {
                 float v = acc[j][r];
                 v = fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f);     // branch-free none / relu / leaky-relu
-                sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (NT * 32) + j * 32 + n0] = v;
+                const int mm = (r & 3) + 8 * (r >> 2) + 4 * h;                  // MFMA row -> pixel of the slice
+                sT[((r >> 3) ? 16 + ((mm + 14) & 15) : mm) * (NT * 32) + j * 32 + n0] = v;
             }
         asm volatile("" ::: "memory");      // keep the row reads below behind the column writes above
         const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
@@ -388,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
             const int co = (wn * NT + j) * 32 + n0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mm = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int mrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int mm = (r >> 3) ? 16 + ((mrow + 14) & 15) : mrow;       // MFMA row -> pixel of the slice
                 const int gy = ty0 + 2 * wm + (mm >> 4), gx = tx0 + (mm & 15);
                 if (gy >= H || gx >= W || co >= 3) continue;
                 float v = acc[j][r];

@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave;
-    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    // MFMA row m of the wave's 2 x 16 pixel slice: row 0 is pixels 0..15 in order, row 1 is ROTATED by two pixels
+    // (m = 16 + i is pixel (i - 2) mod 16).  With the 272-B pixel stride the 18-pixel halo rows are 32 B off a multiple
+    // of 256 B, so in a ds_read_b128 lane group (4 + 4 lanes of row 0, 8 of row 1) the unrotated rows shared 8 banks
+    // (2-way conflicts on 18 % of the LDS cycles); rotated, the two rows tile all 64 banks.
+    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = my ? ((m + 14) & 15) : (m & 15);
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
     const int ntiles = tiles_x * ((H + TH - 1) / TH);
@@ -322,7 +326,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
             for (int r = 0; r < 16; ++r) {
                 float v = acc[j][r];
                 v = fmaxf(v, 0.f) + neg_slope * fminf(v, 0.f);     // branch-free none / relu / leaky-relu
-                sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (NT * 32) + j * 32 + n0] = v;
+                const int mm = (r & 3) + 8 * (r >> 2) + 4 * h;                  // MFMA row -> pixel of the slice
+                const int pp = (r >> 3) ? 16 + ((mm + 14) & 15) : mm;
+                sT[pp * (NT * 32) + j * 32 + n0] = v;
             }
         asm volatile("" ::: "memory");
         unsigned long long dbg_x = 0;
