@@ -51,7 +51,8 @@ bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y);
 int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream);
 
 // per-tile summary of a partition map for ConvArgs::par_flags (conv_persist.hip); flags: ((W+15)/16) * ((H+7)/8) ints
-int launch_par_tile_flags(const float* par, long par_plane, int* flags, int H, int W, hipStream_t stream);
+// frames consecutive (3, H, W) maps -> frames consecutive flag arrays
+int launch_par_tile_flags(const float* par, long par_plane, int* flags, int frames, int H, int W, hipStream_t stream);
 
 // conv_last on the vector ALUs (conv_last.hip): OIHW (3,64,3,3) -> [9][64][4]; 2304 floats
 int launch_pack_last_valu(const float* w_oihw, float* dst, hipStream_t stream);

@@ -397,8 +397,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
 }  // namespace
 
 namespace {
+// blockIdx.y = frame: par advances by 3 planes, flags by gridDim.x
 __global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __restrict__ par, long plane, int* __restrict__ flags,
                                                              int H, int W, int tiles_x) {
+    par += (long)blockIdx.y * 3 * plane;
+    flags += (long)blockIdx.y * gridDim.x;
     const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int gy = ty * TH + (threadIdx.x >> 4), gx = tx * TW + (threadIdx.x & 15);
     const bool in = gy < H && gx < W;
@@ -412,9 +415,9 @@ __global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __rest
 }
 }  // namespace
 
-int launch_par_tile_flags(const float* par, long par_plane, int* flags, int H, int W, hipStream_t stream) {
+int launch_par_tile_flags(const float* par, long par_plane, int* flags, int frames, int H, int W, hipStream_t stream) {
     const int tiles_x = (W + TW - 1) / TW, tiles = tiles_x * ((H + TH - 1) / TH);
-    hipLaunchKernelGGL(par_tile_flags_kernel, dim3(tiles), dim3(128), 0, stream, par, par_plane, flags, H, W, tiles_x);
+    hipLaunchKernelGGL(par_tile_flags_kernel, dim3(tiles, frames), dim3(128), 0, stream, par, par_plane, flags, H, W, tiles_x);
     return (int)hipGetLastError();
 }
 

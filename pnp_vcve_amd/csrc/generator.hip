@@ -636,9 +636,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         rc = launch_pack_lr(lr_b, W.lr4, t, h, w, st);
         if (rc) return rc;
         // which 1x1 partition branches each 8x16 tile of each frame needs at all (32 front-half launches per frame use it)
-        const int64_t ntile = (int64_t)((w + 15) / 16) * ((h + 7) / 8);
-        for (int i = 0; i < t && g_par_skip; ++i) {
-            rc = launch_par_tile_flags(par_b + (int64_t)i * 3 * hw, hw, W.parflags + i * ntile, h, w, st);
+        if (g_par_skip) {
+            rc = launch_par_tile_flags(par_b, hw, W.parflags, t, h, w, st);
             if (rc) return rc;
         }
         // ---- CAA hyper-network (iconvsr_ipb_par.py:45-48)
@@ -1049,7 +1048,7 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels,
 
 int pnp_par_tile_flags_f32(const float* par, int* flags, int h, int w, void* st) {
     if (!par || !flags || h < 1 || w < 1) return PNP_ERR_BAD_ARG;
-    return launch_par_tile_flags(par, (long)h * w, flags, h, w, (hipStream_t)st);
+    return launch_par_tile_flags(par, (long)h * w, flags, 1, h, w, (hipStream_t)st);
 }
 
 int pnp_f16_image_from_f32(const float* packed_w, void* dst, int nchunks, void* st) {
