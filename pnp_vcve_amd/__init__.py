@@ -6,5 +6,6 @@ Importing the package registers the generator under the reference's registry nam
 from .registry import (BACKBONES, COMPONENTS, DATASETS, LOSSES, MODELS, PIPELINES, Registry,  # noqa: F401
                        build_backbone, build_component, build_from_cfg, build_loss, build_model)
 from . import generator  # noqa: F401  (registers the class)
+from . import torch_ops  # noqa: F401  (registers torch.ops.pnpvcve.*)
 
 __version__ = '0.1.0'

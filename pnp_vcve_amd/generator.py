@@ -79,6 +79,8 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         self._workspace = {}
         self._graphs = {}
         self._profiling = False
+        from . import torch_ops
+        self._op_handle = torch_ops.register_generator(self)       # id under which torch.ops.pnpvcve finds this module
 
     # ---------------------------------------------------------------- precision
     @property
@@ -195,16 +197,19 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             # the three (n,t,1,1,1) side-info tensors drive host control flow (key frames, expert dedup)
             side = torch.stack([slices.reshape(n, t).float(), QPs.reshape(n, t).float(),
                                 base_QPs.reshape(n, t).float()]).cpu().contiguous()
-            fp = ctypes.POINTER(ctypes.c_float)
-            base = side.data_ptr()
-            sl_p = ctypes.cast(base, fp)
-            qp_p = ctypes.cast(base + 4 * n * t, fp)
-            bq_p = ctypes.cast(base + 8 * n * t, fp)
-            s = 4 if self.vsr else 1
+            # the PyTorch custom op over pnp_generator_forward (pnp_vcve_amd/torch_ops.py)
+            out = torch.ops.pnpvcve.generator_forward(self._op_handle, lrs_c, mvs_c, par_c, side)
+        return out
+
+    def _forward_native(self, lrs_c, mvs_c, par_c, side):
+        """Body of torch.ops.pnpvcve.generator_forward: contiguous fp32 CUDA tensors + the (3, n, t) host side info."""
+        n, t, _, h, w = lrs_c.shape
+        s = 4 if self.vsr else 1
+        with torch.cuda.device(lrs_c.device):
             if self.use_graphs and not self._profiling:
                 return self._forward_graphed(lrs_c, mvs_c, par_c, side, (n, t, 3, h * s, w * s))
-            out = torch.empty((n, t, 3, h * s, w * s), device=dev, dtype=torch.float32)
-            ws = self._get_workspace(n, t, h, w, dev)
+            out = torch.empty((n, t, 3, h * s, w * s), device=lrs_c.device, dtype=torch.float32)
+            ws = self._get_workspace(n, t, h, w, lrs_c.device)
             self._launch(lrs_c, mvs_c, par_c, side, out, ws)
         return out
 

@@ -378,3 +378,20 @@ def test_par_tile_flags_vs_numpy():
             blk = par[:, ty * 8:ty * 8 + 8, tx * 16:tx * 16 + 16]
             exp[ty, tx] = sum(int((blk[j] != 0).any()) << j for j in range(3))
     assert np.array_equal(got, exp) and got[0, 0] == 1 and got[1, 1] == 2 and got[2, 0] == 6 and got[-1, -1] == 4
+
+
+def test_torch_custom_ops_call_the_hip_kernels():
+    """torch.ops.pnpvcve.flow_warp / mv_warp == the ctypes wrappers (same C-ABI calls underneath)."""
+    import pnp_vcve_amd  # noqa: F401
+    from pnp_vcve_amd import ops
+    case = gu.WARP_CASES[1]
+    x, flow = gu.warp_case_inputs(case)
+    a = torch.ops.pnpvcve.flow_warp(G(x), G(flow))
+    assert torch.equal(a, ops.flow_warp(G(x), G(flow)))
+    assert maxdiff(a, gu.load_golden(case['name'])['out']) < TOL_WARP
+    feat = G(gu.syn.uniform(41, 'f', (40, 56, 64), -1, 1))
+    fx = G(gu.syn.uniform(41, 'fx', (40, 56), -3, 3))
+    fy = G(gu.syn.uniform(41, 'fy', (40, 56), -3, 3))
+    assert torch.equal(torch.ops.pnpvcve.mv_warp(feat, fx, fy), ops.mv_warp_nhwc(feat, fx, fy))
+    with pytest.raises(RuntimeError):
+        torch.ops.pnpvcve.generator_forward(987654, feat, feat, feat, torch.zeros(3, 1, 1))

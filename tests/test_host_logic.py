@@ -248,3 +248,21 @@ def test_async_frame_writer_matches_tensor2img_and_surfaces_errors(tmp_path):
     w.submit(str(blocker / 'sub' / 'a.png'), q[0])                     # parent is a file: makedirs fails in the worker
     with pytest.raises(OSError):
         w.close()
+
+
+def test_torch_custom_ops_are_registered_with_fake_kernels():
+    """torch.ops.pnpvcve.*: schemas exist and the fake (meta) kernels propagate shapes without a GPU."""
+    import pnp_vcve_amd  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in ('flow_warp', 'mv_warp', 'psnr_sse', 'generator_forward'):
+        assert hasattr(torch.ops.pnpvcve, name), name
+    assert 'Tensor x, Tensor flow' in str(torch.ops.pnpvcve.flow_warp.default._schema)
+    with FakeTensorMode():
+        x = torch.empty(2, 8, 64, 96)
+        assert torch.ops.pnpvcve.flow_warp(x, torch.empty(2, 64, 96, 2)).shape == x.shape
+        f = torch.empty(64, 96, 64)
+        assert torch.ops.pnpvcve.mv_warp(f, torch.empty(64, 96), torch.empty(64, 96)).shape == f.shape
+        lrs = torch.empty(1, 3, 3, 64, 64)
+        out = torch.ops.pnpvcve.generator_forward(0, lrs, torch.empty(1, 3, 4, 64, 64), torch.empty(1, 3, 3, 64, 64),
+                                                  torch.empty(3, 1, 3))
+        assert out.shape == (1, 3, 3, 64, 64)
