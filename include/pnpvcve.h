@@ -5,7 +5,11 @@
  * /root/reference).  All pointers named *_dev are device (HBM) addresses owned by the
  * caller; the library allocates no device memory, launches asynchronously on the supplied
  * stream (a hipStream_t passed as void*) and returns 0 on success, a hipError_t value, or
- * one of the PNP_ERR_* codes.  fp32 throughout unless PNP_PREC_F16 is selected.  No global state: every call is re-entrant.
+ * one of the PNP_ERR_* codes.  fp32 throughout unless PNP_PREC_F16 is selected.
+ * State: all mutable state lives in the pnp_generator handle (precision, options, profiling events, side streams);
+ * a handle must not be used from two threads at once.  The only process-wide state is a per-DEVICE cache of one-time
+ * kernel attributes (dynamic-LDS opt-in, CU count), keyed by the current device and mutex-protected, so one process may
+ * drive several GPUs.  No environment variables are read.
  */
 #ifndef PNPVCVE_H
 #define PNPVCVE_H
@@ -21,7 +25,7 @@ extern "C" {
 #define PNP_ERR_SIZE_ASSERT 1004 /* reference: AssertionError, h/w < 64 (iconvsr_ipb_par.py:51) */
 #define PNP_ERR_SIZE_VALUE 1005  /* reference: ValueError from flow_warp.py:27-29 (h/w % 4 != 0) */
 
-int pnp_abi_version(void);
+int pnp_abi_version(void); /* 2: pnp_generator_cfg.sparse_val, pnp_generator_set_option, pnp_bae_block_* */
 
 /* ------------------------------------------------------------------ generator (a1/a2)
  * Constructor kwargs of IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par
@@ -35,6 +39,10 @@ typedef struct pnp_generator_cfg {
     int one_layer, channel_first, align_key, vsr;
     int deform; /* 0 'vos' (MV bilinear warp, iconvsr_mv.py:12-18); 1 'basic' (:52-84), 2 'fvc' (:21-41):
                    flow-guided modulated deformable conv, deform_groups 16 (mmcv semantics restated) */
+    int sparse_val; /* eval-time sparse evaluation of the 1x1 partition branches (basicvsr_net.py:456-476,511-514,
+                       sr_backbone_utils.py:262-302): branch j where plane j != 0, later planes overwrite, result / 255.
+                       Identical to the dense path for one-hot maps in {0, 1/255}; one clip at a time (n == 1): the
+                       reference indexes sample 0 only */
 } pnp_generator_cfg;
 
 typedef struct pnp_generator pnp_generator;
@@ -61,6 +69,17 @@ int64_t pnp_generator_packed_floats(const pnp_generator* g);
 #define PNP_PREC_F16 1
 int pnp_generator_set_precision(pnp_generator* g, int precision);
 int pnp_generator_get_precision(const pnp_generator* g);
+
+/* Per-generator execution switches (A/B and diagnostic; results are bit-identical either way unless stated).
+ * value 0/1; all default to 1.  State lives in the handle. */
+#define PNP_OPT_F16_MAPS 0       /* PNP_PREC_F16: the map between the two halves of a BAE block / behind conv_hr is stored fp16 */
+#define PNP_OPT_PAR_SKIP 1       /* skip 1x1 partition branches whose plane is all zero on a tile (exact zeros) */
+#define PNP_OPT_CONV_LAST_VALU 2 /* conv_last on the vector ALUs (<= 2e-6 from the MFMA kernel: other summation order) */
+#define PNP_OPT_PERSIST 3        /* persistent strip kernel for the 64->64 convs on frames with >= 1024 tiles */
+#define PNP_OPT_FUSED_BLOCK 4    /* one launch per BAE block where a fused kernel exists (sr_backbone_utils.py:304-333) */
+#define PNP_OPT_COUNT 5
+int pnp_generator_set_option(pnp_generator* g, int option, int value);
+int pnp_generator_get_option(const pnp_generator* g, int option);
 
 /* flat (reference layouts) -> packed (MFMA B images); replaces nothing in the reference,
  * it is the checkpoint-load-time half of mmcv load_checkpoint (iconvsr.py:510-523). */

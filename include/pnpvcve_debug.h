@@ -1,0 +1,37 @@
+/* libpnpvcve_hip.so -- diagnostic entry points (kernel-variant selection and in-kernel timelines).
+ *
+ * Declared separately from pnpvcve.h because nothing in the reference corresponds to them: they exist so that
+ * tests can compare two kernels of this build bit for bit and so that tools/trace_*.py can read shader-clock
+ * timelines.  Same conventions as pnpvcve.h (device pointers, void* stream, int return); no global state -- the
+ * variant and the trace buffer are arguments of the call.
+ */
+#ifndef PNPVCVE_DEBUG_H
+#define PNPVCVE_DEBUG_H
+#include "pnpvcve.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNP_CONV_AUTO 0     /* what pnp_conv3x3_f32 does: persistent strips from 1024 tiles, else tile per block */
+#define PNP_CONV_TILE 1     /* tile-per-block kernel, tile size picked from the frame size */
+#define PNP_CONV_TILE_BIG 2 /* tile-per-block kernel, 8x16 tiles */
+
+/* The fused conv of pnpvcve.h (sr_backbone_utils.py:304-333 halves, basicvsr_net.py:484, iconvsr.py:365) with an explicit kernel
+ * variant, optional per-tile partition flags (pnp_par_tile_flags_f32; NULL = no branch skipped) and an optional
+ * timeline buffer (8-16 u64 per block, device memory, NULL = none). */
+int pnp_conv3x3_f32_ex(int nsrc, const float* const* srcs_dev, const int* src_channels,
+                       const float* const* packed_w_dev, const float* bias_dev, const float* gamma_dev,
+                       const float* packed_w1x1_dev, const float* par_dev, const float* residual_dev,
+                       int act, float* out_dev, int h, int w, int variant, const int* par_flags_dev,
+                       void* trace_dev, void* stream);
+
+/* The fp16-operand conv of pnpvcve.h with an optional timeline buffer (16 u64 per 4-wave group). */
+int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs_dev, const int* src_channels,
+                       const void* const* packed_w_f16_dev, const float* bias_dev, const float* gamma_dev,
+                       const void* packed_w1x1_f16_dev, const float* par_dev, const float* residual_dev,
+                       int act, float* out_dev, int h, int w, void* trace_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

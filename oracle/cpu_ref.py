@@ -177,6 +177,25 @@ def dynamic_conv_se(x, ew, weight, bias, gamma, with_se):
 
 
 # --------------------------------------------------------------------------
+# a13  sparse evaluation of the 1x1 partition branches (sparse_val=True, eval only)
+# --------------------------------------------------------------------------
+def sparse_conv(sd, prefix, feature, par):
+    """common/sr_backbone_utils.py:294-302 (sparse_conv) with mask_roi / mask_roi_back (:262-275) and the index
+    lists of backbones/sr_backbones/basicvsr_net.py:456-476,511-514 (generate_indices(par[:, j], 1)).
+    par (1,3,1,h,w).  Branch j is evaluated at the pixels where plane j is NONZERO (its value is not used), the
+    three results are scattered in the order 16x16, 16x8, 8x8 (a later plane overwrites an earlier one) and the
+    map is divided by 255.  Only sample 0 is touched (`feature[0, ...]`): one clip at a time."""
+    assert feature.shape[0] == 1, 'sparse_val: the reference indexes sample 0 only'
+    dy = torch.zeros_like(feature)
+    for j, name in enumerate(('conv16x16', 'conv16x8', 'conv8x8')):
+        idx = torch.nonzero(par[:, j].squeeze())           # generate_indices, kernel_size == 1
+        h_idx, w_idx = idx[:, 0], idx[:, 1]
+        res = torch.mm(sd[prefix + name + '.weight'].view(64, -1), feature[0, :, h_idx, w_idx])
+        dy[0, :, h_idx, w_idx] = res
+    return dy / 255
+
+
+# --------------------------------------------------------------------------
 # K5/K6  one BAE block
 # --------------------------------------------------------------------------
 def bae_block(sd, cfg, prefix, x, par, ew, gamma):
@@ -186,6 +205,8 @@ def bae_block(sd, cfg, prefix, x, par, ew, gamma):
     one_layer = cfg.get('one_layer', False)
 
     def dyres(v):                                          # :310 / :324
+        if cfg.get('sparse_val', False):                   # eval-only sparse evaluation, :308-309 / :322-323
+            return sparse_conv(sd, prefix, v, par)
         return (F.conv2d(v, sd[prefix + 'conv16x16.weight']) * par[:, 0] +
                 F.conv2d(v, sd[prefix + 'conv16x8.weight']) * par[:, 1] +
                 F.conv2d(v, sd[prefix + 'conv8x8.weight']) * par[:, 2])

@@ -5,7 +5,8 @@ oracle/ref_shim.py) on seeded synthetic inputs/weights defined in
 tests/golden_util.py.  Only outputs are stored; inputs are regenerated from
 seeds on whichever machine runs the tests.
 
-    python oracle/gen_golden.py            # (re)write every fixture + manifest
+    python oracle/gen_golden.py                    # (re)write every fixture + manifest
+    python oracle/gen_golden.py --only a,b         # only the named generator cases, merged into the manifest
 """
 import json
 import os
@@ -32,12 +33,19 @@ def main():
     os.makedirs(gu.GOLDEN_DIR, exist_ok=True)
     manifest = dict(reference='ZeldaM1/PnP-VCVE @ /root/reference (imported on CPU via oracle/ref_shim.py)',
                     torch=torch.__version__, cases={})
+    only = None
+    if '--only' in sys.argv:
+        only = set(sys.argv[sys.argv.index('--only') + 1].split(','))
+        with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json')) as f:
+            manifest = json.load(f)
     Ref = ref_shim.reference_generator_class()
     sbu, da, bvn = ref_shim.reference_modules()
     ref_flow_warp = ref_shim.reference_flow_warp()
 
     # ---- full generator -------------------------------------------------
     for case in gu.GEN_CASES:
+        if only is not None and case['name'] not in only:
+            continue
         cfg, sd_np, clip = gu.gen_case_inputs(case)
         m = Ref(**cfg).eval()
         sd = cpu_ref.to_torch_state(sd_np)
@@ -66,6 +74,12 @@ def main():
                                                out_minus_lq_maxabs=float((ref - (a['lq'] if not cfg['vsr'] else 0)).abs().max()))
         print(case['name'], list(ref.shape), 'oracle-vs-ref', d, sens, flush=True)
         assert d < 1e-5
+
+    if only is not None:
+        with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json'), 'w') as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print('updated', sorted(only))
+        return
 
     # ---- flow_warp --------------------------------------------------------
     for case in gu.WARP_CASES:

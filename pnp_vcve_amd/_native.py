@@ -16,7 +16,7 @@ PNP_ERR = {1001: 'bad argument', 1002: 'unsupported configuration', 1003: 'works
 class GeneratorCfg(ctypes.Structure):
     _fields_ = [(k, c_int) for k in (
         'mid_channels', 'num_blocks', 'num_experts', 'with_cat', 'use_base_qp', 'expert_softmax', 'with_bias',
-        'with_se', 'one_layer', 'channel_first', 'align_key', 'vsr', 'deform')]
+        'with_se', 'one_layer', 'channel_first', 'align_key', 'vsr', 'deform', 'sparse_val')]
 
 
 # name -> (restype, argtypes); every symbol include/pnpvcve.h declares
@@ -38,6 +38,8 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_generator_set_precision': (c_int, [c_void_p, c_int]),
     'pnp_generator_get_precision': (c_int, [c_void_p]),
+    'pnp_generator_set_option': (c_int, [c_void_p, c_int, c_int]),
+    'pnp_generator_get_option': (c_int, [c_void_p, c_int]),
     'pnp_generator_profile': (c_int, [c_void_p, c_int]),
     'pnp_generator_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),
                                            POINTER(ctypes.c_double)]),
@@ -67,6 +69,19 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
 }
 
+# include/pnpvcve_debug.h: kernel-variant selection / timelines for tests and tools
+DEBUG_SIGNATURES = {
+    'pnp_conv3x3_f32_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                   c_void_p, c_void_p]),
+    'pnp_conv3x3_f16_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+}
+
+# pnp_generator_set_option ids (include/pnpvcve.h)
+OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_FUSED_BLOCK = range(5)
+CONV_AUTO, CONV_TILE, CONV_TILE_BIG = range(3)
+
 _lib = None
 
 
@@ -79,7 +94,7 @@ def lib():
                 f'{LIB_PATH} is missing: build it with `python -m pnp_vcve_amd.build_native` '
                 '(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.')
         L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(L, name)       # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args

@@ -558,12 +558,12 @@ __global__ __launch_bounds__(256) void f16_image_kernel(const float* __restrict_
 }
 
 int f16_grid(int grid_y) {
-    static std::once_flag once;
-    static int cus = 256;
-    std::call_once(once, [&] {
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    });
+    static PnpPerDevice once;
+    int cus = 256;
+    (void)once.run([](int dev, int& v) {
+        v = 256;
+        return hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    }, &cus);
     int g = cus / grid_y;
     g -= g % 8;
     return g < 8 ? 8 : g;
@@ -572,11 +572,10 @@ int f16_grid(int grid_y) {
 template <bool PAR, bool LR4, bool SRC16, bool OUT16, bool RGB = false>
 int launch_one(const F16Args& fa, int grid_y, hipStream_t stream) {
     auto kern = conv3x3_f16_kernel<PAR, LR4, SRC16, OUT16, RGB>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       LDS_BYTES);
+    static PnpPerDevice once;
+    const hipError_t attr_err = once.run([&](int, int&) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     hipLaunchKernelGGL(kern, dim3(f16_grid(grid_y), grid_y), dim3(512), LDS_BYTES, stream, fa);

@@ -440,11 +440,10 @@ template <int WM, int WN, int NT, int NTB>
 int launch_cfg(const ConvArgs& a, int grid_y, hipStream_t stream) {
     using C = ConvCfg<WM, WN, NT, NTB>;
     auto kern = conv3x3_mfma_kernel<WM, WN, NT, NTB>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    static PnpPerDevice once;
+    const hipError_t attr_err = once.run([&](int, int&) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   C::LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     const int tiles = ((a.W + C::TW - 1) / C::TW) * ((a.H + C::TH - 1) / C::TH);
@@ -457,7 +456,6 @@ int launch_cfg(const ConvArgs& a, int grid_y, hipStream_t stream) {
 int conv_pick_cfg(int H, int W) {
     // 8x16 tiles need >= 2 blocks per CU (512 tiles) to fill the chip; below that use 4x16 tiles.
     const long tiles_big = (long)((W + 15) / 16) * ((H + 7) / 8);
-    if (getenv("PNP_FORCE_BIG")) return CONV_CFG_BIG;
     return tiles_big >= 1024 ? CONV_CFG_BIG : CONV_CFG_SMALL;
 }
 

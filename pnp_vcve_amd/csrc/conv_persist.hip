@@ -421,32 +421,27 @@ int launch_par_tile_flags(const float* par, long par_plane, int* flags, int fram
     return (int)hipGetLastError();
 }
 
-static int g_persist_mode = -1;      // -1: from the environment (PNP_NO_PERSIST), 0 off, 1 on
-// Diagnostic switch (not part of include/pnpvcve.h): lets tests compare the two kernels bit for bit.
-extern "C" void pnp_debug_set_persist(int mode) { g_persist_mode = mode; }
-
 bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y) {
-    static const bool env_off = getenv("PNP_NO_PERSIST") != nullptr;
-    if (g_persist_mode == 0 || (g_persist_mode < 0 && env_off)) return false;
+    if (a.no_persist) return false;         // the caller asked for the tile-per-block kernel
     const long tiles = (long)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     return cfg == CONV_CFG_BIG && grid_y == 1 && a.nsrc == 1 && a.src_c[0] == 64 && a.out_mode == 0 && tiles >= 1024;
 }
 
 int launch_conv3x3_persist(const ConvArgs& a, hipStream_t stream) {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    static int grid = 512;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_persist_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_persist_kernel<true>),
+    static PnpPerDevice once;
+    int grid = 512;
+    const hipError_t attr_err = once.run([](int dev, int& g) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_persist_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        grid = 2 * cus;                 // two resident blocks per CU (LDS-limited)
-        grid -= grid % 8;
-    });
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_persist_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        g = 2 * cus;                    // two resident blocks per CU (LDS-limited)
+        g -= g % 8;
+        return e;
+    }, &grid);
     if (attr_err != hipSuccess) return (int)attr_err;
     if (a.wpar) hipLaunchKernelGGL(conv3x3_persist_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, stream, a);
     else hipLaunchKernelGGL(conv3x3_persist_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, stream, a);

@@ -126,11 +126,10 @@ __global__ __launch_bounds__(256, 2) void dcn_mfma_kernel(const DcnArgs a) {
 }  // namespace
 
 int launch_dcn(const DcnArgs& a, hipStream_t stream) {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_mfma_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static PnpPerDevice once;
+    const hipError_t attr_err = once.run([](int, int&) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_mfma_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     const int tiles = ((a.W + 15) / 16) * ((a.H + 7) / 8);

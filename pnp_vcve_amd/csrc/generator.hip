@@ -20,16 +20,13 @@
 #include <cstdlib>
 
 #include "../../include/pnpvcve.h"
+#include "../../include/pnpvcve_debug.h"
 #include "conv_mfma.h"
 #include "prep.h"
 #include "warp.h"
 #include "dcn.h"
 
 namespace {
-
-bool g_f16_storage = true;             // pnp_debug_set_f16_storage
-bool g_par_skip = true;                // pnp_debug_set_par_skip
-bool g_conv_last_valu = true;          // pnp_debug_set_conv_last_valu
 
 constexpr int64_t IMG_WIDE = 9 * 4096;   // floats: 9 chunks, 64 output channels
 constexpr int64_t IMG_CHUNK = 4096;      // 1 chunk, 64 output channels
@@ -69,6 +66,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1};   // pnp_generator_set_option (defaults: everything on)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -344,13 +342,21 @@ struct ConvCall {
 };
 
 struct Workspace {
-    float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om;
+    float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om, *parbin;
     float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 only
     int* parflags;    // per frame, per 8x16 tile: which partition planes are nonzero there (ConvArgs::par_flags)
     int64_t bytes;
 };
 
 int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// Largest per-LR-pixel byte extent any kernel of the clip addresses with 32-bit offsets: a 64-channel fp32 map is
+// 256 B/pixel (x16 pixels behind the x4 heads); the DCN aligners' offset/mask map is 448 channels = 1792 B/pixel.
+int64_t pnp_addr32_bytes_per_lr_pixel(int vsr, int deform) {
+    int64_t b = 256 * (vsr ? 16 : 1);
+    if (deform != 0 && b < 1792) b = 1792;
+    return b;
+}
 
 Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     Workspace W;
@@ -379,6 +385,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     } else {
         W.flow4 = W.om = nullptr;
     }
+    W.parbin = g->cfg.sparse_val ? take(hw * 3 * t) : nullptr;
     W.ew = take((int64_t)t * g->cfg.num_experts);
     W.gamma = take((int64_t)t * 64);
     W.mixw = take((int64_t)t * g->ndyn * IMG_WIDE);
@@ -393,7 +400,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
 
 extern "C" {
 
-int pnp_abi_version(void) { return 1; }
+int pnp_abi_version(void) { return 2; }
 
 int pnp_generator_create(const pnp_generator_cfg* cfg, pnp_generator** out) {
     if (!cfg || !out) return PNP_ERR_BAD_ARG;
@@ -434,6 +441,15 @@ int pnp_generator_set_precision(pnp_generator* g, int precision) {
     return PNP_OK;
 }
 int pnp_generator_get_precision(const pnp_generator* g) { return g ? g->prec : -1; }
+
+int pnp_generator_set_option(pnp_generator* g, int option, int value) {
+    if (!g || option < 0 || option >= PNP_OPT_COUNT) return PNP_ERR_BAD_ARG;
+    g->opt[option] = value != 0;
+    return PNP_OK;
+}
+int pnp_generator_get_option(const pnp_generator* g, int option) {
+    return (g && option >= 0 && option < PNP_OPT_COUNT) ? g->opt[option] : -1;
+}
 
 int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
@@ -573,7 +589,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.out = q.dst;
         a.lr = q.lr_;
         a.lr_plane = q.lr_plane_;
-        a.wvalu = g_conv_last_valu ? q.wvalu_ : nullptr;
+        a.wvalu = g->opt[PNP_OPT_CONV_LAST_VALU] ? q.wvalu_ : nullptr;
+        a.no_persist = g->opt[PNP_OPT_PERSIST] ? 0 : 1;
         a.w_ystride = q.w_ystride_;
         a.bias_ystride = q.bias_ystride_;
         a.H = q.H;
@@ -593,7 +610,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         ProfScope ps(g, st, kind, 2.0 * kreal * nreal * (double)q.H * q.W * q.gy_);
         return launch_conv3x3(a, q.cfg_, q.gy_, st);
     };
-    const bool f16_maps = g->prec == PNP_PREC_F16 && g_f16_storage;
+    const bool f16_maps = g->prec == PNP_PREC_F16 && g->opt[PNP_OPT_F16_MAPS];
+    const bool par_skip = g->opt[PNP_OPT_PAR_SKIP] != 0;
 
     // deform_align(feat, flow) -> W.kw  (iconvsr_ipb.py:19-24 dispatch; iconvsr_mv.py:12-84)
     auto align = [&](const float* feat, const float* fxp, const float* fyp) -> int {
@@ -635,8 +653,13 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         g->prof_last = nullptr;           // untimed launches follow
         rc = launch_pack_lr(lr_b, W.lr4, t, h, w, st);
         if (rc) return rc;
+        if (c.sparse_val) {               // the reference's sparse evaluation as a dense map (prep.hip)
+            rc = launch_par_sparse(par_b, W.parbin, t, h, w, st);
+            if (rc) return rc;
+            par_b = W.parbin;
+        }
         // which 1x1 partition branches each 8x16 tile of each frame needs at all (32 front-half launches per frame use it)
-        if (g_par_skip) {
+        if (par_skip) {
             rc = launch_par_tile_flags(par_b, hw, W.parflags, t, h, w, st);
             if (rc) return rc;
         }
@@ -719,7 +742,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const BranchPk& B = g->br[brid];
             const float* gam = (c.with_bias && c.with_se) ? W.gamma + (int64_t)i * 64 : nullptr;
             const float* parp = par_b + (int64_t)i * 3 * hw;
-            const int* pflags = g_par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
+            const int* pflags = par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
             int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0));
@@ -837,11 +860,13 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
                           int h, int w, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (n < 1 || t < 1) return PNP_ERR_BAD_ARG;
+    if (g->cfg.sparse_val && n != 1) return PNP_ERR_UNSUPPORTED;   // sparse_conv reads feature[0] only (sr_backbone_utils.py:262-275)
     if (h < 64 || w < 64) return PNP_ERR_SIZE_ASSERT;
     if ((h % 4) || (w % 4)) return PNP_ERR_SIZE_VALUE;
     // the kernels address a feature map with 32-bit byte offsets: the largest one (x16 pixels with the x4 heads) must
     // stay below 4 GiB (2160p, or 720p -> 2880p with vsr, still fit)
-    if ((int64_t)h * w * 256 * (g->cfg.vsr ? 16 : 1) >= (int64_t)1 << 32) return PNP_ERR_UNSUPPORTED;
+    if (pnp_addr32_bytes_per_lr_pixel(g->cfg.vsr, g->cfg.deform) * (int64_t)h * w >= (int64_t)1 << 32)
+        return PNP_ERR_UNSUPPORTED;
     const int64_t ctx_bytes = carve(g, nullptr, t, h, w).bytes;
     if (workspace_bytes < ctx_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255)) return PNP_ERR_WORKSPACE;
     const int64_t hw = (int64_t)h * w;
@@ -1003,26 +1028,19 @@ int pnp_pack_conv1x1_f32(const float* w, float* dst, void* st) {
     return launch_pack_weights(plain_pack(w, 64, 1, PACK_1X1, 0, 2, 64, dst), 1, (hipStream_t)st);
 }
 
-// Diagnostic only (not part of include/pnpvcve.h): 0 keeps the BAE-block intermediate in fp32 on the fp16 path (tests
-// compare the two bit for bit).
-void pnp_debug_set_f16_storage(int on) { g_f16_storage = on != 0; }
-
-// Diagnostic only (not part of include/pnpvcve.h): 0 makes every tile run all three 1x1 partition branches (tests compare
-// the two bit for bit).
-void pnp_debug_set_par_skip(int on) { g_par_skip = on != 0; }
-
-// Diagnostic only (not part of include/pnpvcve.h): 0 sends conv_last back to the MFMA kernel (tests compare the two).
-void pnp_debug_set_conv_last_valu(int on) { g_conv_last_valu = on != 0; }
-
-// Diagnostic only (not part of include/pnpvcve.h): per-block shader-clock timeline of the next
-// pnp_conv3x3_f32 launches, 8 u64 per block.  Used by tools/trace_conv.py.
-static unsigned long long* g_conv_dbg = nullptr;
-void pnp_debug_set_conv_trace(void* buf) { g_conv_dbg = (unsigned long long*)buf; }
-
 int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w,
                     const float* bias, const float* gamma, const float* packed_w1x1, const float* par,
                     const float* residual, int act, float* out, int h, int w, void* st) {
+    return pnp_conv3x3_f32_ex(nsrc, srcs, src_channels, packed_w, bias, gamma, packed_w1x1, par, residual, act, out, h, w,
+                              PNP_CONV_AUTO, nullptr, nullptr, st);
+}
+
+int pnp_conv3x3_f32_ex(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w,
+                       const float* bias, const float* gamma, const float* packed_w1x1, const float* par,
+                       const float* residual, int act, float* out, int h, int w, int variant, const int* par_flags,
+                       void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4) return PNP_ERR_BAD_ARG;
+    if (variant != PNP_CONV_AUTO && variant != PNP_CONV_TILE && variant != PNP_CONV_TILE_BIG) return PNP_ERR_BAD_ARG;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nsrc = nsrc;
@@ -1042,8 +1060,10 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels,
     a.W = w;
     a.act = act;
     a.out_mode = 0;
-    a.dbg = g_conv_dbg;
-    return launch_conv3x3(a, conv_pick_cfg(h, w), 1, (hipStream_t)st);
+    a.par_flags = par_flags;
+    a.dbg = (unsigned long long*)trace;
+    a.no_persist = variant != PNP_CONV_AUTO;
+    return launch_conv3x3(a, variant == PNP_CONV_TILE_BIG ? CONV_CFG_BIG : conv_pick_cfg(h, w), 1, (hipStream_t)st);
 }
 
 int pnp_par_tile_flags_f32(const float* par, int* flags, int h, int w, void* st) {
@@ -1059,6 +1079,13 @@ int pnp_f16_image_from_f32(const float* packed_w, void* dst, int nchunks, void* 
 int pnp_conv3x3_f16(int nsrc, const float* const* srcs, const int* src_channels, const void* const* packed_w_f16,
                     const float* bias, const float* gamma, const void* packed_w1x1_f16, const float* par,
                     const float* residual, int act, float* out, int h, int w, void* st) {
+    return pnp_conv3x3_f16_ex(nsrc, srcs, src_channels, packed_w_f16, bias, gamma, packed_w1x1_f16, par, residual, act, out,
+                              h, w, nullptr, st);
+}
+
+int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs, const int* src_channels, const void* const* packed_w_f16,
+                       const float* bias, const float* gamma, const void* packed_w1x1_f16, const float* par,
+                       const float* residual, int act, float* out, int h, int w, void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4) return PNP_ERR_BAD_ARG;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1080,7 +1107,7 @@ int pnp_conv3x3_f16(int nsrc, const float* const* srcs, const int* src_channels,
     a.W = w;
     a.act = act;
     a.out_mode = 0;
-    a.dbg = g_conv_dbg;
+    a.dbg = (unsigned long long*)trace;
     if (a.wpar_h && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
     if (!conv_f16_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_f16(a, 1, (hipStream_t)st);

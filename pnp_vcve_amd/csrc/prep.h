@@ -4,6 +4,8 @@
 
 // (T,3,H,W) NCHW frames -> (T,H,W,4) pixel-major, 4th channel zero
 int launch_pack_lr(const float* lrs, float* lr4, int T, int H, int W, hipStream_t stream);
+// (T,3,H,W) partition maps -> the dense equivalent of the reference's sparse_val evaluation (prep.hip)
+int launch_par_sparse(const float* par, float* out, int T, int H, int W, hipStream_t stream);
 // DCN conv_offset output channel order used by this build (dcn.hip): packed channel c' ->
 // reference channel of conv_offset[2] (offsets (g*9+k)*2+{dy,dx} for c' < 288, masks 288+g*9+k), -1 = padding
 static inline __host__ __device__ int pnp_dcn_ref_channel_impl(int c) {

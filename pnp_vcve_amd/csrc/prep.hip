@@ -21,6 +21,24 @@ __global__ __launch_bounds__(256) void pack_lr_kernel(const float* __restrict__ 
     reinterpret_cast<f32x4*>(lr4)[i] = v;
 }
 
+// sparse_val (eval): basicvsr_net.py:511-514 generate_indices(par_j) + sr_backbone_utils.py:294-302 sparse_conv:
+// the 1x1 branch j is evaluated where plane j is NONZERO (whatever its value), later planes overwrite earlier ones
+// (mask_roi_back assigns), and the result is divided by 255.  As a dense map: plane j = 1/255 where par_j != 0 and no
+// later plane is nonzero, else 0.
+__global__ __launch_bounds__(256) void par_sparse_kernel(const float* __restrict__ par, float* __restrict__ out, long hw,
+                                                         long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long t = i / hw, p = i - t * hw;
+    const float* s = par + t * 3 * hw + p;
+    float* d = out + t * 3 * hw + p;
+    const bool n0 = s[0] != 0.f, n1 = s[hw] != 0.f, n2 = s[2 * hw] != 0.f;
+    const float v = 1.0f / 255.0f;
+    d[0] = (n0 && !n1 && !n2) ? v : 0.f;
+    d[hw] = (n1 && !n2) ? v : 0.f;
+    d[2 * hw] = n2 ? v : 0.f;
+}
+
 __global__ __launch_bounds__(256) void pack_flow4_kernel(const float* __restrict__ fx, const float* __restrict__ fy,
                                                          float* __restrict__ out4, long hw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,6 +162,13 @@ __global__ __launch_bounds__(64) void caa_predict_kernel(const CaaArgs a) {
 int launch_pack_lr(const float* lrs, float* lr4, int T, int H, int W, hipStream_t stream) {
     const long hw = (long)H * W, total = hw * T;
     hipLaunchKernelGGL(pack_lr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, lrs, lr4, hw,
+                       total);
+    return (int)hipGetLastError();
+}
+
+int launch_par_sparse(const float* par, float* out, int T, int H, int W, hipStream_t stream) {
+    const long hw = (long)H * W, total = hw * T;
+    hipLaunchKernelGGL(par_sparse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, par, out, hw,
                        total);
     return (int)hipGetLastError();
 }

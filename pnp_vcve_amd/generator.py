@@ -52,12 +52,13 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         self.flow_inter = flow_inter
         self.with_cat, self.use_base_qp, self.with_bias = with_cat, use_base_qp, with_bias
         self.with_par, self.vsr, self.align_key = with_par, vsr, align_key
+        self.sparse_val = bool(sparse_val)
         self.is_mirror_extended = False
         self._cfg = _native.GeneratorCfg(
             mid_channels=mid_channels, num_blocks=num_blocks, num_experts=num_experts, with_cat=int(with_cat),
             use_base_qp=int(use_base_qp), expert_softmax=int(expert_softmax), with_bias=int(with_bias),
             with_se=int(with_se), one_layer=int(one_layer), channel_first=int(channel_first),
-            align_key=int(align_key), vsr=int(vsr), deform=_DEFORM[deform])
+            align_key=int(align_key), vsr=int(vsr), deform=_DEFORM[deform], sparse_val=int(bool(sparse_val)))
         self._handle = ctypes.c_void_p()
         L = _native.lib()
         _native.check(L.pnp_generator_create(ctypes.byref(self._cfg), ctypes.byref(self._handle)),
@@ -98,6 +99,15 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         self._pack_key = None
         self._workspace = {}
         self._graphs = {}
+
+    def set_option(self, option, value):
+        """pnp_generator_set_option: A/B switches of the native scheduler (_native.OPT_*); per-generator state."""
+        _native.check(_native.lib().pnp_generator_set_option(self._handle, int(option), int(bool(value))),
+                      'pnp_generator_set_option')
+        self._graphs = {}
+
+    def get_option(self, option):
+        return int(_native.lib().pnp_generator_get_option(self._handle, int(option)))
 
     # ---------------------------------------------------------------- parameters
     def _register(self, dotted, param):
@@ -140,6 +150,25 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             load_checkpoint(self, pretrained, strict=strict)
         elif pretrained is not None:
             raise TypeError(f'"pretrained" must be a str or None. But received {type(pretrained)}.')
+
+    def invalidate_packed(self):
+        """Drop the native weight images (flat / packed / fp16 mirrors); the next forward() re-packs them.
+        The cache is keyed on each parameter's (data_ptr, _version), which in-place writes through `param.data`
+        (EMA helpers, weight surgery, some optimizers) do NOT change -- call this after such writes.
+        load_state_dict(), .to()/.cuda()/.half() and friends call it themselves."""
+        self._flat = self._packed = None
+        self._pack_key = None
+        self._graphs = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
 
     def _ensure_packed(self, device):
         params = dict(self.named_parameters())
@@ -194,9 +223,22 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             if mvs_c.shape != (n, t, 4, h, w) or par_c.shape != (n, t, 3, h, w):
                 raise ValueError(f'The spatial sizes of input ({(h, w)}) and flow/partition maps '
                                  f'({tuple(mvs_c.shape)}, {tuple(par_c.shape)}) are not the same.')
-            # the three (n,t,1,1,1) side-info tensors drive host control flow (key frames, expert dedup)
-            side = torch.stack([slices.reshape(n, t).float(), QPs.reshape(n, t).float(),
-                                base_QPs.reshape(n, t).float()]).cpu().contiguous()
+            if self.sparse_val and n != 1:
+                raise NotImplementedError('sparse_val=True evaluates one clip at a time: the reference reads feature[0] '
+                                          'only (sr_backbone_utils.py:262-275)')
+            # a side tensor the configuration does not read may be None, as in the reference (QPs is always read when
+            # with_bias; base_QPs only when use_base_qp, iconvsr_ipb_par.py:45-48)
+            zero = torch.zeros(n, t, device=slices.device) if slices is not None else None
+            if slices is None:
+                raise TypeError('slices (n,t,1,1,1) is required: it selects the key frames (iconvsr_ipb_par.py:60-62)')
+            if QPs is None and (self.with_bias or not self.use_base_qp):
+                raise TypeError('QPs is required by this configuration (iconvsr_ipb_par.py:45-48)')
+            if base_QPs is None and self.use_base_qp:
+                raise TypeError('base_QPs is required when use_base_qp=True (iconvsr_ipb_par.py:45)')
+            # the three (n,t,1,1,1) side-info tensors drive host control flow (key frames, expert dedup): ONE D2H copy
+            side = torch.stack([slices.reshape(n, t).float(),
+                                QPs.reshape(n, t).float() if QPs is not None else zero,
+                                base_QPs.reshape(n, t).float() if base_QPs is not None else zero]).cpu().contiguous()
             # the PyTorch custom op over pnp_generator_forward (pnp_vcve_amd/torch_ops.py)
             out = torch.ops.pnpvcve.generator_forward(self._op_handle, lrs_c, mvs_c, par_c, side)
         return out

@@ -19,6 +19,23 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _on_device_of_first_tensor(fn):
+    """Run the wrapper with the first tensor argument's device current: the launch goes to torch's current stream of
+    THAT device (a process may hold tensors on several GPUs), like generator.forward does."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        first = next((a for a in args if isinstance(a, torch.Tensor)), None)
+        if first is None:
+            first = next((a[0] for a in args if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor)), None)
+        if first is not None and first.is_cuda:
+            with torch.cuda.device(first.device):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapped
+
+
 def _chk(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f'{name} must be a CUDA/HIP tensor: the PnP-VCVE hot path has no CPU fallback')
@@ -27,6 +44,7 @@ def _chk(t, name):
     return t.contiguous()
 
 
+@_on_device_of_first_tensor
 def flow_warp(x, flow, interpolation='bilinear', padding_mode='zeros', align_corners=True):
     """Drop-in for mmedit.models.common.flow_warp (flow_warp.py:6-50).
     x (n,c,h,w), flow (n,h,w,2) in pixels."""
@@ -43,6 +61,7 @@ def flow_warp(x, flow, interpolation='bilinear', padding_mode='zeros', align_cor
     return out
 
 
+@_on_device_of_first_tensor
 def mv_warp_nhwc(feat, flow_x, flow_y):
     """feat (h,w,c) pixel-major; flow_x/flow_y (h,w)."""
     feat, flow_x, flow_y = _chk(feat, 'feat'), _chk(flow_x, 'flow_x'), _chk(flow_y, 'flow_y')
@@ -53,6 +72,7 @@ def mv_warp_nhwc(feat, flow_x, flow_y):
     return out
 
 
+@_on_device_of_first_tensor
 def nchw_to_nhwc(x):
     x = _chk(x, 'x')
     n, c, h, w = x.shape
@@ -61,6 +81,7 @@ def nchw_to_nhwc(x):
     return out
 
 
+@_on_device_of_first_tensor
 def nhwc_to_nchw(x):
     x = _chk(x, 'x')
     n, h, w, c = x.shape
@@ -69,6 +90,7 @@ def nhwc_to_nchw(x):
     return out
 
 
+@_on_device_of_first_tensor
 def caa_predict(q_ew, q_gamma, w1, b1, w2, b2, v1=None, v2=None, softmax=True):
     """Base_Predictor + SEModule (domain_aware.py:172-183, 210-222).
     q_ew/q_gamma: python sequences of floats (host).  Returns (ew (count,E), gamma (count,64))."""
@@ -87,6 +109,7 @@ def caa_predict(q_ew, q_gamma, w1, b1, w2, b2, v1=None, v2=None, softmax=True):
     return ew, gamma
 
 
+@_on_device_of_first_tensor
 def pack_conv3x3(weight, cbase=0, csrc=64, ew=None):
     """OIHW (cout,cin,3,3) [or (E,cout,cin,3,3) with ew (E,)] -> packed image for input
     channels [cbase, cbase+csrc)."""
@@ -103,6 +126,7 @@ def pack_conv3x3(weight, cbase=0, csrc=64, ew=None):
     return dst
 
 
+@_on_device_of_first_tensor
 def pack_conv1x1(weights):
     """three (64,64,1,1) weights -> one tensor of 3 chunks (conv16x16, conv16x8, conv8x8)."""
     L = _native.lib()
@@ -115,6 +139,7 @@ def pack_conv1x1(weights):
     return dst
 
 
+@_on_device_of_first_tensor
 def par_tile_flags(par):
     """(3,h,w) partition planes -> int32 (tiles_y, tiles_x) of 8x16 tiles: bit j set iff plane j is nonzero in the tile."""
     par = _chk(par, 'par')
@@ -127,6 +152,7 @@ def par_tile_flags(par):
     return out
 
 
+@_on_device_of_first_tensor
 def f16_image(packed):
     """fp32 packed weight image (whole chunks) -> fp16 image for conv3x3(..., fp16=True)."""
     packed = _chk(packed, 'packed')
@@ -139,11 +165,14 @@ def f16_image(packed):
     return dst
 
 
-def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, residual=None, act=0, fp16=False):
+@_on_device_of_first_tensor
+def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, residual=None, act=0, fp16=False,
+            variant=None, par_flags=None, trace=None):
     """Fused conv over pixel-major sources [(h,w,64) or (h,w,4)].  See include/pnpvcve.h.
-    fp16=True: packed_w / packed_w1x1 are f16_image() tensors and the MFMA operands are fp16."""
+    fp16=True: packed_w / packed_w1x1 are f16_image() tensors and the MFMA operands are fp16.
+    variant / par_flags / trace: include/pnpvcve_debug.h (kernel selection, per-tile branch flags, timeline buffer)."""
     if fp16:
-        return _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act)
+        return _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act, trace)
     srcs = [_chk(s, 'src') for s in srcs]
     h, w = srcs[0].shape[:2]
     n = len(srcs)
@@ -152,13 +181,19 @@ def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, r
     sc = (ctypes.c_int * n)(*[s.shape[2] for s in srcs])
     wp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in packed_w])
     keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, packed_w1x1, par, residual)]
-    _native.check(_native.lib().pnp_conv3x3_f32(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]),
-                                                _ptr(keep[3]), _ptr(keep[4]), act, _ptr(out), h, w, _stream()),
-                  'pnp_conv3x3_f32')
+    if variant is None and par_flags is None and trace is None:
+        _native.check(_native.lib().pnp_conv3x3_f32(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]),
+                                                    _ptr(keep[3]), _ptr(keep[4]), act, _ptr(out), h, w, _stream()),
+                      'pnp_conv3x3_f32')
+    else:
+        _native.check(_native.lib().pnp_conv3x3_f32_ex(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]),
+                                                       _ptr(keep[3]), _ptr(keep[4]), act, _ptr(out), h, w,
+                                                       int(variant or 0), _ptr(par_flags), _ptr(trace), _stream()),
+                      'pnp_conv3x3_f32_ex')
     return out
 
 
-def _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act):
+def _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act, trace=None):
     srcs = [_chk(s, 'src') for s in srcs]
     for p in list(packed_w) + ([packed_w1x1] if packed_w1x1 is not None else []):
         if not p.is_cuda or p.dtype != torch.float16 or not p.is_contiguous():
@@ -171,11 +206,13 @@ def _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act):
     wp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in packed_w])
     keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, par, residual)]
     w1 = ctypes.c_void_p(packed_w1x1.data_ptr()) if packed_w1x1 is not None else None
-    _native.check(_native.lib().pnp_conv3x3_f16(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), w1, _ptr(keep[2]),
-                                                _ptr(keep[3]), act, _ptr(out), h, w, _stream()), 'pnp_conv3x3_f16')
+    _native.check(_native.lib().pnp_conv3x3_f16_ex(n, sp, sc, wp, _ptr(keep[0]), _ptr(keep[1]), w1, _ptr(keep[2]),
+                                                   _ptr(keep[3]), act, _ptr(out), h, w, _ptr(trace), _stream()),
+                  'pnp_conv3x3_f16')
     return out
 
 
+@_on_device_of_first_tensor
 def frames_to_rgb8(frames):
     """(n,3,h,w) fp32 CUDA frames -> (n,h,w,3) uint8 RGB CUDA tensor with tensor2img's arithmetic."""
     frames = _chk(frames, 'frames')
@@ -188,6 +225,7 @@ def frames_to_rgb8(frames):
     return out
 
 
+@_on_device_of_first_tensor
 def psnr_frames(a, b, crop_border=0):
     """Per-frame PSNR with the reference's definition (uint8-rounded frames), computed on the GPU.
     a, b: (..., c, h, w) with any leading dims; returns a float64 CPU tensor of the leading shape."""
@@ -206,6 +244,7 @@ def psnr_frames(a, b, crop_border=0):
     return out.reshape(a.shape[:-3])
 
 
+@_on_device_of_first_tensor
 def rasterise_side_info(records, rec_frame, slices, h, w):
     """Decoder MV records -> (mvs (T,4,h,w), partitions (T,3,h,w)) on the GPU
     (LoadImageFromFileList_ipb.__call__, loading_ipb.py:328-369, + RescaleToZeroOne + FramesToTensor).
@@ -226,6 +265,7 @@ def rasterise_side_info(records, rec_frame, slices, h, w):
     return mvs, par
 
 
+@_on_device_of_first_tensor
 def modulated_deform_conv_nhwc(x, offset, mask_logits, weight, bias, flow=None):
     """mmcv.ops.modulated_deform_conv2d(x, offset, sigmoid(mask_logits), weight, bias, 1, 1, 1, 1, 16) for the
     hot path's shapes.  x (h,w,64) pixel-major; offset (288,h,w) and mask_logits (144,h,w) in mmcv's channel
@@ -247,6 +287,7 @@ def modulated_deform_conv_nhwc(x, offset, mask_logits, weight, bias, flow=None):
     return out
 
 
+@_on_device_of_first_tensor
 def ssim_frames(a, b, crop_border=0):
     """Per-frame SSIM with the reference's definition (metrics.py:266-355), computed on the GPU in fp64.
     a, b: (..., c, h, w); returns a float64 CPU tensor of the leading shape."""

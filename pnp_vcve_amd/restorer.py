@@ -86,6 +86,10 @@ class BasicVSR(nn.Module):
         crop_border = self.test_cfg['crop_border']
         convert_to = self.test_cfg.get('convert_to', None)
         eval_result = dict()
+        if output.ndim == 5 and output.size(0) != 1:
+            # the reference evaluates with samples_per_gpu=1 (configs/*: test_dataloader); with n > 1 its tensor2img
+            # would compare make_grid mosaics of the batch.  Refuse loudly instead of scoring sample 0 only.
+            raise ValueError(f'evaluate() expects one clip per call (samples_per_gpu=1), got a batch of {output.size(0)}')
         for metric in self.test_cfg['metrics']:
             if metric == 'PSNR' and convert_to is None and output.is_cuda and output.ndim == 5:
                 # on-device statistic (pnp_psnr_sse_f32): 8 bytes per frame cross PCIe instead of the frames

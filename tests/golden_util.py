@@ -52,7 +52,24 @@ GEN_CASES = [
                   num_blocks=3),
          wseed=24, par_gain=10.0,
          clip=dict(seed=115, n=1, t=3, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    # sparse_val=True (eval-time sparse evaluation of the 1x1 branches): maps with NON-binary values and overlapping
+    # planes, so that "nonzero -> 1/255, later plane wins" is visible (a one-hot/255 map would equal the dense path)
+    dict(name='gen_sparse_val_64x64', cfg=dict(sparse_val=True), wseed=25, par_gain=10.0, par_kind='overlap',
+         clip=dict(seed=116, n=1, t=3, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_sparse_val_channel_last_64x72', cfg=dict(sparse_val=True, channel_first=False), wseed=26,
+         par_gain=10.0, par_kind='overlap',
+         clip=dict(seed=117, n=1, t=3, h=64, w=72, slices='allP', qp_mode='qp', crf=35)),
 ]
+
+
+def overlap_par(seed, shape):
+    """partition planes for the sparse_val cases: per 4x4 block each plane is zero with probability 1/2, otherwise a
+    float in (0, 1] -- planes overlap and are not binary."""
+    n, t, c, h, w = shape
+    on = syn.randint(seed, 'par_on', (n, t, c, h // 4, w // 4), 0, 1).astype(np.float32)
+    val = syn.uniform(seed, 'par_val', (n, t, c, h // 4, w // 4), 0.05, 1.0)
+    blk = on * val
+    return np.ascontiguousarray(np.repeat(np.repeat(blk, 4, axis=3), 4, axis=4))
 
 
 def gen_case_inputs(case):
@@ -61,6 +78,8 @@ def gen_case_inputs(case):
     cfg.update(case['cfg'])
     sd = syn.make_state_dict(cfg, seed=case['wseed'], par_gain=case.get('par_gain', 1.0))
     clip = syn.make_clip(**case['clip'])
+    if case.get('par_kind') == 'overlap':
+        clip['partitions'] = overlap_par(case['clip']['seed'], clip['partitions'].shape)
     if case.get('mirror'):
         # mirror-extended sequence: frame i == frame t-1-i (iconvsr.py:396-410)
         t = clip['lq'].shape[1]

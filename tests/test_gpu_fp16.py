@@ -143,13 +143,15 @@ def test_f16_operands_saturate_instead_of_overflowing():
 
 
 # ---------------------------------------------------------------- whole path
-def _run(case, fp16):
+def _run(case, fp16, options=()):
     import pnp_vcve_amd as P
     cfg, sd_np, clip = gu.gen_case_inputs(case)
     m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
     m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
     m = m.to(dev()).eval()
     m.fp16_enabled = fp16
+    for opt, val in options:                      # pnp_generator_set_option (per-generator state)
+        m.set_option(opt, val)
     a = {k: G(v) for k, v in clip.items()}
     with torch.no_grad():
         out = m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
@@ -200,18 +202,10 @@ def test_f16_precision_switch_resizes_buffers_and_round_trips():
 def test_f16_intermediate_maps_are_bit_identical_to_fp32_storage():
     """The BAE-block intermediate is only ever an MFMA A operand: writing it rounded (fp16 map) instead of rounding it
     in its reader must not change a single bit of the clip."""
-    import ctypes
     from pnp_vcve_amd import _native
-    L = _native.lib()
-    L.pnp_debug_set_f16_storage.argtypes = [ctypes.c_int]
-    L.pnp_debug_set_f16_storage.restype = None
     for name in ('gen_parfloat_72x88', 'gen_channel_last_64x64', 'gen_two_layer_64x64'):
         case = [c for c in gu.GEN_CASES if c['name'] == name][0]
-        try:
-            L.pnp_debug_set_f16_storage(0)
-            a, _ = _run(case, True)
-        finally:
-            L.pnp_debug_set_f16_storage(1)
+        a, _ = _run(case, True, options=[(_native.OPT_F16_MAPS, 0)])
         b, _ = _run(case, True)
         assert torch.equal(a, b), name
 

@@ -334,11 +334,7 @@ def test_forward_workspace_errors_through_the_raw_abi():
 def test_partition_branch_skipping_is_bit_identical(par_kind, hw):
     """Both conv kernels skip a 1x1 partition branch on tiles where its plane is zero (per-tile flags,
     pnp_par_tile_flags_f32): exact zeros dropped, so the clip must not change by a single bit."""
-    import ctypes
     from pnp_vcve_amd import _native
-    L = _native.lib()
-    L.pnp_debug_set_par_skip.argtypes = [ctypes.c_int]
-    L.pnp_debug_set_par_skip.restype = None
     cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
     sd_np = gu.syn.make_state_dict(cfg, seed=95, par_gain=10.0)
     clip = gu.syn.make_clip(seed=96, n=1, t=3, h=hw[0], w=hw[1], slices='IBBBP', block=8,
@@ -351,11 +347,9 @@ def test_partition_branch_skipping_is_bit_identical(par_kind, hw):
         planes = (clip['partitions'][0, 1:] != 0).sum(1)             # P/B frames: at most one plane per pixel
         assert planes.max() == 1 and planes.mean() > 0.5 and float(np.abs(clip['partitions'][0, 0]).max()) == 0.0
     m = build(cfg, sd_np)
-    try:
-        L.pnp_debug_set_par_skip(0)
-        ref = run(m, clip).clone()
-    finally:
-        L.pnp_debug_set_par_skip(1)
+    m.set_option(_native.OPT_PAR_SKIP, 0)
+    ref = run(m, clip).clone()
+    m.set_option(_native.OPT_PAR_SKIP, 1)
     out = run(m, clip)
     assert torch.equal(out, ref)
     if par_kind == 'one_hot_blocks':          # and the branch is live: zeroing the map changes the result
@@ -367,20 +361,14 @@ def test_partition_branch_skipping_is_bit_identical(par_kind, hw):
 def test_conv_last_on_the_vector_alus_matches_the_mfma_kernel(vsr):
     """conv_last (64 -> 3) runs on the VALUs with scalar weights (conv_last.hip); against the MFMA kernel it replaces
     (same fp32 products, different summation order) on a ragged frame, both output modes."""
-    import ctypes
     from pnp_vcve_amd import _native
-    L = _native.lib()
-    L.pnp_debug_set_conv_last_valu.argtypes = [ctypes.c_int]
-    L.pnp_debug_set_conv_last_valu.restype = None
     cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=1, vsr=vsr)
     sd_np = gu.syn.make_state_dict(cfg, seed=101, par_gain=10.0)
     clip = gu.syn.make_clip(seed=102, n=1, t=2, h=68, w=100, slices='IBBBP', block=4)
     m = build(cfg, sd_np)
-    try:
-        L.pnp_debug_set_conv_last_valu(0)
-        ref = run(m, clip).clone()
-    finally:
-        L.pnp_debug_set_conv_last_valu(1)
+    m.set_option(_native.OPT_CONV_LAST_VALU, 0)
+    ref = run(m, clip).clone()
+    m.set_option(_native.OPT_CONV_LAST_VALU, 1)
     out = run(m, clip)
     d = float((out - ref).abs().max())
     assert out.shape == ref.shape and 0.0 < d < 2e-6, d

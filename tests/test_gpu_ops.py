@@ -30,7 +30,7 @@ def maxdiff(a, b):
 
 def test_native_library_is_loaded():
     from pnp_vcve_amd import _native
-    assert _native.lib().pnp_abi_version() == 1
+    assert _native.lib().pnp_abi_version() == 2
 
 
 @pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])
@@ -306,11 +306,7 @@ def test_modulated_deform_conv_vs_oracle(with_flow):
 def test_persistent_conv_is_bit_identical_to_the_tile_per_block_kernel(hw):
     """frames with >= 1024 tiles run the persistent kernel (conv_persist.hip): same arithmetic in the same
     order as conv_mfma.hip, so plain / residual (in place) / gamma+par variants must match bit for bit."""
-    import ctypes
     from pnp_vcve_amd import _native, ops
-    L = _native.lib()
-    L.pnp_debug_set_persist.argtypes = [ctypes.c_int]
-    L.pnp_debug_set_persist.restype = None
     h, w = hw
     x = torch.randn(h, w, 64, device=dev())
     r = torch.randn(h, w, 64, device=dev())
@@ -322,15 +318,10 @@ def test_persistent_conv_is_bit_identical_to_the_tile_per_block_kernel(hw):
     par = torch.rand(3, h, w, device=dev())
     variants = [dict(bias=bias, act=2), dict(bias=bias, residual=r, act=0),
                 dict(bias=bias, gamma=gamma, packed_w1x1=p1, par=par, act=1)]
-    try:
-        for kw in variants:
-            L.pnp_debug_set_persist(0)
-            a = ops.conv3x3([x], [pw], **kw)
-            L.pnp_debug_set_persist(1)
-            b = ops.conv3x3([x], [pw], **kw)
-            assert torch.equal(a, b), sorted(kw)
-    finally:
-        L.pnp_debug_set_persist(-1)
+    for kw in variants:
+        a = ops.conv3x3([x], [pw], variant=_native.CONV_TILE, **kw)        # include/pnpvcve_debug.h
+        b = ops.conv3x3([x], [pw], variant=_native.CONV_AUTO, **kw)
+        assert torch.equal(a, b), sorted(kw)
     ref = F.leaky_relu(F.conv2d(x[:64, :96].permute(2, 0, 1).unsqueeze(0).cpu(), wt.cpu(), bias.cpu(), padding=1), 0.1)
     got = ops.conv3x3([x], [pw], bias=bias, act=2)[:63, :95].permute(2, 0, 1).unsqueeze(0)
     assert maxdiff(got, ref[..., :63, :95]) < TOL_CONV * 4

@@ -19,14 +19,31 @@ def lib():
     return _native.lib()
 
 
+def _declared(header):
+    hdr = open(os.path.join(ROOT, 'include', header)).read()
+    return set(re.findall(r'\b(pnp_[a-z0-9_]+)\s*\(', hdr))
+
+
 def test_every_declared_symbol_is_exported(lib):
-    hdr = open(os.path.join(ROOT, 'include', 'pnpvcve.h')).read()
-    declared = set(re.findall(r'\b(pnp_[a-z0-9_]+)\s*\(', hdr))
+    declared = _declared('pnpvcve.h')
     assert declared, 'no declarations found'
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
-    for name in declared:
+    debug = _declared('pnpvcve_debug.h')
+    assert debug == set(_native.DEBUG_SIGNATURES), debug ^ set(_native.DEBUG_SIGNATURES)
+    for name in declared | debug:
         assert hasattr(lib, name), name
-    assert lib.pnp_abi_version() == 1
+    assert lib.pnp_abi_version() == 2
+
+
+def test_no_undeclared_pnp_symbol_is_exported(lib):
+    """Everything the .so exports under the pnp_ prefix is declared in include/*.h (no hidden global switches)."""
+    import subprocess
+    nm = '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.check_output([nm if os.path.exists(nm) else 'nm', '-D', '--defined-only', _native.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('pnp_')}
+    declared = _declared('pnpvcve.h') | _declared('pnpvcve_debug.h')
+    assert exported, 'no pnp_* exports found'
+    assert exported <= declared, sorted(exported - declared)
 
 
 def test_schema_equals_reference_state_dict():
@@ -93,6 +110,10 @@ def test_c_abi_error_codes_without_a_gpu(lib):
     assert lib.pnp_generator_set_precision(h, 1) == 0 and lib.pnp_generator_get_precision(h) == 1
     assert lib.pnp_generator_packed_floats(h) == n32 + n32 // 2          # fp16 mirror of every image
     assert lib.pnp_generator_workspace_bytes(h, 7, 128, 128) > ctx       # + mirror of the mixed experts
+    for opt in range(5):                                                 # per-handle switches, default on
+        assert lib.pnp_generator_get_option(h, opt) == 1
+    assert lib.pnp_generator_set_option(h, 3, 0) == 0 and lib.pnp_generator_get_option(h, 3) == 0
+    assert lib.pnp_generator_set_option(h, 5, 0) == 1001 and lib.pnp_generator_get_option(h, 5) == -1
     assert n32 % 4096 == 0 and ctx % 256 == 0
     lib.pnp_generator_destroy(h)
 
@@ -103,12 +124,16 @@ def test_forward_refuses_maps_beyond_32_bit_offsets_before_touching_memory(lib):
     import ctypes
     kw = dict(mid_channels=64, num_blocks=1, num_experts=2, with_cat=1, use_base_qp=1, expert_softmax=1, with_bias=1,
               with_se=1, one_layer=1, channel_first=1, align_key=1, vsr=0, deform=0)
-    for vsr, hw, rc_exp in ((0, (4096, 4096), 1002), (1, (1024, 1024), 1002), (0, (60, 64), 1004), (0, (66, 64), 1005)):
+    # deform != 0: the 448-channel offset/mask map (1792 B/pixel) is the widest one -> 1440p is already too large
+    for vsr, hw, rc_exp, deform in ((0, (4096, 4096), 1002, 0), (1, (1024, 1024), 1002, 0), (0, (60, 64), 1004, 0),
+                                    (0, (66, 64), 1005, 0), (0, (1440, 2560), 1002, 1), (0, (1440, 2560), 1002, 2),
+                                    (0, (1440, 2560), 1003, 0), (0, (1080, 1920), 1003, 1), (1, (720, 1280), 1003, 0)):
         kw['vsr'] = vsr
+        kw['deform'] = deform
         h = ctypes.c_void_p()
         assert lib.pnp_generator_create(ctypes.byref(_native.GeneratorCfg(**kw)), ctypes.byref(h)) == 0
         side = (ctypes.c_float * 1)(73.0)
         rc = lib.pnp_generator_forward(h, None, None, None, None, None, side, side, side, None, None, 0, 1, 1, hw[0], hw[1],
                                        None)
-        assert rc == rc_exp, (vsr, hw, rc)
+        assert rc == rc_exp, (vsr, hw, deform, rc)      # 1003: passed the guard, stopped at the (null) workspace
         lib.pnp_generator_destroy(h)

@@ -1,6 +1,5 @@
 #!/usr/bin/env python
 """Diagnostic: per-block timeline of one conv launch (shader-clock stamps written by the kernel)."""
-import ctypes
 import os
 import sys
 from collections import defaultdict
@@ -15,7 +14,6 @@ from pnp_vcve_amd import _native, ops  # noqa: E402
 def main():
     h = int(sys.argv[1]) if len(sys.argv) > 1 else 720
     w = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
-    force_big = True
     dev = torch.device('cuda:0')
     x = torch.randn(h, w, 64, device=dev)
     x2 = torch.randn(h, w, 64, device=dev)
@@ -23,16 +21,12 @@ def main():
     pw = ops.pack_conv3x3(wt)
     bias = torch.randn(64, device=dev) * 0.1
     ntiles = ((w + 15) // 16) * ((h + 7) // 8)
-    L = _native.lib()
-    L.pnp_debug_set_conv_trace.argtypes = [ctypes.c_void_p]
-    L.pnp_debug_set_conv_trace.restype = None
     for _ in range(3):
-        ops.conv3x3([x], [pw], bias=bias, residual=x2)
+        ops.conv3x3([x], [pw], bias=bias, residual=x2, variant=_native.CONV_TILE_BIG)
     dbg = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
-    L.pnp_debug_set_conv_trace(ctypes.c_void_p(dbg.data_ptr()))
-    ops.conv3x3([x], [pw], bias=bias, residual=x2)
+    # include/pnpvcve_debug.h: the tile-per-block kernel with 8x16 tiles and a timeline buffer
+    ops.conv3x3([x], [pw], bias=bias, residual=x2, variant=_native.CONV_TILE_BIG, trace=dbg)
     torch.cuda.synchronize()
-    L.pnp_debug_set_conv_trace(ctypes.c_void_p(0))
     d = dbg.cpu().numpy().reshape(ntiles, 16).astype(np.int64)
     t0, t1, t2, t3 = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
     hw, xcc, rt = d[:, 4], d[:, 5], d[:, 6]

@@ -1,6 +1,5 @@
 #!/usr/bin/env python
 """Diagnostic: per-block phase sums of the fp16-operand persistent conv kernel (shader-clock stamps)."""
-import ctypes
 import os
 import sys
 
@@ -19,26 +18,21 @@ pw = ops.f16_image(ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev) * 0.05
 p1 = ops.f16_image(ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev) * 0.1 for _ in range(3)]))
 par = (torch.rand(3, h, w, device=dev) > 0.66).float() / 255.0
 bias = torch.randn(64, device=dev) * 0.1
-L = _native.lib()
-L.pnp_debug_set_conv_trace.argtypes = [ctypes.c_void_p]
-L.pnp_debug_set_conv_trace.restype = None
 
 
-def run():
+def run(trace=None):
     if mode == 'res':
-        return ops.conv3x3([x], [pw], bias=bias, residual=x2, fp16=True)
+        return ops.conv3x3([x], [pw], bias=bias, residual=x2, fp16=True, trace=trace)
     if mode == 'par':
-        return ops.conv3x3([x], [pw], bias=bias, packed_w1x1=p1, par=par, act=1, fp16=True)
-    return ops.conv3x3([x], [pw], bias=bias, act=2, fp16=True)
+        return ops.conv3x3([x], [pw], bias=bias, packed_w1x1=p1, par=par, act=1, fp16=True, trace=trace)
+    return ops.conv3x3([x], [pw], bias=bias, act=2, fp16=True, trace=trace)
 
 
 for _ in range(3):
     run()
 dbg = torch.zeros(512 * 16, dtype=torch.int64, device=dev)
-L.pnp_debug_set_conv_trace(ctypes.c_void_p(dbg.data_ptr()))
-run()
+run(dbg)       # include/pnpvcve_debug.h
 torch.cuda.synchronize()
-L.pnp_debug_set_conv_trace(ctypes.c_void_p(0))
 d = dbg.cpu().numpy().reshape(512, 16)      # one row per 4-wave group (2 per block)
 d = d[d[:, 7] > 0]
 n = d[:, 7]

@@ -1,6 +1,5 @@
 #!/usr/bin/env python
 """Diagnostic: per-block phase sums of the persistent conv kernel (shader-clock stamps)."""
-import ctypes
 import os
 import sys
 
@@ -16,16 +15,11 @@ x = torch.randn(h, w, 64, device=dev)
 x2 = torch.randn(h, w, 64, device=dev)
 pw = ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev) * 0.05)
 bias = torch.randn(64, device=dev) * 0.1
-L = _native.lib()
-L.pnp_debug_set_conv_trace.argtypes = [ctypes.c_void_p]
-L.pnp_debug_set_conv_trace.restype = None
 for _ in range(3):
     ops.conv3x3([x], [pw], bias=bias, residual=x2)
 dbg = torch.zeros(512 * 16, dtype=torch.int64, device=dev)
-L.pnp_debug_set_conv_trace(ctypes.c_void_p(dbg.data_ptr()))
-ops.conv3x3([x], [pw], bias=bias, residual=x2)
+ops.conv3x3([x], [pw], bias=bias, residual=x2, trace=dbg)      # include/pnpvcve_debug.h
 torch.cuda.synchronize()
-L.pnp_debug_set_conv_trace(ctypes.c_void_p(0))
 d = dbg.cpu().numpy().reshape(512, 16)
 n = d[:, 7]
 tot = d[:, 3] - d[:, 0]
