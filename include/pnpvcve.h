@@ -79,6 +79,8 @@ int pnp_generator_get_precision(const pnp_generator* g);
 #define PNP_OPT_FUSED_BLOCK 4    /* one launch per BAE block where a fused kernel exists (sr_backbone_utils.py:304-333) */
 #define PNP_OPT_COUNT 5
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
+/* 1 when a BAE block of an h x w frame runs as ONE fused launch under the current precision / options, else 0 */
+int pnp_generator_uses_fused_block(const pnp_generator* g, int h, int w);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 
 /* flat (reference layouts) -> packed (MFMA B images); replaces nothing in the reference,

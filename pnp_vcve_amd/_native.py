@@ -40,6 +40,7 @@ SIGNATURES = {
     'pnp_generator_get_precision': (c_int, [c_void_p]),
     'pnp_generator_set_option': (c_int, [c_void_p, c_int, c_int]),
     'pnp_generator_get_option': (c_int, [c_void_p, c_int]),
+    'pnp_generator_uses_fused_block': (c_int, [c_void_p, c_int, c_int]),
     'pnp_generator_profile': (c_int, [c_void_p, c_int]),
     'pnp_generator_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),
                                            POINTER(ctypes.c_double)]),

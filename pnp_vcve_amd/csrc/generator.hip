@@ -241,6 +241,14 @@ __global__ void small_copy_kernel(const float* __restrict__ src, float* __restri
     }
 }
 
+// One launch per BAE block (PNP_OPT_FUSED_BLOCK): which (precision, layout, frame size) combinations have a fused kernel.
+bool fused_block_eligible(const pnp_generator* g, int h, int w) {
+    (void)h;
+    (void)w;
+    if (!g->opt[PNP_OPT_FUSED_BLOCK]) return false;
+    return false;      // no fused kernel yet
+}
+
 PackArgs plain_pack(const float* w, int cin_total, int ktaps, int kind, int cbase, int ntb, int n_valid, float* dst) {
     PackArgs a;
     memset(&a, 0, sizeof(a));
@@ -446,6 +454,9 @@ int pnp_generator_set_option(pnp_generator* g, int option, int value) {
     if (!g || option < 0 || option >= PNP_OPT_COUNT) return PNP_ERR_BAD_ARG;
     g->opt[option] = value != 0;
     return PNP_OK;
+}
+int pnp_generator_uses_fused_block(const pnp_generator* g, int h, int w) {
+    return (g && fused_block_eligible(g, h, w)) ? 1 : 0;
 }
 int pnp_generator_get_option(const pnp_generator* g, int option) {
     return (g && option >= 0 && option < PNP_OPT_COUNT) ? g->opt[option] : -1;

@@ -106,6 +106,10 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
                       'pnp_generator_set_option')
         self._graphs = {}
 
+    def fused_block_active(self, h, w):
+        """True when a BAE block of an h x w frame runs as one fused launch (pnp_generator_uses_fused_block)."""
+        return bool(_native.lib().pnp_generator_uses_fused_block(self._handle, int(h), int(w)))
+
     def get_option(self, option):
         return int(_native.lib().pnp_generator_get_option(self._handle, int(option)))
 

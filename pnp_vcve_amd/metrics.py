@@ -3,7 +3,14 @@
 tensor2img: mmedit/core/misc.py:9-74 ; psnr: mmedit/core/evaluation/metrics.py:170-215 ;
 ssim: metrics.py:218-355 (11x11 Gaussian sigma 1.5, 'valid' window).  The reference computes
 SSIM with cv2.filter2D; cv2 is not available here, the same window is applied with a separable
-'valid' correlation in float64 (SSIM parity is therefore unpinned -- SURVEY.md section 8c).
+'valid' correlation in float64 (SSIM parity is unpinned against cv2 itself -- SURVEY.md section 8c --
+but checked against an independent scipy.ndimage restatement of the reference formula,
+tests/test_host_logic.py::test_ssim_against_independent_scipy_restatement).
+
+Reference quirk kept: with crop_border != 0 the reference slices `img[cb:-cb, cb:-cb, None]`
+(metrics.py:343-345), which turns an HWC image into (H', W', 1, 3); its channel loop then runs once
+over `img[..., 0]`, i.e. SSIM is computed on channel 0 (B of the BGR image) only.  PSNR is a mean over
+all elements and is unaffected.  The shipped configs use crop_border=0.
 """
 import numpy as np
 import torch
@@ -74,11 +81,11 @@ def ssim(img1, img2, crop_border=0, input_order='HWC', convert_to=None):
         raise NotImplementedError('convert_to is not used by the shipped configs')
     if input_order == 'CHW':
         img1, img2 = img1.transpose(1, 2, 0), img2.transpose(1, 2, 0)
-    if crop_border != 0:
-        img1 = img1[crop_border:-crop_border, crop_border:-crop_border]
-        img2 = img2[crop_border:-crop_border, crop_border:-crop_border]
     if img1.ndim == 2:
         img1, img2 = img1[..., None], img2[..., None]
+    if crop_border != 0:       # metrics.py:343-350: the `None` index leaves only channel 0 in the loop (see module docstring)
+        img1 = img1[crop_border:-crop_border, crop_border:-crop_border, :1]
+        img2 = img2[crop_border:-crop_border, crop_border:-crop_border, :1]
     return float(np.mean([_ssim_channel(img1[..., i], img2[..., i]) for i in range(img1.shape[2])]))
 
 

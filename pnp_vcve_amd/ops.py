@@ -304,5 +304,9 @@ def ssim_frames(a, b, crop_border=0):
     _native.check(L.pnp_ssim_partials_f32(_ptr(a), _ptr(b), _ptr(part), frames, c, h, w, int(crop_border), _stream()),
                   'pnp_ssim_partials_f32')
     n = (h - 2 * crop_border - 10) * (w - 2 * crop_border - 10)
-    per_plane = part.sum(dim=1) / n
-    return per_plane.reshape(frames, c).mean(dim=1).cpu().reshape(a.shape[:-3])
+    per_plane = (part.sum(dim=1) / n).reshape(frames, c)
+    if crop_border != 0 and c == 3:
+        # reference quirk (metrics.py:343-350, see pnp_vcve_amd/metrics.py): with a crop only channel 0 of the BGR image,
+        # i.e. the B plane of these RGB frames, enters the SSIM mean
+        per_plane = per_plane[:, 2:3]
+    return per_plane.mean(dim=1).cpu().reshape(a.shape[:-3])

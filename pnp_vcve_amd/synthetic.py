@@ -198,13 +198,15 @@ def slice_pattern(name_or_list, t):
 
 
 def make_clip(seed, n=1, t=7, h=128, w=128, slices='IBBBP', qp_mode='qp', crf=25,
-              par_scale=1.0 / 255.0, mv_range=32, block=8):
+              par_scale=1.0 / 255.0, mv_range=32, block=8, par_classes=4):
     """One synthetic batch of clips with the SURVEY.md section 8(d) distributions.
 
     slices: pattern name / list (same for all samples) or list of n of them.
     qp_mode: 'qp' -> per-frame QP in 20..40 /255 ; 'ipb' -> ord(slice)/255.
     crf: int or list of n ints (base_QPs = crf/255, constant over T).
     par_scale: value of the active one-hot partition plane (reference: 1/255).
+    par_classes: 3 = SURVEY 8(d)'s U{0,1,2} (every block of a P/B frame carries a partition record; bench.py);
+                 4 = a quarter of the blocks carry none (all-zero) -- the golden fixtures were drawn with this.
     """
     assert h % block == 0 and w % block == 0
     bh, bw = h // block, w // block
@@ -213,7 +215,7 @@ def make_clip(seed, n=1, t=7, h=128, w=128, slices='IBBBP', qp_mode='qp', crf=25
     gt = np.clip(lq + noise, 0.0, 1.0).astype(np.float32)
 
     mv_blk = randint(seed, 'mv', (n, t, 4, bh, bw), -mv_range, mv_range).astype(np.float32) / 4.0
-    cls = randint(seed, 'par', (n, t, bh, bw), 0, 3)       # 3 -> no record (all-zero)
+    cls = randint(seed, 'par', (n, t, bh, bw), 0, par_classes - 1)       # 3 -> no record (all-zero)
     par_blk = np.zeros((n, t, 3, bh, bw), np.float32)
     for j in range(3):
         par_blk[:, :, j] = (cls == j).astype(np.float32) * np.float32(par_scale)

@@ -372,3 +372,81 @@ def test_conv_last_on_the_vector_alus_matches_the_mfma_kernel(vsr):
     out = run(m, clip)
     d = float((out - ref).abs().max())
     assert out.shape == ref.shape and 0.0 < d < 2e-6, d
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] sizes (HR_davis_LR_128x128_IPB_LR_test.py: 180x320 frames, +x4 heads, mixed crf15/25/35)
+# and the headline size directly against the oracle
+# ------------------------------------------------------------------------------------------------------------
+def _oracle(cfg, sd_np, clip):
+    t = {k: torch.from_numpy(v) for k, v in clip.items()}
+    with torch.no_grad():
+        return cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, t['lq'], t['QPs'], t['slices'], t['mvs'],
+                                         t['base_QPs'], t['partitions'])
+
+
+def test_lr180_clip_fp32_vs_oracle():
+    """configs[4] as the config ships (vsr=False): a 180x320 clip (T = 3) enhanced at 180x320, whole generator vs the
+    pinned oracle.  180 = 22.5 tiles of 8 rows: ragged bottom tiles on the small-tile kernel."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=401, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=4010, n=1, t=3, h=180, w=320, slices='IBBBP', qp_mode='ipb', crf=25, block=4)
+    out = run(build(cfg, sd_np), clip).cpu()
+    ref = _oracle(cfg, sd_np, clip)
+    d = float((out - ref).abs().max())
+    print('180x320 T=3 fp32 max|hip - oracle| =', d)
+    assert out.shape == (1, 3, 3, 180, 320) and d < TOL
+
+
+def test_lr180_x4_heads_fp32_vs_oracle():
+    """configs[4] as BASELINE.json describes it (vsr=True): LR 180x320 -> 720x1280 through the two PixelShufflePack
+    heads (iconvsr_ipb_par.py:135-142), T = 2, vs the oracle."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, vsr=True)
+    sd_np = gu.syn.make_state_dict(cfg, seed=402, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=4020, n=1, t=2, h=180, w=320, slices='IBBBP', qp_mode='ipb', crf=35, block=4)
+    out = run(build(cfg, sd_np), clip).cpu()
+    ref = _oracle(cfg, sd_np, clip)
+    d = float((out - ref).abs().max())
+    print('180x320 -> 720x1280 T=2 fp32 max|hip - oracle| =', d)
+    assert out.shape == (1, 2, 3, 720, 1280) and d < TOL
+
+
+@pytest.mark.parametrize('vsr', [False, True], ids=['enhance', 'x4'])
+def test_lr180_mixed_crf_batch_fp16_vs_fp32(vsr):
+    """configs[4]: n = 3 clips of crf 15/25/35 (three different expert mixtures in one batch) with the fp16 MFMA convs
+    against the fp32 path of the same build: PSNR delta < 1e-3 dB per clip (north_star's PSNR gate), max-abs 2e-2."""
+    from pnp_vcve_amd.ops import psnr_frames
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, vsr=vsr)
+    sd_np = gu.syn.make_state_dict(cfg, seed=403)
+    clip = gu.syn.make_clip(seed=4030, n=3, t=3, h=180, w=320, slices='IBBBP', qp_mode='ipb', crf=[15, 25, 35], block=4)
+    m = build(cfg, sd_np)
+    o32 = run(m, clip)
+    m.fp16_enabled = True
+    o16 = run(m, clip)
+    gt = torch.from_numpy(clip['gt']).to(dev())
+    if vsr:
+        gt = gt.repeat_interleave(4, -1).repeat_interleave(4, -2).contiguous()
+    p32, p16 = psnr_frames(o32, gt).mean(dim=1), psnr_frames(o16, gt).mean(dim=1)
+    print('fp16 vs fp32 per-clip PSNR', p32.tolist(), p16.tolist(), 'max-abs', float((o16 - o32).abs().max()))
+    assert o16.shape == o32.shape and torch.isfinite(o16).all()
+    assert float((p16 - p32).abs().max()) < 1e-3
+    assert 0.0 < float((o16 - o32).abs().max()) < 2e-2
+    # the three clips really ran three different mixtures: crf only enters through base_QPs
+    same = dict(clip, base_QPs=np.full_like(clip['base_QPs'], 25 / 255.0))
+    m.fp16_enabled = False
+    assert float((run(m, same)[0] - o32[0]).abs().max()) > 1e-6
+
+
+def test_720p_clip_directly_vs_oracle():
+    """The headline path itself (persistent strip kernel, 8x16 tiles, 720p) against the pinned oracle on a whole 2-frame
+    clip -- not through a crop (about 40 s of CPU)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=404, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=4040, n=1, t=2, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, par_classes=3)
+    out = run(build(cfg, sd_np), clip).cpu()
+    ref = _oracle(cfg, sd_np, clip)
+    d = float((out - ref).abs().max())
+    print('720p T=2 max|hip - oracle| =', d)
+    assert d < TOL
+    gt = torch.from_numpy(clip['gt'])
+    assert abs(cpu_ref.clip_psnr(out, gt) - cpu_ref.clip_psnr(ref, gt)) < 1e-3

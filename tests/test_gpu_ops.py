@@ -341,6 +341,21 @@ def test_ssim_on_device_matches_host_definition(crop):
     assert abs(float(got[2]) - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize('crop', [0, 3])
+def test_ssim_on_device_matches_independent_scipy_restatement(crop):
+    """the fp64 SSIM kernel against the scipy.ndimage restatement of the reference's cv2 formula
+    (tests/test_host_logic.py::_ssim_scipy), which shares no code with pnp_vcve_amd.metrics"""
+    from pnp_vcve_amd import ops
+    from pnp_vcve_amd.metrics import tensor2img
+    from test_host_logic import _ssim_scipy
+    a = torch.from_numpy(gu.syn.uniform01(61, 'a', (2, 3, 52, 83)))
+    b = (a + 0.06 * torch.from_numpy(gu.syn.normal(61, 'n', (2, 3, 52, 83)))).clamp(0, 1)
+    got = ops.ssim_frames(a.to(dev()), b.to(dev()), crop)
+    for i in range(2):
+        ref = _ssim_scipy(tensor2img(a[i]), tensor2img(b[i]), crop)
+        assert abs(float(got[i]) - ref) < 1e-10, (i, float(got[i]), ref)
+
+
 def test_frames_to_rgb8_matches_tensor2img():
     """write-back conversion on the device == the reference's tensor2img (core/misc.py:51-71), incl. ties and clamping"""
     from pnp_vcve_amd import ops

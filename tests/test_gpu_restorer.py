@@ -138,3 +138,44 @@ def test_bench_emits_the_contract_line():
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
     assert d['parity']['max_abs_diff_vs_cpu'] < d['parity']['gate']
     assert 'workload' in d['config'] and 'model' not in d['config']
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` (the driver's plain form, no torch.distributed environment) starts two ranks itself
+    (tools/dist_test.sh:11-22's job), gathers per-rank metrics and prints ONE line with n_gpus == 2.  Both ranks share
+    cuda:0 here and the tiny collectives go over gloo (RCCL needs one GPU per rank)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['PNP_DIST_BACKEND'] = 'gloo'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', '128', '--frames', '3',
+                          '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'clip-sharded replicas x2'
+    assert len(d['frames_per_s_per_rank']) == 2 and len(d['psnr_per_rank']) == 2
+    assert d['psnr_per_rank'][0] != d['psnr_per_rank'][1]            # rank r ran clip r of the synthetic set
+    assert 'roofline' in d and 'cpu_baseline' not in d              # the CPU baseline is an N = 1 leg
+    # whole-job rate = all ranks' frames over the slowest rank's time
+    assert abs(d['value'] - 2 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+
+
+def test_bench_headline_line_carries_the_secondary_workloads():
+    """the default (720p fp32) line also measures the other BASELINE workloads in `secondary` and the dense-partition
+    figure next to the roofline (kept short: 1 step, no CPU baseline)."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['metric'].startswith('enhanced frames/sec (1280x720') and d['dtype'] == 'f32'
+    r = d['roofline']
+    assert 0 < r['frac_dense_par'] <= r['frac'] * 1.02 and 0 < r['executed_frac'] <= r['frac']
+    assert 'U{0,1,2}' in d['config']['workload']
+    sec = d['secondary']
+    assert len(sec) == 4
+    for e in sec:
+        assert e['value'] > 0 and e['roofline']['frac'] > 0 and e['launches_per_frame'] > 0
+    assert sec[0]['roofline']['bound'] == 'mfma' and sec[2]['roofline']['bound'] == 'hbm'
+    assert sec[3]['vsr_x4_heads'] is True

@@ -266,3 +266,64 @@ def test_torch_custom_ops_are_registered_with_fake_kernels():
         out = torch.ops.pnpvcve.generator_forward(0, lrs, torch.empty(1, 3, 4, 64, 64), torch.empty(1, 3, 3, 64, 64),
                                                   torch.empty(3, 1, 3))
         assert out.shape == (1, 3, 3, 64, 64)
+
+
+def test_bench_gpus_n_spawns_ranks_and_propagates_their_failure():
+    """`python bench.py --gpus 2` with no torch.distributed environment launches the ranks as child processes before
+    touching the GPU.  Without a GPU the ranks cannot run: the launcher must come back non-zero (the children's status)
+    instead of silently measuring one rank."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only check (the GPU variant lives in tests/test_gpu_restorer.py)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['PNP_DIST_BACKEND'] = 'gloo'
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', '128', '--steps', '1',
+                          '--warmup', '0'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert 'torch.distributed' in out.stderr or 'ChildFailedError' in out.stderr or 'rank' in out.stderr.lower()
+
+
+def _ssim_scipy(img1, img2, crop_border=0):
+    """The reference formula (mmedit/core/evaluation/metrics.py:266-355) restated with scipy.ndimage, independently of
+    pnp_vcve_amd.metrics: cv2.filter2D(img, -1, window) is a correlation with BORDER_REFLECT_101 (= scipy 'mirror'),
+    cropped [5:-5, 5:-5]; cv2.getGaussianKernel(11, 1.5) = normalised exp(-(i-5)^2 / (2 * 1.5^2))."""
+    from scipy import ndimage
+    k = np.exp(-((np.arange(11) - 5) ** 2) / (2 * 1.5 ** 2))
+    k /= k.sum()
+    window = np.outer(k, k)
+    if crop_border != 0:                    # :343-345 -- (H', W', 1, 3): the loop below then sees channel 0 only
+        img1 = img1[crop_border:-crop_border, crop_border:-crop_border, None]
+        img2 = img2[crop_border:-crop_border, crop_border:-crop_border, None]
+    vals = []
+    for i in range(img1.shape[2]):
+        a = img1[..., i].astype(np.float64)
+        b = img2[..., i].astype(np.float64)
+        if a.ndim == 3:                     # (H', W', 1) after the crop: cv2 filters it as a 1-channel image
+            a, b = a[..., 0], b[..., 0]
+        f = lambda x: ndimage.correlate(x, window, mode='mirror')[5:-5, 5:-5]       # noqa: E731
+        C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        mu1, mu2 = f(a), f(b)
+        s1, s2, s12 = f(a ** 2) - mu1 ** 2, f(b ** 2) - mu2 ** 2, f(a * b) - mu1 * mu2
+        m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
+        vals.append(m.mean())
+    return float(np.array(vals).mean())
+
+
+@pytest.mark.parametrize('crop', [0, 3])
+def test_ssim_against_independent_scipy_restatement(crop):
+    """pnp_vcve_amd.metrics.ssim (the host definition the GPU kernel is tested against) vs a scipy.ndimage
+    restatement of the reference's cv2 formula that shares no code with it."""
+    from pnp_vcve_amd.metrics import ssim, tensor2img
+    rng = np.random.RandomState(5)
+    for hw in ((40, 48), (33, 61)):
+        a = torch.from_numpy(rng.rand(1, 3, *hw).astype(np.float32))
+        b = (a + 0.05 * torch.from_numpy(rng.randn(1, 3, *hw).astype(np.float32))).clamp(0, 1)
+        ia, ib = tensor2img(a), tensor2img(b)
+        ref = _ssim_scipy(ia, ib, crop)
+        assert abs(ssim(ia, ib, crop) - ref) < 1e-12, (hw, crop)
+    if crop:                                  # the quirk is visible: all-channel SSIM differs
+        assert abs(_ssim_scipy(ia[crop:-crop, crop:-crop], ib[crop:-crop, crop:-crop], 0) - ref) > 1e-6
