@@ -160,6 +160,23 @@ int pnp_conv3x3_f32(int nsrc, const float* const* srcs_dev, const int* src_chann
                     const float* packed_w1x1_dev, const float* par_dev, const float* residual_dev,
                     int act, float* out_dev, int h, int w, void* stream);
 
+/* One BAE block, ResidualBlockNoBNDynamic_drt.forward in the shipped layout (channel_first, one_layer;
+ * sr_backbone_utils.py:305-313,329):  out = x + conv1(relu(gamma * (conv2_mix(x) + b2) + sum_j par_j * conv1x1_j(x))) + b1.
+ * w2_packed: the expert-mixed dynamic conv (pnp_pack_conv3x3_f32 with num_experts > 1 = Dynamic_conv2d_se's
+ * mm(attention, weight), :198-199); w1_packed: the static conv1; w1x1_packed / par may both be NULL.
+ * scratch_dev: h*w*64 floats for the intermediate; out_dev may alias x_dev. */
+int pnp_bae_block_f32(const float* x_dev, const float* w2_packed_dev, const float* b2_dev, const float* gamma_dev,
+                      const float* w1x1_packed_dev, const float* par_dev, const float* w1_packed_dev,
+                      const float* b1_dev, float* scratch_dev, float* out_dev, int h, int w, void* stream);
+
+/* PixelShufflePack (mmedit/models/common/upsample.py:8-51): conv3x3 64 -> 256 followed by F.pixel_shuffle(2).
+ * w (256,64,3,3), b (256) -> packed image (pnp_packed_pixel_shuffle_floats floats); x (h,w,64) -> out (2h,2w,64),
+ * act as in pnp_conv3x3_f32 (the x4 head applies leaky-relu, iconvsr_ipb_par.py:136-137). */
+int64_t pnp_packed_pixel_shuffle_floats(void);
+int pnp_pack_pixel_shuffle_f32(const float* w_dev, const float* b_dev, float* dst_dev, void* stream);
+int pnp_pixel_shuffle_conv_f32(const float* x_dev, const float* packed_dev, int act, float* out_dev, int h, int w,
+                               void* stream);
+
 /* Which of the three 1x1 partition branches (sr_backbone_utils.py:310-311, Sum_j par_j * conv1x1_j(x)) an 8x16 pixel tile
  * needs at all: par_dev (3,h,w) -> flags_dev[((w+15)/16) * ((h+7)/8)] ints, bit j set iff plane j is nonzero somewhere in
  * the tile.  pnp_generator_forward computes these once per frame; its persistent conv kernel skips a branch on tiles

@@ -64,6 +64,10 @@ SIGNATURES = {
     'pnp_ssim_partials_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_conv3x3_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'pnp_bae_block_f32': (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
+    'pnp_packed_pixel_shuffle_floats': (c_int64, []),
+    'pnp_pack_pixel_shuffle_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'pnp_pixel_shuffle_conv_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'pnp_par_tile_flags_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     'pnp_f16_image_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'pnp_conv3x3_f16': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,

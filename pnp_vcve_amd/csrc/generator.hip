@@ -1077,6 +1077,61 @@ int pnp_conv3x3_f32_ex(int nsrc, const float* const* srcs, const int* src_channe
     return launch_conv3x3(a, variant == PNP_CONV_TILE_BIG ? CONV_CFG_BIG : conv_pick_cfg(h, w), 1, (hipStream_t)st);
 }
 
+// ResidualBlockNoBNDynamic_drt.forward, channel_first / one_layer branch (sr_backbone_utils.py:305-313,329): two fused-conv
+// launches with the intermediate in caller scratch.
+int pnp_bae_block_f32(const float* x, const float* w2_packed, const float* b2, const float* gamma, const float* w1x1_packed,
+                      const float* par, const float* w1_packed, const float* b1, float* scratch, float* out, int h, int w,
+                      void* st) {
+    if (!x || !w2_packed || !w1_packed || !scratch || !out || h < 1 || w < 1) return PNP_ERR_BAD_ARG;
+    if ((w1x1_packed == nullptr) != (par == nullptr)) return PNP_ERR_BAD_ARG;
+    const float* src[1] = {x};
+    const int sc[1] = {64};
+    const float* wp[1] = {w2_packed};
+    int rc = pnp_conv3x3_f32(1, src, sc, wp, b2, gamma, w1x1_packed, par, nullptr, 1, scratch, h, w, st);
+    if (rc) return rc;
+    src[0] = scratch;
+    wp[0] = w1_packed;
+    return pnp_conv3x3_f32(1, src, sc, wp, b1, nullptr, nullptr, nullptr, x, 0, out, h, w, st);
+}
+
+// PixelShufflePack (common/upsample.py:40-51): conv3x3 64 -> 256 + F.pixel_shuffle(2), as 4 sub-pixel convs whose
+// output-channel order is permuted at pack time so that every sub-pixel is a contiguous 64-channel pixel row.
+int64_t pnp_packed_pixel_shuffle_floats(void) { return 4 * IMG_WIDE + 256; }
+
+int pnp_pack_pixel_shuffle_f32(const float* w, const float* b, float* dst, void* st_) {
+    hipStream_t st = (hipStream_t)st_;
+    if (!w || !b || !dst) return PNP_ERR_BAD_ARG;
+    for (int sub = 0; sub < 4; ++sub) {
+        PackArgs a = plain_pack(w, 64, 9, PACK_WIDE, 0, 2, 64, dst + sub * IMG_WIDE);
+        a.co_mul = 4;      // conv channel c*4 + (dy*2+dx) -> pixel (2y+dy, 2x+dx), channel c
+        a.co_add = sub;
+        const int rc = launch_pack_weights(a, 1, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(small_copy_kernel, dim3(1), dim3(256), 0, st, b, dst + 4 * IMG_WIDE, 256, 256, 1);
+    return (int)hipGetLastError();
+}
+
+int pnp_pixel_shuffle_conv_f32(const float* x, const float* packed, int act, float* out, int h, int w, void* st) {
+    if (!x || !packed || !out || h < 1 || w < 1 || act < 0 || act > 2) return PNP_ERR_BAD_ARG;
+    if ((int64_t)h * w * 4 * 256 >= (int64_t)1 << 32) return PNP_ERR_UNSUPPORTED;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = 1;
+    a.src[0] = x;
+    a.src_c[0] = 64;
+    a.wsrc[0] = packed;
+    a.w_ystride = IMG_WIDE;
+    a.bias = packed + 4 * IMG_WIDE;
+    a.bias_ystride = 64;
+    a.out = out;
+    a.H = h;
+    a.W = w;
+    a.act = act;
+    a.out_mode = 1;
+    return launch_conv3x3(a, conv_pick_cfg(h, w), 4, (hipStream_t)st);
+}
+
 int pnp_par_tile_flags_f32(const float* par, int* flags, int h, int w, void* st) {
     if (!par || !flags || h < 1 || w < 1) return PNP_ERR_BAD_ARG;
     return launch_par_tile_flags(par, (long)h * w, flags, 1, h, w, (hipStream_t)st);

@@ -310,3 +310,42 @@ def ssim_frames(a, b, crop_border=0):
         # i.e. the B plane of these RGB frames, enters the SSIM mean
         per_plane = per_plane[:, 2:3]
     return per_plane.mean(dim=1).cpu().reshape(a.shape[:-3])
+
+
+@_on_device_of_first_tensor
+def bae_block(x, w2_packed, b2, gamma, w1x1_packed, par, w1_packed, b1):
+    """One BAE block (ResidualBlockNoBNDynamic_drt.forward, sr_backbone_utils.py:305-313,329), pnp_bae_block_f32.
+    x (h,w,64) pixel-major; w2_packed = pack_conv3x3(experts, ew=attention); w1_packed = pack_conv3x3(conv1.weight);
+    w1x1_packed = pack_conv1x1([...]) and par (3,h,w), or both None; gamma (64,) or None."""
+    x = _chk(x, 'x')
+    h, w, _ = x.shape
+    keep = [(_chk(t, 'arg') if t is not None else None) for t in (w2_packed, b2, gamma, w1x1_packed, par, w1_packed, b1)]
+    scratch = torch.empty_like(x)
+    out = torch.empty_like(x)
+    _native.check(_native.lib().pnp_bae_block_f32(_ptr(x), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(keep[3]),
+                                                  _ptr(keep[4]), _ptr(keep[5]), _ptr(keep[6]), _ptr(scratch), _ptr(out),
+                                                  h, w, _stream()), 'pnp_bae_block_f32')
+    return out
+
+
+@_on_device_of_first_tensor
+def pack_pixel_shuffle(weight, bias):
+    """PixelShufflePack.upsample_conv (256,64,3,3) + bias (256) -> packed image for pixel_shuffle_conv."""
+    weight, bias = _chk(weight, 'weight'), _chk(bias, 'bias')
+    if tuple(weight.shape) != (256, 64, 3, 3) or tuple(bias.shape) != (256,):
+        raise ValueError('pixel-shuffle conv: weight (256,64,3,3), bias (256,)')
+    L = _native.lib()
+    dst = torch.empty(int(L.pnp_packed_pixel_shuffle_floats()), device=weight.device, dtype=torch.float32)
+    _native.check(L.pnp_pack_pixel_shuffle_f32(_ptr(weight), _ptr(bias), _ptr(dst), _stream()), 'pnp_pack_pixel_shuffle_f32')
+    return dst
+
+
+@_on_device_of_first_tensor
+def pixel_shuffle_conv(x, packed, act=0):
+    """PixelShufflePack.forward (upsample.py:40-51): x (h,w,64) -> (2h,2w,64); act 0 none / 1 relu / 2 leaky-relu(0.1)."""
+    x, packed = _chk(x, 'x'), _chk(packed, 'packed')
+    h, w, _ = x.shape
+    out = torch.empty((2 * h, 2 * w, 64), device=x.device, dtype=torch.float32)
+    _native.check(_native.lib().pnp_pixel_shuffle_conv_f32(_ptr(x), _ptr(packed), int(act), _ptr(out), h, w, _stream()),
+                  'pnp_pixel_shuffle_conv_f32')
+    return out

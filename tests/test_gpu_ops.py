@@ -401,3 +401,51 @@ def test_torch_custom_ops_call_the_hip_kernels():
     assert torch.equal(torch.ops.pnpvcve.mv_warp(feat, fx, fy), ops.mv_warp_nhwc(feat, fx, fy))
     with pytest.raises(RuntimeError):
         torch.ops.pnpvcve.generator_forward(987654, feat, feat, feat, torch.zeros(3, 1, 1))
+
+
+# ------------------------------------------------------------------ torch.ops.pnpvcve.* (SURVEY 8b's custom-op list)
+def test_custom_ops_equal_their_ctypes_wrappers_and_the_aten_definition():
+    """torch.ops.pnpvcve.{conv3x3, expert_mix, bae_block, pixel_shuffle_conv}: each equals the ops.* wrapper bit for bit
+    and the ATen definition of what it replaces within the conv tolerance."""
+    import pnp_vcve_amd  # noqa: F401
+    from pnp_vcve_amd import ops
+    P = torch.ops.pnpvcve
+    h, w = 40, 48
+    x = torch.randn(h, w, 64, device=dev())
+    xn = x.permute(2, 0, 1).unsqueeze(0).cpu()
+    experts = torch.randn(6, 64, 64, 3, 3, device=dev()) * 0.05
+    att = torch.softmax(torch.randn(6, device=dev()), 0)
+    # expert_mix == Dynamic_conv2d_se's mm(attention, weight) then packed (sr_backbone_utils.py:198-199)
+    w2p = P.expert_mix(experts, att)
+    assert torch.equal(w2p, ops.pack_conv3x3(experts, ew=att))
+    w2 = torch.einsum('e,eoikl->oikl', att.cpu(), experts.cpu())
+    b2 = torch.randn(64, device=dev()) * 0.1
+    gamma = torch.rand(64, device=dev()) * 2
+    # conv3x3
+    got = P.conv3x3([x], [w2p], b2, gamma, None, None, None, 1)
+    assert torch.equal(got, ops.conv3x3([x], [w2p], bias=b2, gamma=gamma, act=1))
+    ref = F.relu((F.conv2d(xn, w2, b2.cpu(), padding=1)) * gamma.cpu().view(1, -1, 1, 1))
+    assert maxdiff(got.permute(2, 0, 1).unsqueeze(0), ref) < TOL_CONV * 4
+    # bae_block == x + conv1(relu(gamma * (conv2(x) + b2) + sum_j par_j * conv1x1_j(x))) + b1
+    w1 = torch.randn(64, 64, 3, 3, device=dev()) * 0.05
+    b1 = torch.randn(64, device=dev()) * 0.1
+    k1 = [torch.randn(64, 64, 1, 1, device=dev()) * 0.1 for _ in range(3)]
+    par = (torch.rand(3, h, w, device=dev()) > 0.5).float() * torch.rand(3, h, w, device=dev())
+    w1p, k1p = ops.pack_conv3x3(w1), ops.pack_conv1x1(k1)
+    got = P.bae_block(x, w2p, b2, gamma, k1p, par, w1p, b1)
+    assert torch.equal(got, ops.bae_block(x, w2p, b2, gamma, k1p, par, w1p, b1))
+    two = ops.conv3x3([ops.conv3x3([x], [w2p], bias=b2, gamma=gamma, packed_w1x1=k1p, par=par, act=1)], [w1p], bias=b1,
+                      residual=x)
+    assert torch.equal(got, two)
+    dy = sum(F.conv2d(xn, k1[j].cpu()) * par[j].cpu() for j in range(3))
+    mid = F.relu(F.conv2d(xn, w2, b2.cpu(), padding=1) * gamma.cpu().view(1, -1, 1, 1) + dy)
+    ref = xn + F.conv2d(mid, w1.cpu(), b1.cpu(), padding=1)
+    assert maxdiff(got.permute(2, 0, 1).unsqueeze(0), ref) < 5e-5
+    # pixel_shuffle_conv == PixelShufflePack.forward (+ the head's leaky-relu)
+    wu = torch.randn(256, 64, 3, 3, device=dev()) * 0.05
+    bu = torch.randn(256, device=dev()) * 0.1
+    pk = ops.pack_pixel_shuffle(wu, bu)
+    got = P.pixel_shuffle_conv(x, pk, 2)
+    assert got.shape == (2 * h, 2 * w, 64) and torch.equal(got, ops.pixel_shuffle_conv(x, pk, 2))
+    ref = F.leaky_relu(F.pixel_shuffle(F.conv2d(xn, wu.cpu(), bu.cpu(), padding=1), 2), 0.1)
+    assert maxdiff(got.permute(2, 0, 1).unsqueeze(0), ref) < TOL_CONV * 4

@@ -254,7 +254,8 @@ def test_torch_custom_ops_are_registered_with_fake_kernels():
     """torch.ops.pnpvcve.*: schemas exist and the fake (meta) kernels propagate shapes without a GPU."""
     import pnp_vcve_amd  # noqa: F401
     from torch._subclasses.fake_tensor import FakeTensorMode
-    for name in ('flow_warp', 'mv_warp', 'psnr_sse', 'generator_forward'):
+    for name in ('flow_warp', 'mv_warp', 'psnr_sse', 'generator_forward', 'conv3x3', 'expert_mix', 'bae_block',
+                 'pixel_shuffle_conv'):                       # SURVEY 8(b)'s op list
         assert hasattr(torch.ops.pnpvcve, name), name
     assert 'Tensor x, Tensor flow' in str(torch.ops.pnpvcve.flow_warp.default._schema)
     with FakeTensorMode():
@@ -266,6 +267,11 @@ def test_torch_custom_ops_are_registered_with_fake_kernels():
         out = torch.ops.pnpvcve.generator_forward(0, lrs, torch.empty(1, 3, 4, 64, 64), torch.empty(1, 3, 3, 64, 64),
                                                   torch.empty(3, 1, 3))
         assert out.shape == (1, 3, 3, 64, 64)
+        pw = torch.empty(9 * 4096)
+        assert torch.ops.pnpvcve.conv3x3([f, f], [pw, pw], None, None, None, None, None, 2).shape == (64, 96, 64)
+        assert torch.ops.pnpvcve.expert_mix(torch.empty(6, 64, 64, 3, 3), torch.empty(6)).shape == (9 * 4096,)
+        assert torch.ops.pnpvcve.bae_block(f, pw, None, None, None, None, pw, None).shape == f.shape
+        assert torch.ops.pnpvcve.pixel_shuffle_conv(f, torch.empty(4 * 9 * 4096 + 256), 2).shape == (128, 192, 64)
 
 
 def test_bench_gpus_n_spawns_ranks_and_propagates_their_failure():
