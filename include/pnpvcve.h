@@ -220,6 +220,11 @@ int pnp_ssim_partials_f32(const float* a_dev, const float* b_dev, double* partia
 int pnp_dcn_nhwc_f32(const float* x_dev, const float* om_dev, const float* flow_x_dev, const float* flow_y_dev,
                      const float* w_packed_dev, const float* bias_dev, float* out_dev, int h, int w, void* stream);
 int pnp_dcn_ref_channel(int packed_channel);
+/* The same op with fp16 MFMA operands (PNP_PREC_F16: samples and weights rounded to fp16, fp32 accumulation):
+ * w_f16_dev = pnp_dcn_f16_image_from_f32(w_packed) (9 * 4096 halfs = 73,728 bytes). */
+int pnp_dcn_f16_image_from_f32(const float* w_packed_dev, void* dst_dev, void* stream);
+int pnp_dcn_nhwc_f16(const float* x_dev, const float* om_dev, const float* flow_x_dev, const float* flow_y_dev,
+                     const void* w_f16_dev, const float* bias_dev, float* out_dev, int h, int w, void* stream);
 
 /* MV / partition records -> dense maps: the inner loop of LoadImageFromFileList_ipb.__call__
  * (mmedit/datasets/pipelines/loading_ipb.py:328-369) + RescaleToZeroOne(partitions) + HWC->CHW.

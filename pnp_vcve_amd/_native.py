@@ -60,6 +60,9 @@ SIGNATURES = {
     'pnp_dcn_nhwc_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_void_p]),
     'pnp_dcn_ref_channel': (c_int, [c_int]),
+    'pnp_dcn_f16_image_from_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'pnp_dcn_nhwc_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_void_p]),
     'pnp_ssim_blocks': (c_int, [c_int, c_int, c_int]),
     'pnp_ssim_partials_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_conv3x3_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
@@ -82,6 +85,9 @@ DEBUG_SIGNATURES = {
     'pnp_conv3x3_f16_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
+
+DEBUG_SIGNATURES['pnp_dcn_nhwc_f32_ex'] = (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                   c_int, c_void_p, c_void_p])
 
 # pnp_generator_set_option ids (include/pnpvcve.h)
 OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_FUSED_BLOCK = range(5)

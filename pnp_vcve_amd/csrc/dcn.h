@@ -7,8 +7,12 @@ struct DcnArgs {
     const float* fx;       // 'basic': flow planes added to every offset (dx += fx, dy += fy); nullptr for 'fvc'
     const float* fy;
     const float* w;        // packed B image of deform_align.weight (9 chunks)
+    const void* w16;       // launch_dcn_f16_image of it: fp16 MFMA operands (PNP_PREC_F16), or nullptr = exact fp32 MFMA
     const float* bias;     // deform_align.bias [64]
     float* out;            // (H,W,64)
     int H, W;
+    unsigned long long* dbg;   // diagnostic timeline (pnp_dcn_nhwc_f32_ex): 8 u64 per wave, or nullptr
 };
 int launch_dcn(const DcnArgs& a, hipStream_t stream);
+// fp32 B image (9 chunks) -> the fp16 image of DcnArgs::w16 (9 * 4096 halfs)
+int launch_dcn_f16_image(const float* packed_w, void* dst, hipStream_t stream);

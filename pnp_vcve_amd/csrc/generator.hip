@@ -546,6 +546,10 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
         // conv_last's image has ONE 32-channel N tile per k-step: its chunks are half as long
         rc = launch_f16_image(packed + g->last_img, reinterpret_cast<uint16_t*>(packed + g->packed_floats) + g->last_img, 9, 1, st);
         if (rc) return rc;
+        if (c.deform != 0) {      // the DCN contraction consumes k in the order its lanes gather it (dcn.hip)
+            rc = launch_dcn_f16_image(packed + g->dcn_img, reinterpret_cast<uint16_t*>(packed + g->packed_floats) + g->dcn_img, st);
+            if (rc) return rc;
+        }
     }
     return (int)hipGetLastError();
 }
@@ -645,11 +649,13 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                      .mode(4, 7, IMG_WIDE).to(W.om));
         if (r) return r;
         DcnArgs d;
+        d.dbg = nullptr;
         d.x = feat;
         d.om = W.om;
         d.fx = c.deform == 1 ? fxp : nullptr;
         d.fy = c.deform == 1 ? fyp : nullptr;
         d.w = packed + g->dcn_img;
+        d.w16 = twin(packed + g->dcn_img);       // nullptr unless PNP_PREC_F16
         d.bias = flat + g->f_dcn_b;
         d.out = W.kw;
         d.H = h;
@@ -1006,8 +1012,38 @@ int pnp_caa_predict_f32(const float* q_ew, const float* q_g, int count, int E, i
 
 int pnp_dcn_nhwc_f32(const float* x, const float* om, const float* fx, const float* fy, const float* w_packed,
                      const float* bias, float* out, int h, int w, void* st) {
+    return pnp_dcn_nhwc_f32_ex(x, om, fx, fy, w_packed, bias, out, h, w, nullptr, st);
+}
+
+int pnp_dcn_f16_image_from_f32(const float* w_packed, void* dst, void* st) {
+    if (!w_packed || !dst) return PNP_ERR_BAD_ARG;
+    return launch_dcn_f16_image(w_packed, dst, (hipStream_t)st);
+}
+
+int pnp_dcn_nhwc_f16(const float* x, const float* om, const float* fx, const float* fy, const void* w_f16,
+                     const float* bias, float* out, int h, int w, void* st) {
+    if (h < 1 || w < 1 || !w_f16) return PNP_ERR_BAD_ARG;
+    DcnArgs d;
+    d.dbg = nullptr;
+    d.x = x;
+    d.om = om;
+    d.fx = fx;
+    d.fy = fy;
+    d.w = nullptr;
+    d.w16 = w_f16;
+    d.bias = bias;
+    d.out = out;
+    d.H = h;
+    d.W = w;
+    return launch_dcn(d, (hipStream_t)st);
+}
+
+int pnp_dcn_nhwc_f32_ex(const float* x, const float* om, const float* fx, const float* fy, const float* w_packed,
+                        const float* bias, float* out, int h, int w, void* trace, void* st) {
     if (h < 1 || w < 1) return PNP_ERR_BAD_ARG;
     DcnArgs d;
+    d.w16 = nullptr;
+    d.dbg = (unsigned long long*)trace;
     d.x = x;
     d.om = om;
     d.fx = fx;

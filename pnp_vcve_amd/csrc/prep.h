@@ -6,11 +6,20 @@
 int launch_pack_lr(const float* lrs, float* lr4, int T, int H, int W, hipStream_t stream);
 // (T,3,H,W) partition maps -> the dense equivalent of the reference's sparse_val evaluation (prep.hip)
 int launch_par_sparse(const float* par, float* out, int T, int H, int W, hipStream_t stream);
-// DCN conv_offset output channel order used by this build (dcn.hip): packed channel c' ->
-// reference channel of conv_offset[2] (offsets (g*9+k)*2+{dy,dx} for c' < 288, masks 288+g*9+k), -1 = padding
+// DCN conv_offset output channel order used by this build (dcn.hip): packed channel c' -> reference channel of
+// conv_offset[2] (offsets (g*9+k)*2+{dy,dx}, masks 288+g*9+k; g = deform group, k = tap), -1 = padding.
+// Packed order: a lane of the DCN kernel is (pixel, k-half h) and needs groups g = 2q+h, q = 0..7, of one tap at a
+// time, so offsets are [tap k][h][q][dy,dx] (c' = 32k + 16h + 2q + e) and mask logits [tap k][h][q] (288 + 16k + 8h + q):
+// 64 + 32 contiguous bytes per lane and tap.
 static inline __host__ __device__ int pnp_dcn_ref_channel_impl(int c) {
-    if (c < 288) return ((((c & 31) >> 1) * 9 + (c >> 5)) << 1) + (c & 1);
-    if (c < 432) return 288 + ((c - 288) & 15) * 9 + ((c - 288) >> 4);
+    if (c < 288) {
+        const int k = c >> 5, r = c & 31, g = 2 * ((r >> 1) & 7) + (r >> 4);
+        return ((g * 9 + k) << 1) + (r & 1);
+    }
+    if (c < 432) {
+        const int k = (c - 288) >> 4, r = (c - 288) & 15, g = 2 * (r & 7) + (r >> 3);
+        return 288 + g * 9 + k;
+    }
     return -1;
 }
 // two (H,W) planes -> (H,W,4) pixel-major (x, y, 0, 0): the flow as a conv source

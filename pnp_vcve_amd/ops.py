@@ -266,10 +266,11 @@ def rasterise_side_info(records, rec_frame, slices, h, w):
 
 
 @_on_device_of_first_tensor
-def modulated_deform_conv_nhwc(x, offset, mask_logits, weight, bias, flow=None):
+def modulated_deform_conv_nhwc(x, offset, mask_logits, weight, bias, flow=None, fp16=False):
     """mmcv.ops.modulated_deform_conv2d(x, offset, sigmoid(mask_logits), weight, bias, 1, 1, 1, 1, 16) for the
     hot path's shapes.  x (h,w,64) pixel-major; offset (288,h,w) and mask_logits (144,h,w) in mmcv's channel
-    order; weight (64,64,3,3); optional flow (2,h,w) = (dx,dy) added to every offset.  Returns (h,w,64)."""
+    order; weight (64,64,3,3); optional flow (2,h,w) = (dx,dy) added to every offset.  Returns (h,w,64).
+    fp16=True: fp16 MFMA operands (what PNP_PREC_F16 runs), fp32 accumulation."""
     x = _chk(x, 'x')
     h, w, _ = x.shape
     L = _native.lib()
@@ -282,6 +283,13 @@ def modulated_deform_conv_nhwc(x, offset, mask_logits, weight, bias, flow=None):
     out = torch.empty_like(x)
     fx = _chk(flow[0], 'flow') if flow is not None else None
     fy = _chk(flow[1], 'flow') if flow is not None else None
+    if fp16:
+        w16 = torch.empty(9 * 4096, device=x.device, dtype=torch.float16)
+        _native.check(L.pnp_dcn_f16_image_from_f32(_ptr(wp), ctypes.c_void_p(w16.data_ptr()), _stream()),
+                      'pnp_dcn_f16_image_from_f32')
+        _native.check(L.pnp_dcn_nhwc_f16(_ptr(x), _ptr(om), _ptr(fx), _ptr(fy), ctypes.c_void_p(w16.data_ptr()),
+                                         _ptr(_chk(bias, 'bias')), _ptr(out), h, w, _stream()), 'pnp_dcn_nhwc_f16')
+        return out
     _native.check(L.pnp_dcn_nhwc_f32(_ptr(x), _ptr(om), _ptr(fx), _ptr(fy), _ptr(wp), _ptr(_chk(bias, 'bias')), _ptr(out),
                                      h, w, _stream()), 'pnp_dcn_nhwc_f32')
     return out

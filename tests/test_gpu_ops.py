@@ -302,6 +302,29 @@ def test_modulated_deform_conv_vs_oracle(with_flow):
     assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < 5e-5
 
 
+@pytest.mark.parametrize('with_flow', [False, True])
+def test_modulated_deform_conv_fp16_operands_track_fp32(with_flow):
+    """PNP_PREC_F16's DCN contraction (v_mfma_f32_32x32x16_f16 over the lane-gathered k order, dcn_f16_image_kernel): a
+    layout slip would be an O(1) error; operand rounding is ~1e-3 of the output scale.  Block-constant flow + small
+    offsets (the LDS-window path) and a few far ones (the global fallback)."""
+    from pnp_vcve_amd import ops
+    h, w = 72, 80
+    x = G(gu.syn.uniform(22, 'x', (h, w, 64), -1, 1))
+    off = gu.syn.uniform(22, 'off', (288, h, w), -1.0, 1.0)
+    off[:, :3] *= 9.0
+    ml = gu.syn.uniform(22, 'm', (144, h, w), -2.0, 2.0)
+    wt = gu.syn.uniform(22, 'w', (64, 64, 3, 3), -0.06, 0.06)
+    b = gu.syn.uniform(22, 'b', (64,), -0.1, 0.1)
+    blk = gu.syn.randint(22, 'fl', (2, h // 8, w // 8), -32, 32).astype(np.float32) / 4.0
+    flow = G(np.ascontiguousarray(np.repeat(np.repeat(blk, 8, 1), 8, 2))) if with_flow else None
+    o32 = ops.modulated_deform_conv_nhwc(x, G(off), G(ml), G(wt), G(b), flow=flow)
+    o16 = ops.modulated_deform_conv_nhwc(x, G(off), G(ml), G(wt), G(b), flow=flow, fp16=True)
+    d = float((o16 - o32).abs().max())
+    scale = float(o32.abs().max())
+    print('dcn fp16 vs fp32', d, 'scale', scale)
+    assert 0.0 < d < 4e-3 * scale
+
+
 @pytest.mark.parametrize('hw', [(256, 512), (260, 516), (720, 1280)])
 def test_persistent_conv_is_bit_identical_to_the_tile_per_block_kernel(hw):
     """frames with >= 1024 tiles run the persistent kernel (conv_persist.hip): same arithmetic in the same
