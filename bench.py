@@ -111,6 +111,14 @@ def committed_pmc_traffic(tag):
         return json.load(fh), os.path.relpath(f, ROOT)
 
 
+def _launch_weighted_traffic(pmc, prefix):
+    """launch-weighted mean HBM bytes per launch over the kernel variants whose summarised name starts with `prefix`"""
+    ks = [v for k, v in pmc.items() if k.startswith(prefix) and 'hbm_bytes_per_launch' in v]
+    if not ks:
+        return None
+    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
+
+
 def make_inputs(seed, t, h, w, dev, n=1, crfs=None):
     """lq ~ U[0,1), quarter-pel block MVs, partition class ~ U{0,1,2} per 8x8 block (one-hot
     / 255, none on I frames), IBBBP cadence, QP 20..40, base_QP = crf / 255."""
@@ -211,8 +219,8 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
              'frac': ach / PEAK_F32_MFMA_TFLOPS, 'executed_TFLOPs': executed,
              'executed_frac': executed / PEAK_F32_MFMA_TFLOPS,
              'partition_branches_needed_per_tile': branches, 'partition_branch_chunks_run_per_tile': run,
-             'traffic': (pmc.get('conv3x3_persist_kernel', {}) if big else {}).get('hbm_bytes_per_launch'),
-             'traffic_source': pmc_src if big else None,
+             'traffic': _launch_weighted_traffic(pmc, 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>'),
+             'traffic_source': pmc_src,
              'launches': cb['launches'], 'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
              'all_convs_TFLOPs': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
              'device_ms_per_step': dev_ms}
@@ -232,9 +240,7 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         per_block = 524 if fused else 1036
         bytes_frame = h * w * (nb * per_block + (16 if vsr else 1) * 384)
         gbs = bytes_frame * T * steps * a['lq'].shape[0] / (cb['ms'] * 1e-3) / 1e9 if cb['ms'] > 0 else 0.0
-        f16k = [v for k, v in pmc.items() if 'f16' in k and 'hbm_bytes_per_launch' in v]
-        f16_traffic = (sum(v['hbm_bytes_per_launch'] * v['launches'] for v in f16k) / sum(v['launches'] for v in f16k)
-                       if f16k else None)
+        f16_traffic = _launch_weighted_traffic(pmc, 'conv3x3_f16_kernel')
         res['roofline'] = {
             'kernel': ('bae_block_f16_kernel (one launch per BAE block: both 3x3 convs + 1x1 branches, intermediate in LDS) + '
                        'conv3x3_f16_kernel (conv_hr)' if fused else
@@ -249,16 +255,17 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         gbs = wp['work'] / (wp['ms'] * 1e-3) / 1e9
         res['roofline_mv_warp'] = {'kernel': 'mv_warp_nhwc_kernel (MV-guided bilinear alignment)', 'bound': 'hbm',
                                    'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                                   'traffic': pmc.get('mv_warp_nhwc_kernel', {}).get('hbm_bytes_per_launch'),
+                                   'traffic': _launch_weighted_traffic(pmc, 'mv_warp_nhwc_kernel'),
                                    'traffic_source': pmc_src, 'launches': wp['launches'],
                                    'avg_launch_us': 1e3 * wp['ms'] / wp['launches'],
                                    'algorithmic_bytes_per_launch': wp['work'] / wp['launches']}
     if dc['launches']:
         gbs = dc['work'] / (dc['ms'] * 1e-3) / 1e9
-        res['roofline_dcn'] = {'kernel': 'dcn kernel (modulated deformable alignment: per-tap bilinear gather of 16 groups + '
-                                         '64x576 MFMA contraction)', 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS,
+        res['roofline_dcn'] = {'kernel': 'dcn_window_kernel<%s> (modulated deformable alignment: per-tap bilinear gather of 16 groups '
+                                         'from per-half LDS windows + 64x576 MFMA contraction, %s)'
+                                         % (('true', 'fp16 MFMA operands') if precision == 'fp16' else ('false', 'exact fp32 MFMA')), 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS,
                                'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                               'traffic': pmc.get('dcn', {}).get('hbm_bytes_per_launch'), 'traffic_source': pmc_src,
+                               'traffic': _launch_weighted_traffic(pmc, 'dcn_window_kernel'), 'traffic_source': pmc_src,
                                'launches': dc['launches'], 'avg_launch_us': 1e3 * dc['ms'] / dc['launches'],
                                'algorithmic_bytes_per_launch': dc['work'] / dc['launches'],
                                'algorithmic_bytes_per_pixel': 2240}
@@ -454,7 +461,10 @@ def secondary_workloads(dev, T):
     specs = [
         dict(name='7x3x128x128 fp32, 1 clip (north_star / configs[0-1])', workload='128', precision='fp32', vsr=False, clips=1,
              steps=20, warmup=3),
-        dict(name='7x3x128x128 fp32, 8 clips per step', workload='128', precision='fp32', vsr=False, clips=8, steps=5, warmup=2),
+        dict(name='7x3x128x128 fp32, 8 clips per step (8 concurrent contexts)', workload='128', precision='fp32', vsr=False,
+             clips=8, steps=5, warmup=2),
+        dict(name='7x3x128x128 fp32, 8 clips per step, each clip replayed as one hipGraph', workload='128', precision='fp32',
+             vsr=False, clips=8, steps=5, warmup=2, graphs=True, kernel_events=False),
         dict(name='7x3x180x320 fp16 MFMA convs, mixed crf15/25/35 batch of 3 (configs[4], vsr=False as the config ships)',
              workload='lr180', precision='fp16', vsr=False, clips=3, steps=5, warmup=2, crfs=[15, 25, 35]),
         dict(name='7x3x180x320 -> 720x1280 fp16 MFMA convs, x4 heads, mixed crf15/25/35 batch of 3 (configs[4] as described)',
@@ -466,12 +476,13 @@ def secondary_workloads(dev, T):
         sd_np = syn.make_state_dict(cfg, seed=2025)
         h, w = WORKLOADS[sp['workload']]
         r, m, a = measure(dev, sd_np, cfg, workload=sp['workload'], precision=sp['precision'], vsr=sp['vsr'],
-                          clips=sp['clips'], graphs=False, steps=sp['steps'], warmup=sp['warmup'], T=T,
-                          crfs=sp.get('crfs'))
+                          clips=sp['clips'], graphs=sp.get('graphs', False), steps=sp['steps'], warmup=sp['warmup'], T=T,
+                          crfs=sp.get('crfs'), kernel_events=sp.get('kernel_events', True))
         e = {'name': sp['name'], 'metric': f'enhanced frames/sec ({w}x{h}, {T}-frame window)', 'value': r['value'],
              'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': sp['steps'], 'warmup': sp['warmup'],
              'dtype': 'f32' if sp['precision'] == 'fp32' else 'f16 MFMA operands, f32 accumulate',
-             'clips_per_step': sp['clips'], 'vsr_x4_heads': sp['vsr'], 'kernel_events': r['kernel_events'],
+             'clips_per_step': sp['clips'], 'vsr_x4_heads': sp['vsr'], 'hip_graphs': sp.get('graphs', False),
+             'kernel_events': r['kernel_events'],
              'launches_per_frame': r['launches_per_frame'], 'psnr': r['psnr_rank']}
         for k in ('roofline', 'roofline_mv_warp'):
             if k in r:

@@ -90,7 +90,7 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat_dev, float* pac
 /* Bytes of ONE workspace context (one clip in flight).  pnp_generator_forward accepts a workspace of k such
  * contexts (k <= PNP_MAX_CONTEXTS) and then runs up to k samples of the batch concurrently on internal streams
  * forked from / joined to the caller's stream -- worth it for small frames, which cannot fill 256 CUs alone. */
-#define PNP_MAX_CONTEXTS 4
+#define PNP_MAX_CONTEXTS 8
 int64_t pnp_generator_workspace_bytes(const pnp_generator* g, int t, int h, int w);
 
 /* generator.forward(lrs, QPs, slices, mvs, base_QPs, par_map)  iconvsr_ipb_par.py:44-149.

@@ -195,7 +195,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
 
     #: frames below this many pixels cannot fill the chip alone: samples of a batch then run concurrently
     CONCURRENT_BELOW_PIXELS = 512 * 512
-    MAX_CONTEXTS = 4                       # PNP_MAX_CONTEXTS
+    MAX_CONTEXTS = 8                       # PNP_MAX_CONTEXTS (r02, 128x128 fp32, 8 clips: 2 ctx 2130, 4 ctx 2022, 8 ctx 2213 frames/s)
 
     def _get_workspace(self, n, t, h, w, device):
         ctx = 1 if h * w >= self.CONCURRENT_BELOW_PIXELS else min(n, self.MAX_CONTEXTS)

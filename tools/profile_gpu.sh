@@ -5,7 +5,7 @@
 #   usage: tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events}
+ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
