@@ -450,3 +450,46 @@ def test_720p_clip_directly_vs_oracle():
     assert d < TOL
     gt = torch.from_numpy(clip['gt'])
     assert abs(cpu_ref.clip_psnr(out, gt) - cpu_ref.clip_psnr(ref, gt)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------
+# host-side behaviour fixed in round 2
+# ------------------------------------------------------------------------------------------------------------
+def test_param_data_writes_need_invalidate_packed_and_state_dict_loads_do_not():
+    """the native weight images are cached on (data_ptr, _version): an in-place write through `.data` changes neither, so
+    invalidate_packed() is the documented way to make it visible; load_state_dict() and .to() invalidate by themselves."""
+    case = gu.GEN_CASES[1]
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    m = build(cfg, sd_np)
+    a = run(m, clip)
+    m.conv_last.bias.data.add_(0.25)            # no _version bump
+    m.invalidate_packed()
+    b = run(m, clip)
+    assert float((b - a - 0.25).abs().max()) < 1e-6
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd['conv_last.bias'] = sd['conv_last.bias'] - 0.25
+    m.load_state_dict(sd)                       # invalidates on its own
+    assert float((run(m, clip) - a).abs().max()) < 1e-6
+
+
+def test_unused_side_tensors_may_be_none_like_in_the_reference():
+    """use_base_qp=False never reads base_QPs (iconvsr_ipb_par.py:45): None must be accepted; a tensor the configuration
+    does read raises TypeError instead of AttributeError."""
+    case = [c for c in gu.GEN_CASES if c['name'] == 'gen_nobias_nosoftmax_qp_64x64'][0]
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    m = build(cfg, sd_np)
+    a = {k: torch.from_numpy(v).to(dev()) for k, v in clip.items()}
+    with torch.no_grad():
+        out = m(a['lq'], a['QPs'], a['slices'], a['mvs'], None, a['partitions'])
+        with pytest.raises(TypeError):
+            m(a['lq'], None, a['slices'], a['mvs'], None, a['partitions'])
+    ref = gu.load_golden(case['name'])['out']
+    assert float(np.abs(out.cpu().numpy() - ref).max()) < TOL
+
+
+def test_sparse_val_is_one_clip_at_a_time():
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, sparse_val=True, num_blocks=1)
+    m = build(cfg, gu.syn.make_state_dict(cfg, seed=1))
+    clip = gu.syn.make_clip(seed=2, n=2, t=2, h=64, w=64)
+    with pytest.raises(NotImplementedError):     # the reference reads feature[0] only (sr_backbone_utils.py:262-275)
+        run(m, clip)

@@ -181,3 +181,18 @@ def test_bench_headline_line_carries_the_secondary_workloads():
             assert e['roofline']['frac'] > 0 and e['launches_per_frame'] > 0
     assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm'
     assert sec[2]['hip_graphs'] is True and sec[4]['vsr_x4_heads'] is True
+
+
+def test_evaluate_refuses_a_batch_instead_of_scoring_sample_zero():
+    """the reference evaluates with samples_per_gpu=1; a batch would silently drop samples from the metric"""
+    from pnp_vcve_amd.registry import build_model
+    from pnp_vcve_amd import synthetic as syn
+    gcfg = dict(syn.DEFAULT_GENERATOR_CFG, num_blocks=1)
+    model = build_model(dict(type='BasicVSR', generator=dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par',
+                                                              **gcfg), pixel_loss=dict(type='CharbonnierLoss')),
+                        train_cfg=None, test_cfg=dict(metrics=['PSNR', 'SSIM'], crop_border=0)).cuda().eval()
+    x = torch.rand(2, 3, 3, 64, 64, device='cuda')
+    with pytest.raises(ValueError):
+        model.evaluate(x, x.clone())
+    one = model.evaluate(x[:1], x[:1].clone())
+    assert one['PSNR'] == float('inf') and abs(one['SSIM'] - 1.0) < 1e-12
