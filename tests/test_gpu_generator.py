@@ -241,20 +241,20 @@ def test_randomised_configs_and_shapes_vs_oracle():
 
 @pytest.mark.parametrize('fp16', [False, True])
 def test_batch_samples_run_concurrently_and_match_one_at_a_time(fp16):
-    """n = 6 small clips with mixed crf / slice-independent side info: the batch goes through the multi-context path
-    (4 contexts on side streams, samples 4 and 5 reuse contexts 0 and 1) and must equal sample-by-sample calls
+    """n = 10 small clips with mixed crf / slice-independent side info: the batch goes through the multi-context path
+    (8 contexts on side streams, samples 8 and 9 reuse contexts 0 and 1) and must equal sample-by-sample calls
     bit for bit; a following call on the caller's stream sees the finished output (join)."""
     cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
     sd_np = gu.syn.make_state_dict(cfg, seed=61, par_gain=10.0)
-    clip = gu.syn.make_clip(seed=62, n=6, t=4, h=64, w=80, slices='IBBBP', block=4, qp_mode='ipb',
-                            crf=[15, 25, 35, 25, 15, 35])
+    clip = gu.syn.make_clip(seed=62, n=10, t=4, h=64, w=80, slices='IBBBP', block=4, qp_mode='ipb',
+                            crf=[15, 25, 35, 25, 15, 35, 20, 30, 15, 35])
     m = build(cfg, sd_np)
     m.fp16_enabled = fp16
     out = run(m, clip)
     chk = out.sum()                      # consumer on the caller's stream, right behind the join
-    assert m._workspace and next(iter(m._workspace))[0] == 4
+    assert m.MAX_CONTEXTS == 8 and m._workspace and next(iter(m._workspace))[0] == 8
     singles = []
-    for b in range(6):
+    for b in range(10):
         one = {k: v[b:b + 1] for k, v in clip.items()}
         singles.append(run(m, one))
         assert next(iter(m._workspace))[0] == 1
