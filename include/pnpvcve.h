@@ -77,7 +77,8 @@ int pnp_generator_get_precision(const pnp_generator* g);
 #define PNP_OPT_CONV_LAST_VALU 2 /* conv_last on the vector ALUs (<= 2e-6 from the MFMA kernel: other summation order) */
 #define PNP_OPT_PERSIST 3        /* persistent strip kernel for the 64->64 convs on frames with >= 1024 tiles */
 #define PNP_OPT_FUSED_BLOCK 4    /* one launch per BAE block where a fused kernel exists (sr_backbone_utils.py:304-333) */
-#define PNP_OPT_COUNT 5
+#define PNP_OPT_SMALL_F16 5      /* PNP_PREC_F16: tile-per-block fp16 kernel for the 64->64 convs on frames with < 1024 tiles */
+#define PNP_OPT_COUNT 6
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 /* 1 when a BAE block of an h x w frame runs as ONE fused launch under the current precision / options, else 0 */
 int pnp_generator_uses_fused_block(const pnp_generator* g, int h, int w);

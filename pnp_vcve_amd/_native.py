@@ -90,7 +90,7 @@ DEBUG_SIGNATURES['pnp_dcn_nhwc_f32_ex'] = (c_int, [c_void_p, c_void_p, c_void_p,
                                                    c_int, c_void_p, c_void_p])
 
 # pnp_generator_set_option ids (include/pnpvcve.h)
-OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_FUSED_BLOCK = range(5)
+OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_FUSED_BLOCK, OPT_SMALL_F16 = range(6)
 CONV_AUTO, CONV_TILE, CONV_TILE_BIG = range(3)
 
 _lib = None

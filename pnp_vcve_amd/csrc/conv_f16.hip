@@ -541,6 +541,203 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small frames (fewer tiles than ~4 per CU: 180x320, 128x128).  The persistent kernel above pays its 72..96 KiB weight
+// prologue and its anti-phase pipeline for one or two tiles per block (12-14 us per launch at 180x320, 3 phases for two
+// tiles, one launch monopolising every CU's LDS).  Here a block is ONE 8x16 tile: 4 waves, the A tile + a 3-slot ring of
+// 8-KiB weight chunks (one 3x3 tap or one 1x1 branch = 4 k-steps x 2 N tiles) = 52 KiB of LDS -> three blocks per CU, the
+// whole frame resident at once, every block's latencies (halo from L2, chunk hand-over barriers, epilogue) hidden by its two
+// neighbours.  Chunk c+2 is requested while chunk c is contracted; one barrier per chunk.  Same k order, same fp32
+// accumulation and same epilogue arithmetic as the persistent kernel: bit-identical results (tested).
+// Covers the single-source 64 -> 64 launches (both halves of a BAE block, conv_hr): 33 of the ~38 launches of a frame.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int S_RING = 3;
+constexpr int S_CHUNK = 8 * UNIT;                          // 8192 B: 4 k-steps x 2 N tiles
+constexpr int S_OFF_R = A_BYTES;                           // ring behind the A tile
+constexpr int S_LDS_BYTES = A_BYTES + S_RING * S_CHUNK;    // 52,736
+static_assert(3 * S_LDS_BYTES <= 160 * 1024, "three blocks per CU");
+static_assert(S_LDS_BYTES >= 4 * 8192, "the epilogue transposes 4 x 8 KiB through the (dead) A tile + ring");
+
+template <bool PAR, bool SRC16, bool OUT16>
+__global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args a) {
+    constexpr int AIT = SRC16 ? AIT16 : AIT32;
+    constexpr int CPP = SRC16 ? 8 : 16;
+    constexpr int NC = 9 + (PAR ? 3 : 0);                  // weight chunks
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + TW - 1) / TW;
+    int tile;
+    {   // XCD-aware remap: each XCD walks a contiguous band of tiles (halo rows meet in its L2)
+        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
+        const int q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    char* const sA = smem;
+    char* const sR = smem + S_OFF_R;
+
+    const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
+    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, SRC16 ? map_bytes / 2 : map_bytes);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : a.src, a.residual ? map_bytes : 0);
+    const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, (unsigned)H * (unsigned)W * (OUT16 ? 128u : 256u));
+
+    // ---- requests: halo, the first two weight chunks, residual rows / partition values
+    f32x4 areg[AIT];
+    const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * (SRC16 ? 128u : 256u);
+#pragma unroll
+    for (int k = 0; k < AIT; ++k) {
+        const int i = t + 256 * k;
+        const int pix = i / CPP, cs = i % CPP;
+        const int ry = pix / PW, rx = pix - ry * PW;
+        const bool ok = (pix < NPIX) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);      // rows outside the image leave the descriptor by themselves
+        areg[k] = buf_load4(r_src, ok ? hbase + (unsigned)(ry * W + rx) * (SRC16 ? 128u : 256u) + (unsigned)cs * 16u : OOB);
+    }
+    const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
+    const f32x4* wgp = reinterpret_cast<const f32x4*>(a.wpar);
+    auto chunk_ptr = [&](int c) -> const f32x4* {          // 512 float4 per chunk
+        return (PAR && c >= 9) ? wgp + (c - 9) * 512 : wg + c * 512;
+    };
+    f32x4 wreg[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const f32x4* g = chunk_ptr(c);
+        const f32x4 v0 = g[t], v1 = g[t + 256];
+        *reinterpret_cast<f32x4*>(sR + c * S_CHUNK + t * 16) = v0;
+        *reinterpret_cast<f32x4*>(sR + c * S_CHUNK + (t + 256) * 16) = v1;
+    }
+    constexpr int EIT = 8;
+    const int ec = lane & 15, ep = lane >> 4, n0 = lane & 31;
+    const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    float bco[2], gco[2], pv[3] = {0.f, 0.f, 0.f};
+    f32x4 res4[EIT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bco[j] = a.bias ? a.bias[j * 32 + n0] : 0.f;
+        gco[j] = a.gamma ? a.gamma[j * 32 + n0] : 1.f;
+    }
+    const unsigned row_bytes = (unsigned)W * 256u;
+    {
+        const unsigned rbase = ((unsigned)((ty0 + 2 * wave) * W + tx0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
+#pragma unroll
+        for (int i = 0; i < (OUT16 ? 0 : EIT); ++i) {
+            const bool ok = tx0 + ep + 4 * (i & 3) < W;
+            res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
+        }
+        if (PAR) {
+            const int gy = ty0 + 2 * wave + my, gx = tx0 + mx;
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+                pv[jj] = buf_load1(r_par, ((gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+        }
+    }
+    // ---- halo -> fp16 A tile
+#pragma unroll
+    for (int k = 0; k < AIT; ++k) {
+        const int i = t + 256 * k;
+        const int pix = i / CPP, cs = i % CPP;
+        const int ry = pix / PW, rx = pix - ry * PW;
+        if (pix < NPIX) {
+            char* d = sA + ry * RSB + rx * PSB + cs * (SRC16 ? 16 : 8);
+            if (SRC16) *reinterpret_cast<f32x4*>(d) = areg[k];
+            else *reinterpret_cast<h4*>(d) = to_h4(areg[k]);
+        }
+    }
+    lds_barrier();
+
+    // ---- K loop: chunk c from ring slot c % 3; chunk c + 2 requested before, written after the contraction
+    const char* a_lane = sA + (2 * wave + my) * RSB + mx * PSB + 16 * h;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c + 2 < NC) {
+            const f32x4* g = chunk_ptr(c + 2);
+            wreg[0] = g[t];
+            wreg[1] = g[t + 256];
+        }
+        const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
+        const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
+        if (PAR && c == 9) {                       // (conv + bias) * gamma BEFORE the 1x1 partition branches
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+        }
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk) {
+            h8 av = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
+            const h8 b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
+            const h8 b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
+            if (PAR && c >= 9) av *= (_Float16)pv[c - 9];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+        }
+        if (c + 2 < NC) {
+            char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1: every wave left it at the previous barrier
+            *reinterpret_cast<f32x4*>(d + t * 16) = wreg[0];
+            *reinterpret_cast<f32x4*>(d + (t + 256) * 16) = wreg[1];
+        }
+        lds_barrier();
+    }
+    if (!PAR) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+    }
+
+    // ---- epilogue (the persistent kernel's, one tile): transpose through the dead A tile + ring, activation, residual,
+    //      whole pixel rows to HBM
+    float* sT = reinterpret_cast<float*>(smem + wave * 8192);
+    const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc[j][r];
+    asm volatile("" ::: "memory");
+    if (OUT16) {
+        const int ec8 = lane & 7, ep8 = lane >> 3;
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8];
+            hi[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8 + 1];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 u = lo[i], v = hi[i];
+            u = __builtin_elementwise_max(u, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(u, (f32x4)(0.f));
+            v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+            const h4 uh = to_h4(u), vh = to_h4(v);
+            const h8 pk = __builtin_shufflevector(uh, vh, 0, 1, 2, 3, 4, 5, 6, 7);
+            const int gx = tx0 + ep8 + 8 * (i & 1);
+            const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 1)) * (unsigned)W + (unsigned)gx) * 128u + (unsigned)ec8 * 16u;
+            buf_store4(r_out, gx < W ? o : OOB, __builtin_bit_cast(f32x4, pk));
+        }
+    } else {
+        f32x4 rows[EIT];
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            f32x4 v = rows[i];
+            v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+            v += res4[i];
+            const int gx = tx0 + ep + 4 * (i & 3);
+            const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 2)) * (unsigned)W + (unsigned)gx) * 256u + (unsigned)ec * 16u;
+            buf_store4(r_out, gx < W ? o : OOB, v);
+        }
+    }
+}
+
 // fp32 B image (common.h) -> fp16 image, chunk by chunk: element (s, nt, lane = (h, n), j) of the fp16 chunk is
 // input channel k = 16 s + 8 h + j, i.e. fp32 element ((k >> 3) * NTB + nt, ((k >> 2) & 1) * 32 + n, k & 3).
 __global__ __launch_bounds__(256) void f16_image_kernel(const float* __restrict__ src, _Float16* __restrict__ dst,
@@ -612,6 +809,26 @@ bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
     return true;
 }
 
+// single-source 64 -> 64 launches on frames with fewer than 1024 tiles (what the persistent design cannot amortise)
+static bool f16_small_eligible(const ConvArgs& a, int grid_y) {
+    if (a.no_small16) return false;
+    const long tiles = (long)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    return tiles < 1024 && grid_y == 1 && a.nsrc == 1 && a.src_c[0] == 64 && a.out_mode == 0 && !(a.src_f16 && a.out_f16);
+}
+
+template <bool PAR, bool SRC16, bool OUT16>
+static int launch_small(const F16Args& fa, hipStream_t stream) {
+    auto kern = conv3x3_f16_small_kernel<PAR, SRC16, OUT16>;
+    static PnpPerDevice once;
+    const hipError_t attr_err = once.run([&](int, int&) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const int tiles = ((fa.W + TW - 1) / TW) * ((fa.H + TH - 1) / TH);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), S_LDS_BYTES, stream, fa);
+    return (int)hipGetLastError();
+}
+
 // A conv over several 64-channel sources runs as a chain of single-source launches that accumulate through
 // `out` (fp32, added before the activation of the last link): every link keeps its weights resident in LDS.
 int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
@@ -647,6 +864,14 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         f.dbg = a.dbg;
         const bool s16 = a.src_f16 != 0, o16 = a.out_f16 != 0;      // single-source launches only (conv_f16_eligible)
         int rc;
+        if (f16_small_eligible(a, grid_y) && !(o16 && f.residual)) {
+            if (f.wpar) rc = s16 ? launch_small<true, true, false>(f, stream)
+                              : o16 ? launch_small<true, false, true>(f, stream) : launch_small<true, false, false>(f, stream);
+            else rc = s16 ? launch_small<false, true, false>(f, stream)
+                      : o16 ? launch_small<false, false, true>(f, stream) : launch_small<false, false, false>(f, stream);
+            if (rc) return rc;
+            continue;
+        }
         if (a.out_mode == 2 || a.out_mode == 3)
             rc = s16 ? launch_one<false, false, true, false, true>(f, grid_y, stream)
                      : launch_one<false, false, false, false, true>(f, grid_y, stream);

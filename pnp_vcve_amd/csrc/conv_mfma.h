@@ -31,6 +31,7 @@ struct ConvArgs {
     int H, W;               // spatial size of the sources
     int act;                // 0 none, 1 relu, 2 leaky-relu(0.1)
     unsigned long long* dbg; // diagnostic timeline buffer (8 u64 per block) or nullptr
+    int no_small16;         // 1: never the small-frame fp16 kernel (PNP_OPT_SMALL_F16 0): persistent fp16 kernel at every size
     int no_persist;         // 1: never the persistent kernel (pnp_generator_set_option PNP_OPT_PERSIST 0 / pnp_conv3x3_f32_ex)
     int out_cstride;        // out_mode 4: channels per pixel of the output buffer
     int out_mode;           // 0 NHWC64 | 1 NHWC64 pixel-shuffle(2), sub-pixel = blockIdx.y

@@ -66,7 +66,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
-    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1};   // pnp_generator_set_option (defaults: everything on)
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1};   // pnp_generator_set_option (defaults: everything on)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -606,6 +606,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.lr_plane = q.lr_plane_;
         a.wvalu = g->opt[PNP_OPT_CONV_LAST_VALU] ? q.wvalu_ : nullptr;
         a.no_persist = g->opt[PNP_OPT_PERSIST] ? 0 : 1;
+        a.no_small16 = g->opt[PNP_OPT_SMALL_F16] ? 0 : 1;
         a.w_ystride = q.w_ystride_;
         a.bias_ystride = q.bias_ystride_;
         a.H = q.H;

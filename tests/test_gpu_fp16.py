@@ -269,3 +269,33 @@ def test_f16_full_width_720p_tracks_fp32():
     p16 = float(ops.psnr_frames(outs[1][0], a['gt'][0]).mean())
     print(f'720p: max|fp16 - fp32| = {d:.3e}, PSNR {p32:.5f} vs {p16:.5f} dB')
     assert 0.0 < d < TOL_F16_PATH and abs(p32 - p16) < 1e-3
+
+
+@pytest.mark.parametrize('hw', [(180, 320), (128, 128), (68, 100)], ids=lambda s: '%dx%d' % s)
+def test_small_frame_f16_kernel_is_bit_identical_to_the_persistent_one(hw):
+    """frames with < 1024 tiles run the 64 -> 64 convs on conv3x3_f16_small_kernel (one tile per block, weight chunks
+    streamed through a 3-slot ring, three blocks per CU): same k order, same fp32 accumulation, same epilogue arithmetic as
+    the persistent fp16 kernel -- the clip must not change by a single bit (PNP_OPT_SMALL_F16 0 / 1), with fp16 and with
+    fp32 intermediate maps, ragged tiles included."""
+    import pnp_vcve_amd as P
+    from pnp_vcve_amd import _native
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=3)
+    sd_np = gu.syn.make_state_dict(cfg, seed=131, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=132, n=1, t=3, h=hw[0], w=hw[1], slices='IBBBP', block=4, par_classes=3)
+    m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+    m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
+    m = m.to(dev()).eval()
+    m.fp16_enabled = True
+    a = {k: G(v) for k, v in clip.items()}
+
+    def run():
+        with torch.no_grad():
+            return m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
+
+    for maps16 in (1, 0):
+        m.set_option(_native.OPT_F16_MAPS, maps16)
+        m.set_option(_native.OPT_SMALL_F16, 0)
+        ref = run().clone()
+        m.set_option(_native.OPT_SMALL_F16, 1)
+        out = run()
+        assert torch.isfinite(out).all() and torch.equal(out, ref), (hw, maps16, float((out - ref).abs().max()))

@@ -196,3 +196,18 @@ def test_evaluate_refuses_a_batch_instead_of_scoring_sample_zero():
         model.evaluate(x, x.clone())
     one = model.evaluate(x[:1], x[:1].clone())
     assert one['PSNR'] == float('inf') and abs(one['SSIM'] - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16'])
+def test_bench_deform_basic_reports_the_dcn_roofline(precision):
+    """bench.py --deform basic: the modulated-deformable aligner is timed as its own kind and priced on 2240 B per pixel"""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', '128', '--frames', '3', '--steps', '2',
+                          '--warmup', '1', '--deform', 'basic', '--precision', precision, '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    r = d['roofline_dcn']
+    assert d['config']['deform'] == 'basic' and r['bound'] == 'hbm' and r['launches'] == 2 * 4       # 4 alignments per 3-frame clip
+    assert abs(r['algorithmic_bytes_per_launch'] - 2240 * 128 * 128) < 1 and r['frac'] > 0
+    assert ('fp16' in r['kernel']) == (precision == 'fp16')
