@@ -52,6 +52,15 @@ GEN_CASES = [
                   num_blocks=3),
          wseed=24, par_gain=10.0,
          clip=dict(seed=115, n=1, t=3, h=64, w=64, slices='IBBBP', qp_mode='qp', crf=25)),
+    # r02: mixed constructor switches in one model (each switch alone is covered above)
+    dict(name='gen_nocat_twolayer_72x64', cfg=dict(with_cat=False, one_layer=False, align_key=False), wseed=27, par_gain=10.0,
+         clip=dict(seed=118, n=1, t=4, h=72, w=64, slices=[73, 66, 80, 66], qp_mode='qp', crf=35)),
+    dict(name='gen_chlast_nose_n2_64x64', cfg=dict(channel_first=False, with_se=False, num_blocks=4), wseed=28, par_gain=10.0,
+         clip=dict(seed=119, n=2, t=3, h=64, w=64, slices=[[73, 66, 80], [73, 80, 66]], qp_mode='ipb', crf=[15, 25])),
+    dict(name='gen_vsr_nocat_e4_64x64', cfg=dict(vsr=True, with_cat=False, num_experts=4, num_blocks=2), wseed=29, par_gain=10.0,
+         clip=dict(seed=120, n=1, t=3, h=64, w=64, slices='allP', qp_mode='qp', crf=25)),
+    dict(name='gen_t9_two_keys_64x64', cfg=dict(num_blocks=2), wseed=30, par_gain=10.0,
+         clip=dict(seed=121, n=1, t=9, h=64, w=64, slices=[73, 66, 66, 80, 66, 66, 66, 80, 66], qp_mode='qp', crf=25)),
     # sparse_val=True (eval-time sparse evaluation of the 1x1 branches): maps with NON-binary values and overlapping
     # planes, so that "nonzero -> 1/255, later plane wins" is visible (a one-hot/255 map would equal the dense path)
     dict(name='gen_sparse_val_64x64', cfg=dict(sparse_val=True), wseed=25, par_gain=10.0, par_kind='overlap',
