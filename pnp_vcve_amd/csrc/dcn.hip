@@ -247,9 +247,14 @@ __global__ __launch_bounds__(512) void dcn_window_kernel(const DcnArgs a) {
         oo[1] = no[1];
         om = nm;
         if (k < 7) load_om(k + 2, no, nm);
-        // fp16: the contraction is 4 MFMAs per tap -- nothing to hide behind, both groups gather first.  (MFMA-first was also
-        // measured WRONG for the fp16 instantiation on gfx950 / ROCm 7.2: group B's samples of taps >= 1 came out corrupted and
-        // non-deterministic, extra barriers / s_nops did not help; the fp32 instantiation is deterministic and oracle-exact.)
+        // fp16: the contraction is 4 MFMAs per tap -- nothing to hide behind, both groups gather first, and the choice is
+        // made at COMPILE time on purpose.  With a run-time two-armed order (each arm updating the accumulators) hipcc keeps
+        // the accumulators in different registers per arm and copies them with v_mov around the loop; in the fp16
+        // instantiation those copies sit right next to v_mfma_f32_32x32x16_f16 and the kernel then produced corrupted,
+        // non-deterministic sums on gfx950 / ROCm 7.2 (three of a lane's four samples -- the ones whose registers overlapped
+        // an MFMA destination range -- in either execution order; s_nops and barriers did not help).  The straight-line form
+        // below has no accumulator copies; tests/test_gpu_ops.py checks the fp16 kernel for run-to-run determinism and against
+        // the fp32 kernel.  The fp32 instantiation (run-time order) is deterministic and oracle-exact.
         if (F16 || grp == 0) {
             gather(ky, kx, oo, om, nav);
             stamp(d_g);

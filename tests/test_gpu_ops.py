@@ -319,6 +319,9 @@ def test_modulated_deform_conv_fp16_operands_track_fp32(with_flow):
     flow = G(np.ascontiguousarray(np.repeat(np.repeat(blk, 8, 1), 8, 2))) if with_flow else None
     o32 = ops.modulated_deform_conv_nhwc(x, G(off), G(ml), G(wt), G(b), flow=flow)
     o16 = ops.modulated_deform_conv_nhwc(x, G(off), G(ml), G(wt), G(b), flow=flow, fp16=True)
+    for _ in range(4):                                      # run-to-run determinism (see the note in dcn.hip's tap loop)
+        assert torch.equal(ops.modulated_deform_conv_nhwc(x, G(off), G(ml), G(wt), G(b), flow=flow, fp16=True), o16)
+        assert torch.equal(ops.modulated_deform_conv_nhwc(x, G(off), G(ml), G(wt), G(b), flow=flow), o32)
     d = float((o16 - o32).abs().max())
     scale = float(o32.abs().max())
     print('dcn fp16 vs fp32', d, 'scale', scale)
