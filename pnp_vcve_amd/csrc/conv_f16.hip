@@ -552,31 +552,37 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
 // Covers the single-source 64 -> 64 launches (both halves of a BAE block, conv_hr): 33 of the ~38 launches of a frame.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int S_RING = 3;
+constexpr int S_PAIR_TILES = 512;     // from this many tiles on, a block takes two adjacent tiles (measured: r02)
 constexpr int S_CHUNK = 8 * UNIT;                          // 8192 B: 4 k-steps x 2 N tiles
-constexpr int S_OFF_R = A_BYTES;                           // ring behind the A tile
-constexpr int S_LDS_BYTES = A_BYTES + S_RING * S_CHUNK;    // 52,736
-static_assert(3 * S_LDS_BYTES <= 160 * 1024, "three blocks per CU");
-static_assert(S_LDS_BYTES >= 4 * 8192, "the epilogue transposes 4 x 8 KiB through the (dead) A tile + ring");
+constexpr int s_lds_bytes(int g) { return g * A_BYTES + S_RING * S_CHUNK; }      // 52,736 (G = 1) / 80,896 (G = 2)
+static_assert(3 * s_lds_bytes(1) <= 160 * 1024 && 2 * s_lds_bytes(2) <= 160 * 1024, "three / two blocks per CU");
+static_assert(s_lds_bytes(1) >= 4 * 8192 && s_lds_bytes(2) >= 8 * 8192, "the epilogue transposes 8 KiB per wave through the dead LDS");
 
-template <bool PAR, bool SRC16, bool OUT16>
-__global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args a) {
+// G = groups of 4 waves per block, each group one tile (adjacent tiles), all sharing the block's weight ring: G = 2 halves the
+// weight bytes a tile pulls from L2 (two blocks per CU); G = 1 keeps three blocks per CU for the smallest frames.
+template <bool PAR, bool SRC16, bool OUT16, int G>
+__global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_kernel(const F16Args a) {
     constexpr int AIT = SRC16 ? AIT16 : AIT32;
     constexpr int CPP = SRC16 ? 8 : 16;
     constexpr int NC = 9 + (PAR ? 3 : 0);                  // weight chunks
+    constexpr int NT_ = 256 * G;                           // threads
+    constexpr int WPT = 512 / NT_;                         // float4 of a weight chunk per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tt = threadIdx.x, t = tt & 255, grp = tt >> 8, lane = t & 63, wave = t >> 6;
     const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
+    const int ntiles = tiles_x * ((H + TH - 1) / TH);
     int tile;
     {   // XCD-aware remap: each XCD walks a contiguous band of tiles (halo rows meet in its L2)
         const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
         const int q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        tile = ((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3)) * G + grp;
     }
+    const bool live = tile < ntiles;                       // an odd tile count leaves the last block's second group idle
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-    char* const sA = smem;
-    char* const sR = smem + S_OFF_R;
+    char* const sA = smem + grp * A_BYTES;
+    char* const sR = smem + G * A_BYTES;
 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
     const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, SRC16 ? map_bytes / 2 : map_bytes);
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
     const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, (unsigned)H * (unsigned)W * (OUT16 ? 128u : 256u));
 
-    // ---- requests: halo, the first two weight chunks, residual rows / partition values
+    // ---- requests: halo, the first weight chunks, residual rows / partition values
     f32x4 areg[AIT];
     const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * (SRC16 ? 128u : 256u);
 #pragma unroll
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
         const int i = t + 256 * k;
         const int pix = i / CPP, cs = i % CPP;
         const int ry = pix / PW, rx = pix - ry * PW;
-        const bool ok = (pix < NPIX) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);      // rows outside the image leave the descriptor by themselves
+        const bool ok = live & (pix < NPIX) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);  // rows outside the image leave the descriptor by themselves
         areg[k] = buf_load4(r_src, ok ? hbase + (unsigned)(ry * W + rx) * (SRC16 ? 128u : 256u) + (unsigned)cs * 16u : OOB);
     }
     const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
@@ -600,13 +606,22 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
     auto chunk_ptr = [&](int c) -> const f32x4* {          // 512 float4 per chunk
         return (PAR && c >= 9) ? wgp + (c - 9) * 512 : wg + c * 512;
     };
-    f32x4 wreg[2];
+    // weight chunks: chunk c is requested at the start of chunk c - 3's contraction, written to its ring slot at the end of
+    // chunk c - 2's and used after the barrier that ends chunk c - 1 -- two chunk durations for the load to land
+    f32x4 wreg[2][WPT];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const f32x4* g = chunk_ptr(c);
-        const f32x4 v0 = g[t], v1 = g[t + 256];
-        *reinterpret_cast<f32x4*>(sR + c * S_CHUNK + t * 16) = v0;
-        *reinterpret_cast<f32x4*>(sR + c * S_CHUNK + (t + 256) * 16) = v1;
+        f32x4 v[WPT];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) v[i] = g[tt + NT_ * i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * S_CHUNK + (tt + NT_ * i) * 16) = v[i];
+    }
+    {
+        const f32x4* g = chunk_ptr(2);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wreg[0][i] = g[tt + NT_ * i];
     }
     constexpr int EIT = 8;
     const int ec = lane & 15, ep = lane >> 4, n0 = lane & 31;
@@ -623,14 +638,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
         const unsigned rbase = ((unsigned)((ty0 + 2 * wave) * W + tx0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
 #pragma unroll
         for (int i = 0; i < (OUT16 ? 0 : EIT); ++i) {
-            const bool ok = tx0 + ep + 4 * (i & 3) < W;
+            const bool ok = live & (tx0 + ep + 4 * (i & 3) < W);
             res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
         }
         if (PAR) {
             const int gy = ty0 + 2 * wave + my, gx = tx0 + mx;
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj)
-                pv[jj] = buf_load1(r_par, ((gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+                pv[jj] = buf_load1(r_par, (live & (gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
         }
     }
     // ---- halo -> fp16 A tile
@@ -647,7 +662,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
     }
     lds_barrier();
 
-    // ---- K loop: chunk c from ring slot c % 3; chunk c + 2 requested before, written after the contraction
+    // ---- K loop: chunk c from ring slot c % 3
     const char* a_lane = sA + (2 * wave + my) * RSB + mx * PSB + 16 * h;
     f32x16 acc[2];
 #pragma unroll
@@ -656,10 +671,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (c + 2 < NC) {
-            const f32x4* g = chunk_ptr(c + 2);
-            wreg[0] = g[t];
-            wreg[1] = g[t + 256];
+        if (c + 3 < NC) {
+            const f32x4* g = chunk_ptr(c + 3);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) wreg[(c + 1) & 1][i] = g[tt + NT_ * i];
         }
         const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
         const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
@@ -680,8 +695,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
         }
         if (c + 2 < NC) {
             char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1: every wave left it at the previous barrier
-            *reinterpret_cast<f32x4*>(d + t * 16) = wreg[0];
-            *reinterpret_cast<f32x4*>(d + (t + 256) * 16) = wreg[1];
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (tt + NT_ * i) * 16) = wreg[c & 1][i];
         }
         lds_barrier();
     }
@@ -692,9 +707,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
             for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
     }
 
-    // ---- epilogue (the persistent kernel's, one tile): transpose through the dead A tile + ring, activation, residual,
-    //      whole pixel rows to HBM
-    float* sT = reinterpret_cast<float*>(smem + wave * 8192);
+    // ---- epilogue (the persistent kernel's, one tile): transpose through the dead LDS, activation, residual, whole pixel
+    //      rows to HBM
+    float* sT = reinterpret_cast<float*>(smem + (grp * 4 + wave) * 8192);
     const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -719,7 +734,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
             const h8 pk = __builtin_shufflevector(uh, vh, 0, 1, 2, 3, 4, 5, 6, 7);
             const int gx = tx0 + ep8 + 8 * (i & 1);
             const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 1)) * (unsigned)W + (unsigned)gx) * 128u + (unsigned)ec8 * 16u;
-            buf_store4(r_out, gx < W ? o : OOB, __builtin_bit_cast(f32x4, pk));
+            buf_store4(r_out, (live & (gx < W)) ? o : OOB, __builtin_bit_cast(f32x4, pk));
         }
     } else {
         f32x4 rows[EIT];
@@ -733,7 +748,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_f16_small_kernel(const F16Args
             v += res4[i];
             const int gx = tx0 + ep + 4 * (i & 3);
             const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 2)) * (unsigned)W + (unsigned)gx) * 256u + (unsigned)ec * 16u;
-            buf_store4(r_out, gx < W ? o : OOB, v);
+            buf_store4(r_out, (live & (gx < W)) ? o : OOB, v);
         }
     }
 }
@@ -816,17 +831,24 @@ static bool f16_small_eligible(const ConvArgs& a, int grid_y) {
     return tiles < 1024 && grid_y == 1 && a.nsrc == 1 && a.src_c[0] == 64 && a.out_mode == 0 && !(a.src_f16 && a.out_f16);
 }
 
-template <bool PAR, bool SRC16, bool OUT16>
-static int launch_small(const F16Args& fa, hipStream_t stream) {
-    auto kern = conv3x3_f16_small_kernel<PAR, SRC16, OUT16>;
+template <bool PAR, bool SRC16, bool OUT16, int G>
+static int launch_small_g(const F16Args& fa, hipStream_t stream) {
+    auto kern = conv3x3_f16_small_kernel<PAR, SRC16, OUT16, G>;
     static PnpPerDevice once;
     const hipError_t attr_err = once.run([&](int, int&) {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, s_lds_bytes(G));
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     const int tiles = ((fa.W + TW - 1) / TW) * ((fa.H + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), S_LDS_BYTES, stream, fa);
+    hipLaunchKernelGGL(kern, dim3((tiles + G - 1) / G), dim3(256 * G), s_lds_bytes(G), stream, fa);
     return (int)hipGetLastError();
+}
+
+template <bool PAR, bool SRC16, bool OUT16>
+static int launch_small(const F16Args& fa, hipStream_t stream) {
+    // two tiles per block (shared weight ring, half the weight bytes per tile) once the frame has a tile pair per CU slot
+    const int tiles = ((fa.W + TW - 1) / TW) * ((fa.H + TH - 1) / TH);
+    return tiles >= S_PAIR_TILES ? launch_small_g<PAR, SRC16, OUT16, 2>(fa, stream) : launch_small_g<PAR, SRC16, OUT16, 1>(fa, stream);
 }
 
 // A conv over several 64-channel sources runs as a chain of single-source launches that accumulate through
