@@ -583,6 +583,8 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     char* const sA = smem + grp * A_BYTES;
     char* const sR = smem + G * A_BYTES;
+    unsigned long long d_t0 = 0, d_t1 = 0, d_t2 = 0, d_t3 = 0;
+    if (a.dbg) d_t0 = __builtin_amdgcn_s_memtime();
 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
     const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, SRC16 ? map_bytes / 2 : map_bytes);
@@ -661,6 +663,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
         }
     }
     lds_barrier();
+    if (a.dbg) d_t1 = __builtin_amdgcn_s_memtime();
 
     // ---- K loop: chunk c from ring slot c % 3
     const char* a_lane = sA + (2 * wave + my) * RSB + mx * PSB + 16 * h;
@@ -707,6 +710,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
             for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
     }
 
+    if (a.dbg) d_t2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue (the persistent kernel's, one tile): transpose through the dead LDS, activation, residual, whole pixel
     //      rows to HBM
     float* sT = reinterpret_cast<float*>(smem + (grp * 4 + wave) * 8192);
@@ -750,6 +754,17 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
             const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 2)) * (unsigned)W + (unsigned)gx) * 256u + (unsigned)ec * 16u;
             buf_store4(r_out, (live & (gx < W)) ? o : OOB, v);
         }
+    }
+    if (a.dbg && t == 0) {      // diagnostic timeline (pnp_conv3x3_f16_ex): start, prologue end, K loop end, end (shader clock)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        d_t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * G + grp) * 16;
+        d[0] = d_t0;
+        d[1] = d_t1;
+        d[2] = d_t2;
+        d[3] = d_t3;
+        d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+        d[7] = 1;
     }
 }
 
