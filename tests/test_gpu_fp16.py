@@ -299,3 +299,4 @@ def test_small_frame_f16_kernel_is_bit_identical_to_the_persistent_one(hw):
         m.set_option(_native.OPT_SMALL_F16, 1)
         out = run()
         assert torch.isfinite(out).all() and torch.equal(out, ref), (hw, maps16, float((out - ref).abs().max()))
+
