@@ -242,10 +242,10 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         gbs = bytes_frame * T * steps * a['lq'].shape[0] / (cb['ms'] * 1e-3) / 1e9 if cb['ms'] > 0 else 0.0
         f16_traffic = _launch_weighted_traffic(pmc, 'conv3x3_f16_kernel')
         res['roofline'] = {
-            'kernel': ('bae_block_f16_kernel (one launch per BAE block: both 3x3 convs + 1x1 branches, intermediate in LDS) + '
-                       'conv3x3_f16_kernel (conv_hr)' if fused else
-                       'conv3x3_f16_kernel<PAR,LR4> (64->64 BAE-block convs + conv_hr; fp16 MFMA 32x32x16, weights resident '
-                       'in LDS, persistent strips)'),
+            'kernel': ('conv3x3_f16_kernel<PAR,LR4,SRC16,OUT16> (64->64 BAE-block convs + conv_hr; fp16 MFMA 32x32x16, weights resident '
+                       'in LDS, persistent strips, two groups in anti-phase)' if big else
+                       'conv3x3_f16_small_kernel<PAR,SRC16,OUT16,G> (64->64 BAE-block convs + conv_hr on frames under 1024 tiles; fp16 MFMA '
+                       '32x32x16, one tile per 4-wave group, weight chunks streamed through a 3-slot LDS ring, 3 blocks per CU)'),
             'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
             'algorithmic_bytes_per_pixel_per_block': per_block,
             'traffic': f16_traffic, 'traffic_source': pmc_src, 'launches': cb['launches'],
@@ -468,6 +468,8 @@ def secondary_workloads(dev, T):
              clips=8, steps=5, warmup=2),
         dict(name='7x3x128x128 fp32, 8 clips per step, each clip replayed as one hipGraph', workload='128', precision='fp32',
              vsr=False, clips=8, steps=5, warmup=2, graphs=True, kernel_events=False),
+        dict(name='7x3x720x1280 fp16 MFMA convs (the headline shape with the opt-in fp16 operands)', workload='720p', precision='fp16',
+             vsr=False, clips=1, steps=3, warmup=1),
         dict(name='7x3x180x320 fp16 MFMA convs, mixed crf15/25/35 batch of 3 (configs[4], vsr=False as the config ships)',
              workload='lr180', precision='fp16', vsr=False, clips=3, steps=5, warmup=2, crfs=[15, 25, 35]),
         dict(name='7x3x180x320 -> 720x1280 fp16 MFMA convs, x4 heads, mixed crf15/25/35 batch of 3 (configs[4] as described)',

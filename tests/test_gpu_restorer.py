@@ -174,13 +174,14 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert 0 < r['frac_dense_par'] <= r['frac'] * 1.02 and 0 < r['executed_frac'] <= r['frac']
     assert 'U{0,1,2}' in d['config']['workload']
     sec = d['secondary']
-    assert len(sec) == 5
+    assert len(sec) == 6
     for e in sec:
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
             assert e['roofline']['frac'] > 0 and e['launches_per_frame'] > 0
-    assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm'
-    assert sec[2]['hip_graphs'] is True and sec[4]['vsr_x4_heads'] is True
+    assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm' and sec[4]['roofline']['bound'] == 'hbm'
+    assert sec[2]['hip_graphs'] is True and sec[5]['vsr_x4_heads'] is True
+    assert sec[3]['value'] > 3 * d['value']       # fp16 operands at the headline shape: > 3x the fp32 rate
 
 
 def test_evaluate_refuses_a_batch_instead_of_scoring_sample_zero():
