@@ -328,6 +328,41 @@ def test_modulated_deform_conv_fp16_operands_track_fp32(with_flow):
     assert 0.0 < d < 4e-3 * scale
 
 
+@pytest.mark.parametrize('fp16', [False, True], ids=['fp32', 'fp16'])
+def test_dcn_at_720p_collapses_to_the_conv_kernel_and_to_a_shifted_conv(fp16):
+    """full-size properties of the DCN kernel (persistent blocks, LDS windows): with zero offsets and saturated masks it is
+    the plain 3x3 conv (checked against the fused conv kernel), and with a block-constant INTEGER flow added to every offset
+    ('basic', iconvsr_mv.py:77) it is the conv of the image shifted by that flow -- per 8x8 block, i.e. every window position."""
+    from pnp_vcve_amd import ops
+    h, w = 720, 1280
+    x = torch.randn(h, w, 64, device=dev())
+    wt = torch.randn(64, 64, 3, 3, device=dev()) * 0.05
+    b = torch.randn(64, device=dev()) * 0.1
+    off = torch.zeros(288, h, w, device=dev())
+    ml = torch.full((144, h, w), 30.0, device=dev())             # sigmoid(30) = 1 - 9e-14
+    tol = 5e-3 if fp16 else 1e-4          # fp16 operand rounding on randn features over 5.9e7 outputs: 2.1e-3 observed
+    ref = ops.conv3x3([x], [ops.pack_conv3x3(wt)], bias=b)
+    out = ops.modulated_deform_conv_nhwc(x, off, ml, wt, b, fp16=fp16)
+    assert maxdiff(out, ref.cpu()) < tol
+    # one integer flow for the whole frame: out(p) = conv(x)(p + flow) wherever p + flow and its 3x3 support stay inside
+    dy, dx = 3, -5
+    flow = torch.zeros(2, h, w, device=dev())
+    flow[0] = dx
+    flow[1] = dy
+    out = ops.modulated_deform_conv_nhwc(x, off, ml, wt, b, flow=flow, fp16=fp16)
+    assert maxdiff(out[8:-8, 8:-8], ref[8 + dy:h - 8 + dy, 8 + dx:w - 8 + dx].cpu()) < tol
+    # a different integer flow per 8x8 block (every window gets its own origin): sample a few blocks against the shifted conv
+    blk = torch.from_numpy(gu.syn.randint(33, 'f', (2, h // 8, w // 8), -8, 8).astype(np.float32)).to(dev())
+    flow = blk.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()
+    out = ops.modulated_deform_conv_nhwc(x, off, ml, wt, b, flow=flow, fp16=fp16)
+    for by, bx in ((5, 7), (40, 90), (44, 3), (80, 150), (17, 101)):
+        fx, fy = int(blk[0, by, bx]), int(blk[1, by, bx])
+        ys, xs = slice(8 * by + 1, 8 * by + 7), slice(8 * bx + 1, 8 * bx + 7)       # interior of the block (3x3 support stays in one flow)
+        got = out[ys, xs]
+        want = ref[8 * by + 1 + fy:8 * by + 7 + fy, 8 * bx + 1 + fx:8 * bx + 7 + fx]
+        assert maxdiff(got, want.cpu()) < tol, (by, bx, fx, fy)
+
+
 @pytest.mark.parametrize('hw', [(256, 512), (260, 516), (720, 1280)])
 def test_persistent_conv_is_bit_identical_to_the_tile_per_block_kernel(hw):
     """frames with >= 1024 tiles run the persistent kernel (conv_persist.hip): same arithmetic in the same
