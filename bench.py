@@ -56,7 +56,6 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-kernel HIP-event timing')
     ap.add_argument('--no-secondary', action='store_true', help='skip the other BASELINE workloads after the headline')
-    ap.add_argument('--no-fused', action='store_true', help='two launches per BAE block (PNP_OPT_FUSED_BLOCK 0)')
     return ap.parse_args(argv)
 
 
@@ -174,16 +173,51 @@ def cpu_baseline(sd_np, cfg, h, w):
     return clip, ref, dt
 
 
-def build_model(cfg, sd_np, dev, precision, graphs=False, fused=True):
+def cpu_baseline_128(T):
+    """BASELINE configs[0]: the oracle on one synthetic T x 3 x 128 x 128 clip on the host cores, 1 warm-up + median of 5,
+    at the calibrated thread count -- the CPU number that stands beside the 128x128 GPU throughput entries."""
+    import statistics
     import torch
-    from pnp_vcve_amd import _native
+    from oracle import cpu_ref
+    from pnp_vcve_amd import synthetic as syn
+    cfg = dict(syn.DEFAULT_GENERATOR_CFG)
+    sd = cpu_ref.to_torch_state(syn.make_state_dict(cfg, seed=2025))
+    clip = syn.make_clip(seed=1000, n=1, t=T, h=128, w=128, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)
+    a = {k: torch.from_numpy(v) for k, v in clip.items()}
+
+    def run():
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            cpu_ref.generator_forward(sd, cfg, a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
+            return time.perf_counter() - t0
+
+    best, best_nt = None, 1
+    for nt in (8, 16, 32):
+        if nt > (os.cpu_count() or 1):
+            break
+        torch.set_num_threads(nt)
+        run()
+        dt = run()
+        if best is None or dt < best:
+            best, best_nt = dt, nt
+    torch.set_num_threads(best_nt)
+    run()
+    ts = sorted(run() for _ in range(5))
+    med = statistics.median(ts)
+    return {'value': T / med, 'unit': 'frames/s', 'cores': best_nt, 'threads': best_nt, 'host_logical_cpus': os.cpu_count(),
+            'kind': 'port', 'seconds_per_clip_median_of_5': med, 'seconds_per_clip_runs': ts,
+            'sample': f'oracle/cpu_ref.py on one {T}x3x128x128 clip (BASELINE configs[0]), 1 warm-up + median of 5; threads '
+                      f'calibrated over 8/16/32'}
+
+
+def build_model(cfg, sd_np, dev, precision, graphs=False):
+    import torch
     from pnp_vcve_amd.registry import build_backbone
     m = build_backbone(dict(type=GEN_TYPE, **cfg))
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     m = m.to(dev).eval()
     m.fp16_enabled = precision == 'fp16'
     m.use_graphs = bool(graphs)
-    m.set_option(_native.OPT_FUSED_BLOCK, 1 if fused else 0)
     return m
 
 
@@ -201,12 +235,11 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
               'mv_warp': wp['ms'] / steps, 'dcn': dc['ms'] / steps}
     nb = 2 * cfg['num_blocks']
     big = h * w >= 1024 * 128
-    # a fused block launch (PNP_OPT_FUSED_BLOCK) is ONE conv_block record carrying both halves' FLOPs
     if precision == 'fp32':
-        # The conv kernels skip a 1x1 partition branch on tiles where its plane is all zero (bit-identical).  `achieved`
-        # is the reference's dense (algorithmic) FLOP count over the measured time; `executed` discounts the skipped branch
-        # chunks so the matrix pipe's real utilisation is visible next to it; `frac_dense_par` is the same kernels timed on a
-        # dense float partition map (all three branches live on every tile: nothing skipped).
+        # The conv kernels skip a 1x1 partition branch on tiles where its plane is all zero (bit-identical).  `ach` is the
+        # reference's dense (algorithmic) FLOP count over the measured time; `executed` discounts the skipped branch chunks:
+        # the matrix pipe's real utilisation; `frac_dense_par` is the same kernels timed on a dense float partition map (all
+        # three branches live on every tile: nothing skipped, executed == algorithmic).
         fl = torch.stack([par_tile_flags(a['partitions'][0, i]) for i in range(T)])
         branches = sum(((fl >> j) & 1).float().mean().item() for j in range(3))        # needed branches per tile
         run = torch.clamp(sum(((fl >> j) & 1) for j in range(3)), min=1).float().mean().item()   # chunks really run
@@ -215,9 +248,14 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         executed = ach * (1 - skipped_frac)
         kern = ('conv3x3_persist_kernel<PAR> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, persistent strips)'
                 if big else 'conv3x3_mfma_kernel<2,2,1,2> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, 4x16 tiles)')
-        r = {'kernel': kern, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-             'frac': ach / PEAK_F32_MFMA_TFLOPS, 'executed_TFLOPs': executed,
-             'executed_frac': executed / PEAK_F32_MFMA_TFLOPS,
+        # roofline.achieved / frac price the FLOPs the kernel EXECUTES (what the matrix pipe really did per second);
+        # algorithmic_* is the reference's dense count over the same time (what a user gets per second)
+        r = {'kernel': kern, 'bound': 'mfma', 'achieved': executed, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+             'frac': executed / PEAK_F32_MFMA_TFLOPS, 'algorithmic_TFLOPs': ach,
+             'algorithmic_frac': ach / PEAK_F32_MFMA_TFLOPS,
+             'definition': 'achieved = executed FLOPs (dense reference count minus the 64-deep 1x1 branch chunks skipped on tiles '
+                           'whose partition plane is all zero; = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) / HIP-event launch time; '
+                           'algorithmic_* = the dense reference count 2*K*64*H*W over the same time',
              'partition_branches_needed_per_tile': branches, 'partition_branch_chunks_run_per_tile': run,
              'traffic': _launch_weighted_traffic(pmc, 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>'),
              'traffic_source': pmc_src,
@@ -232,15 +270,13 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         res['roofline'] = r
     else:
         # At the fp16 matrix rate the block convs are HBM-bound: price them in algorithmic bytes.  Per frame: nb BAE
-        # blocks (fused launch: read x 256 + 3 partition planes 12 + write 256 B/px = 524; two launches: front 256 + 12 +
-        # 128 [fp16 map], back 128 + 256 [residual] + 256 = 1036) + conv_hr (read 256, write 128 fp16; x16 pixels behind
+        # blocks (two launches: front 256 + 12 [3 partition planes] + 128 [fp16 map], back 128 + 256 [residual] + 256 = 1036)
+        # + conv_hr (read 256, write 128 fp16; x16 pixels behind
         # the x4 heads).
-        from pnp_vcve_amd import _native
-        fused = bool(m.get_option(_native.OPT_FUSED_BLOCK)) and m.fused_block_active(h, w)
-        per_block = 524 if fused else 1036
+        per_block = 1036
         bytes_frame = h * w * (nb * per_block + (16 if vsr else 1) * 384)
         gbs = bytes_frame * T * steps * a['lq'].shape[0] / (cb['ms'] * 1e-3) / 1e9 if cb['ms'] > 0 else 0.0
-        f16_traffic = _launch_weighted_traffic(pmc, 'conv3x3_f16_kernel')
+        f16_traffic = _launch_weighted_traffic(pmc, 'conv3x3_f16_kernel' if big else 'conv3x3_f16_small_kernel')
         res['roofline'] = {
             'kernel': ('conv3x3_f16_kernel<PAR,LR4,SRC16,OUT16> (64->64 BAE-block convs + conv_hr; fp16 MFMA 32x32x16, weights resident '
                        'in LDS, persistent strips, two groups in anti-phase)' if big else
@@ -276,12 +312,12 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
 
 
 def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, warmup, T, rank=0, world=1,
-            kernel_events=True, dense_par=False, fused=True, dist=None, cdev=None, crfs=None):
+            kernel_events=True, dense_par=False, dist=None, cdev=None, crfs=None):
     """Build the model for (cfg, precision), make the clip, time `steps` forwards (barrier + synchronize on both sides,
     MAX over ranks) and take the per-kernel HIP-event records.  Returns (result dict, model, device inputs)."""
     import torch
     h, w = WORKLOADS[workload]
-    m = build_model(cfg, sd_np, dev, precision, graphs, fused)
+    m = build_model(cfg, sd_np, dev, precision, graphs)
     clip, a = make_inputs(1000 + rank, T, h, w, dev, clips, crfs)   # clip `rank` of the synthetic set (sampler rule: idx[rank::world])
 
     def step(inp=a):
@@ -296,18 +332,18 @@ def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, 
     events_inside = kernel_events and workload == '720p'
     if events_inside:
         m.profile(True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed_max = elapsed
-    if world > 1:
+    if dist is not None:
         et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed_max = float(et.item())
@@ -371,15 +407,18 @@ def main():
     ndev = max(torch.cuda.device_count(), 1)                  # counting devices does not initialise the GPU
     local = local % ndev
     dev = torch.device('cuda', local)
-    if world > 1:
+    # A torch.distributed environment (RANK / WORLD_SIZE from torch.distributed.run) means "be a rank": the process group
+    # is created and every collective below runs over it even at WORLD_SIZE=1, so the RCCL path (init with device_id,
+    # barrier, all_reduce(MAX), all_gather on device tensors, destroy) is the same code at N = 1 and N = 8.
+    grouped = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    torch.cuda.set_device(dev)
+    if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(dev)
+        os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(dev)
     cdev = dev if backend == 'nccl' else torch.device('cpu')   # where the tiny collective payloads live
 
     from pnp_vcve_amd import synthetic as syn
@@ -395,11 +434,11 @@ def main():
     r, m, a = measure(dev, sd_np, cfg, workload=args.workload, precision=args.precision, vsr=args.vsr, clips=args.clips,
                       graphs=args.graphs, steps=args.steps, warmup=args.warmup, T=T, rank=rank, world=world,
                       kernel_events=not args.no_kernel_events, dense_par=headline and world == 1,
-                      fused=not args.no_fused, dist=dist, cdev=cdev)
+                      dist=dist if grouped else None, cdev=cdev)
 
     # per-rank metrics, gathered with one small collective (PSNR, frames/s): mmedit/apis/test.py:211-233
     mine = torch.tensor([r['psnr_rank'], r['frames_per_s_rank']], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if grouped:
         allm = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allm, mine)
         allm = torch.stack(allm).cpu().numpy()
@@ -420,6 +459,12 @@ def main():
                        'vsr_x4_heads': bool(args.vsr), 'hip_graphs': bool(args.graphs), 'deform': args.deform,
                        'parallelism': f'clip-sharded replicas x{world}', 'frames_per_step_per_gpu': T * args.clips},
             'kernel_events': r['kernel_events'], 'launches_per_frame': r['launches_per_frame'],
+            # which collectives really ran: with a torch.distributed environment the barrier / all_reduce(MAX) / all_gather
+            # above went over this backend ('nccl' = RCCL) -- at WORLD_SIZE=1 too
+            'dist': {'process_group': grouped, 'backend': dist.get_backend() if grouped else None,
+                     'rccl_version': ('.'.join(str(v) for v in torch.cuda.nccl.version())
+                                      if grouped and backend == 'nccl' else None),
+                     'collectives': ['barrier', 'all_reduce(MAX)', 'all_gather', 'barrier'] if grouped else []},
             'psnr_per_rank': [float(x) for x in allm[:, 0]],
             'frames_per_s_per_rank': [float(x) for x in allm[:, 1]],
         }
@@ -436,7 +481,8 @@ def main():
             if args.vsr:
                 gt = gt.repeat_interleave(4, -1).repeat_interleave(4, -2)
             res['cpu_baseline'] = {
-                'value': 2 / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'value': 2 / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'threads': torch.get_num_threads(),
+                'host_logical_cpus': os.cpu_count(), 'kind': 'port',
                 'sample': f'oracle/cpu_ref.py (PyTorch-CPU fp32 restatement of the reference, pinned by tests/golden) on '
                           f'one 2x3x{h}x{w} clip (2 of the 7 frames, same frame size; both frames are sequence ends, so the '
                           f'sample holds 2 of the clip\'s 12 alignment calls -- 0.7 % of the CPU time) = {dt:.1f} s; threads '
@@ -448,14 +494,14 @@ def main():
         del m, a
         torch.cuda.empty_cache()
         if world == 1 and headline and not args.no_secondary and not args.no_kernel_events:
-            res['secondary'] = secondary_workloads(dev, T)
+            res['secondary'] = secondary_workloads(dev, T, args.no_cpu_baseline)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def secondary_workloads(dev, T):
+def secondary_workloads(dev, T, no_cpu_baseline=False):
     """The other workloads BASELINE.json names, each with its own timed region (same barrier-free N = 1 protocol:
     warm-up, synchronize, K steps, synchronize), roofline and kernel-event mode."""
     import torch
@@ -475,6 +521,7 @@ def secondary_workloads(dev, T):
         dict(name='7x3x180x320 -> 720x1280 fp16 MFMA convs, x4 heads, mixed crf15/25/35 batch of 3 (configs[4] as described)',
              workload='lr180', precision='fp16', vsr=True, clips=3, steps=5, warmup=2, crfs=[15, 25, 35]),
     ]
+    cpu128 = None if no_cpu_baseline else cpu_baseline_128(T)
     for sp in specs:
         cfg = dict(syn.DEFAULT_GENERATOR_CFG)
         cfg['vsr'] = sp['vsr']
@@ -492,6 +539,9 @@ def secondary_workloads(dev, T):
         for k in ('roofline', 'roofline_mv_warp'):
             if k in r:
                 e[k] = r[k]
+        if sp['workload'] == '128' and sp['precision'] == 'fp32' and cpu128 is not None:
+            e['cpu_baseline'] = cpu128          # north_star: "alongside the reference CPU path timed on the host cores"
+            e['speedup_vs_cpu'] = r['value'] / cpu128['value']
         out.append(e)
         del m, a
         torch.cuda.empty_cache()

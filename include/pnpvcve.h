@@ -25,7 +25,7 @@ extern "C" {
 #define PNP_ERR_SIZE_ASSERT 1004 /* reference: AssertionError, h/w < 64 (iconvsr_ipb_par.py:51) */
 #define PNP_ERR_SIZE_VALUE 1005  /* reference: ValueError from flow_warp.py:27-29 (h/w % 4 != 0) */
 
-int pnp_abi_version(void); /* 2: pnp_generator_cfg.sparse_val, pnp_generator_set_option, pnp_bae_block_* */
+int pnp_abi_version(void); /* 3: the never-implemented fused-block option / query of v2 removed, PNP_OPT_* renumbered, PNP_OPT_SPARSE_EVAL */
 
 /* ------------------------------------------------------------------ generator (a1/a2)
  * Constructor kwargs of IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par
@@ -76,12 +76,13 @@ int pnp_generator_get_precision(const pnp_generator* g);
 #define PNP_OPT_PAR_SKIP 1       /* skip 1x1 partition branches whose plane is all zero on a tile (exact zeros) */
 #define PNP_OPT_CONV_LAST_VALU 2 /* conv_last on the vector ALUs (<= 2e-6 from the MFMA kernel: other summation order) */
 #define PNP_OPT_PERSIST 3        /* persistent strip kernel for the 64->64 convs on frames with >= 1024 tiles */
-#define PNP_OPT_FUSED_BLOCK 4    /* one launch per BAE block where a fused kernel exists (sr_backbone_utils.py:304-333) */
-#define PNP_OPT_SMALL_F16 5      /* PNP_PREC_F16: tile-per-block fp16 kernel for the 64->64 convs on frames with < 1024 tiles */
+#define PNP_OPT_SMALL_F16 4      /* PNP_PREC_F16: tile-per-block fp16 kernel for the 64->64 convs on frames with < 1024 tiles */
+#define PNP_OPT_SPARSE_EVAL 5    /* cfg.sparse_val only: 1 = eval mode (sparse semantics), 0 = training mode -- the reference takes the
+                                    sparse branch only when `self.sparse_val and not self.training` (sr_backbone_utils.py:308,322,
+                                    basicvsr_net.py:511) and the dense par * conv1x1 formula otherwise (NOT bit-identical: the two
+                                    differ on non-one-hot maps) */
 #define PNP_OPT_COUNT 6
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
-/* 1 when a BAE block of an h x w frame runs as ONE fused launch under the current precision / options, else 0 */
-int pnp_generator_uses_fused_block(const pnp_generator* g, int h, int w);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 
 /* flat (reference layouts) -> packed (MFMA B images); replaces nothing in the reference,

@@ -40,7 +40,6 @@ SIGNATURES = {
     'pnp_generator_get_precision': (c_int, [c_void_p]),
     'pnp_generator_set_option': (c_int, [c_void_p, c_int, c_int]),
     'pnp_generator_get_option': (c_int, [c_void_p, c_int]),
-    'pnp_generator_uses_fused_block': (c_int, [c_void_p, c_int, c_int]),
     'pnp_generator_profile': (c_int, [c_void_p, c_int]),
     'pnp_generator_profile_read': (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),
                                            POINTER(ctypes.c_double)]),
@@ -90,7 +89,7 @@ DEBUG_SIGNATURES['pnp_dcn_nhwc_f32_ex'] = (c_int, [c_void_p, c_void_p, c_void_p,
                                                    c_int, c_void_p, c_void_p])
 
 # pnp_generator_set_option ids (include/pnpvcve.h)
-OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_FUSED_BLOCK, OPT_SMALL_F16 = range(6)
+OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_SMALL_F16, OPT_SPARSE_EVAL = range(6)
 CONV_AUTO, CONV_TILE, CONV_TILE_BIG = range(3)
 
 _lib = None

@@ -91,6 +91,6 @@ def multi_gpu_test(model, dataset, save_image=False, save_path=None, device='cud
             res = model(test_mode=True, save_image=save_image, save_path=save_path, **data)
         fps = data['lq'].shape[1] / model.last_forward_seconds if getattr(model, 'last_forward_seconds', None) else 0.0
         local.append([float(res['eval_result'].get(m, float('nan'))) for m in metrics] + [fps])
-    table = gather_clip_metrics(local, len(dataset), device=device if world > 1 else None)
+    table = gather_clip_metrics(local, len(dataset), device=device)
     return [dict(eval_result={m: float(table[i, j]) for j, m in enumerate(metrics)}, frames_per_s=float(table[i, -1]))
             for i in range(len(dataset))]

@@ -242,7 +242,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
 
     unsigned long long dbg_k = 0, dbg_e = 0, dbg_h = 0, dbg_t0 = 0, dbg_a = 0, dbg_p[6] = {0, 0, 0, 0, 0, 0};
     int dbg_n = 0;
-    if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dbg_r0 = 0;      // the constant 100 MHz counter next to the shader clock: their ratio is the clock held
+    if (a.dbg) {
+        dbg_t0 = __builtin_amdgcn_s_memtime();
+        dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- prologue for the first tile of the strip
     __builtin_amdgcn_s_setprio(3);
     stage_load(ty0, tx0);
@@ -391,6 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
         d[6] = dbg_h;
         d[7] = dbg_n;
         for (int i = 0; i < 5; ++i) d[8 + i] = dbg_p[i];
+        d[13] = dbg_r0;
+        d[14] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -241,14 +241,6 @@ __global__ void small_copy_kernel(const float* __restrict__ src, float* __restri
     }
 }
 
-// One launch per BAE block (PNP_OPT_FUSED_BLOCK): which (precision, layout, frame size) combinations have a fused kernel.
-bool fused_block_eligible(const pnp_generator* g, int h, int w) {
-    (void)h;
-    (void)w;
-    if (!g->opt[PNP_OPT_FUSED_BLOCK]) return false;
-    return false;      // no fused kernel yet
-}
-
 PackArgs plain_pack(const float* w, int cin_total, int ktaps, int kind, int cbase, int ntb, int n_valid, float* dst) {
     PackArgs a;
     memset(&a, 0, sizeof(a));
@@ -408,7 +400,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
 
 extern "C" {
 
-int pnp_abi_version(void) { return 2; }
+int pnp_abi_version(void) { return 3; }
 
 int pnp_generator_create(const pnp_generator_cfg* cfg, pnp_generator** out) {
     if (!cfg || !out) return PNP_ERR_BAD_ARG;
@@ -454,9 +446,6 @@ int pnp_generator_set_option(pnp_generator* g, int option, int value) {
     if (!g || option < 0 || option >= PNP_OPT_COUNT) return PNP_ERR_BAD_ARG;
     g->opt[option] = value != 0;
     return PNP_OK;
-}
-int pnp_generator_uses_fused_block(const pnp_generator* g, int h, int w) {
-    return (g && fused_block_eligible(g, h, w)) ? 1 : 0;
 }
 int pnp_generator_get_option(const pnp_generator* g, int option) {
     return (g && option >= 0 && option < PNP_OPT_COUNT) ? g->opt[option] : -1;
@@ -671,7 +660,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         g->prof_last = nullptr;           // untimed launches follow
         rc = launch_pack_lr(lr_b, W.lr4, t, h, w, st);
         if (rc) return rc;
-        if (c.sparse_val) {               // the reference's sparse evaluation as a dense map (prep.hip)
+        if (c.sparse_val && g->opt[PNP_OPT_SPARSE_EVAL]) {   // the reference's (eval-mode) sparse evaluation as a dense map (prep.hip)
             rc = launch_par_sparse(par_b, W.parbin, t, h, w, st);
             if (rc) return rc;
             par_b = W.parbin;
@@ -878,7 +867,7 @@ int pnp_generator_forward(const pnp_generator* g, const float* flat, const float
                           int h, int w, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (n < 1 || t < 1) return PNP_ERR_BAD_ARG;
-    if (g->cfg.sparse_val && n != 1) return PNP_ERR_UNSUPPORTED;   // sparse_conv reads feature[0] only (sr_backbone_utils.py:262-275)
+    if (g->cfg.sparse_val && g->opt[PNP_OPT_SPARSE_EVAL] && n != 1) return PNP_ERR_UNSUPPORTED;   // sparse_conv reads feature[0] only (sr_backbone_utils.py:262-275)
     if (h < 64 || w < 64) return PNP_ERR_SIZE_ASSERT;
     if ((h % 4) || (w % 4)) return PNP_ERR_SIZE_VALUE;
     // the kernels address a feature map with 32-bit byte offsets: the largest one (x16 pixels with the x4 heads) must

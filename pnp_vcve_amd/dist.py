@@ -33,8 +33,10 @@ def init_dist(launcher='pytorch', backend='nccl', **kwargs):
         raise ValueError(f'Invalid launcher type: {launcher} (only "pytorch" is built)')
     rank = int(os.environ['RANK'])
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank % max(torch.cuda.device_count(), 1))))
+    if backend == 'nccl':       # RCCL: bind the communicator to this rank's GPU up front (no lazy init at the first collective)
+        local = int(os.environ.get('LOCAL_RANK', rank)) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        kwargs.setdefault('device_id', torch.device('cuda', local))
     dist.init_process_group(backend=backend, **kwargs)
 
 
@@ -55,11 +57,13 @@ def gather_clip_metrics(local, n_total, device=None):
     """local: list (this rank's clips, in shard order) of K-float lists.  Returns, on every rank,
     the [n_total, K] float64 tensor in dataset order."""
     rank, world = get_dist_info()
-    if world > 1 and dist.get_backend() != 'nccl':
-        device = None                               # gloo (CPU tests, dry runs): the payload stays on the host
+    grouped = dist.is_available() and dist.is_initialized()
+    if not grouped or dist.get_backend() != 'nccl':
+        device = None                               # gloo (CPU tests, dry runs) / no group: the payload stays on the host
     t = torch.tensor(local, dtype=torch.float64, device=device).reshape(len(local), -1)
-    if world == 1:
+    if not grouped:
         return t[:n_total].cpu()
+    # with a process group the collective runs even at world size 1: the RCCL path is the same code at 1 and 8 GPUs
     parts = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(parts, t)                       # the only data-path-adjacent collective
     stacked = torch.stack(parts, dim=1)             # [per, world, K]: zip(*parts) order

@@ -106,9 +106,6 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
                       'pnp_generator_set_option')
         self._graphs = {}
 
-    def fused_block_active(self, h, w):
-        """True when a BAE block of an h x w frame runs as one fused launch (pnp_generator_uses_fused_block)."""
-        return bool(_native.lib().pnp_generator_uses_fused_block(self._handle, int(h), int(w)))
 
     def get_option(self, option):
         return int(_native.lib().pnp_generator_get_option(self._handle, int(option)))
@@ -227,7 +224,13 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             if mvs_c.shape != (n, t, 4, h, w) or par_c.shape != (n, t, 3, h, w):
                 raise ValueError(f'The spatial sizes of input ({(h, w)}) and flow/partition maps '
                                  f'({tuple(mvs_c.shape)}, {tuple(par_c.shape)}) are not the same.')
-            if self.sparse_val and n != 1:
+            if self.sparse_val:
+                # the reference's blocks take sparse_conv only when `self.sparse_val and not self.training`
+                # (sr_backbone_utils.py:308,322, basicvsr_net.py:511); in train() mode they run the dense formula
+                sparse_now = 0 if self.training else 1
+                if self.get_option(_native.OPT_SPARSE_EVAL) != sparse_now:
+                    self.set_option(_native.OPT_SPARSE_EVAL, sparse_now)
+            if self.sparse_val and not self.training and n != 1:
                 raise NotImplementedError('sparse_val=True evaluates one clip at a time: the reference reads feature[0] '
                                           'only (sr_backbone_utils.py:262-275)')
             # a side tensor the configuration does not read may be None, as in the reference (QPs is always read when

@@ -172,6 +172,9 @@ def conv3x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, r
     fp16=True: packed_w / packed_w1x1 are f16_image() tensors and the MFMA operands are fp16.
     variant / par_flags / trace: include/pnpvcve_debug.h (kernel selection, per-tile branch flags, timeline buffer)."""
     if fp16:
+        if variant is not None or par_flags is not None:
+            raise ValueError('conv3x3(fp16=True): `variant` and `par_flags` select among the fp32 kernels only '
+                             '(pnp_conv3x3_f16_ex takes neither)')
         return _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act, trace)
     srcs = [_chk(s, 'src') for s in srcs]
     h, w = srcs[0].shape[:2]

@@ -437,6 +437,33 @@ def test_lr180_mixed_crf_batch_fp16_vs_fp32(vsr):
     assert float((run(m, same)[0] - o32[0]).abs().max()) > 1e-6
 
 
+@pytest.mark.parametrize('vsr', [False, True], ids=['enhance', 'x4'])
+def test_lr180_fp16_small_frame_kernel_vs_oracle(vsr):
+    """configs[4] at its own workload, fp16 MFMA operands, against the PINNED ORACLE (not against this build's fp32 path):
+    180x320 is 450 tiles, so every 64->64 conv runs conv3x3_f16_small_kernel.  Gates: max-abs 2e-2 on [0,1] frames and
+    |PSNR delta| < 1e-3 dB vs the oracle's output (north_star's PSNR gate); T = 3 (enhance) / T = 2 (x4 heads)."""
+    from pnp_vcve_amd import _native
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, vsr=vsr)
+    sd_np = gu.syn.make_state_dict(cfg, seed=405)
+    clip = gu.syn.make_clip(seed=4050, n=1, t=2 if vsr else 3, h=180, w=320, slices='IBBBP', qp_mode='ipb', crf=25, block=4)
+    m = build(cfg, sd_np)
+    m.fp16_enabled = True
+    assert m.get_option(_native.OPT_SMALL_F16) == 1
+    out = run(m, clip).cpu()
+    ref = _oracle(cfg, sd_np, clip)
+    gt = torch.from_numpy(clip['gt'])
+    if vsr:
+        gt = gt.repeat_interleave(4, -1).repeat_interleave(4, -2)
+    d = float((out - ref).abs().max())
+    dp = cpu_ref.clip_psnr(out, gt) - cpu_ref.clip_psnr(ref, gt)
+    print(f'180x320 fp16 (vsr={vsr}) vs oracle: max-abs {d:.3e}, PSNR delta {dp:+.2e} dB')
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    assert 1e-6 < d < 2e-2 and abs(dp) < 1e-3
+    # the small-frame kernel really was the one that ran: the persistent fp16 kernel gives the same bits
+    m.set_option(_native.OPT_SMALL_F16, 0)
+    assert torch.equal(run(m, clip).cpu(), out)
+
+
 def test_720p_clip_directly_vs_oracle():
     """The headline path itself (persistent strip kernel, 8x16 tiles, 720p) against the pinned oracle on a whole 2-frame
     clip -- not through a crop (about 40 s of CPU)."""
@@ -493,3 +520,28 @@ def test_sparse_val_is_one_clip_at_a_time():
     clip = gu.syn.make_clip(seed=2, n=2, t=2, h=64, w=64)
     with pytest.raises(NotImplementedError):     # the reference reads feature[0] only (sr_backbone_utils.py:262-275)
         run(m, clip)
+
+
+def test_sparse_val_follows_the_training_flag():
+    """The reference takes sparse_conv only when `self.sparse_val and not self.training` (sr_backbone_utils.py:308,322,
+    basicvsr_net.py:511): in train() mode a sparse_val=True model evaluates the dense par * conv1x1 formula, i.e. exactly
+    what a sparse_val=False model computes; back in eval() it returns to the sparse golden."""
+    case = [c for c in gu.GEN_CASES if c['name'] == 'gen_sparse_val_64x64'][0]
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    m = build(cfg, sd_np)
+    ref = gu.load_golden(case['name'])['out']
+    dense = run(build(dict(cfg, sparse_val=False), sd_np), clip)
+    m.train()
+    with torch.no_grad():
+        tr = run(m, clip)
+    assert torch.equal(tr, dense)
+    assert float((tr.cpu() - torch.from_numpy(ref)).abs().max()) > 1e-3          # the two formulas differ on this map
+    m.eval()
+    assert float(np.abs(run(m, clip).cpu().numpy() - ref).max()) < TOL
+    # a batch is fine in train() mode (dense path), refused in eval() mode (the reference's feature[0] indexing)
+    two = {k: np.concatenate([v, v]) for k, v in clip.items()}
+    m.train()
+    assert run(m, two).shape[0] == 2
+    m.eval()
+    with pytest.raises(NotImplementedError):
+        run(m, two)

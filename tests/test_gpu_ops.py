@@ -30,7 +30,7 @@ def maxdiff(a, b):
 
 def test_native_library_is_loaded():
     from pnp_vcve_amd import _native
-    assert _native.lib().pnp_abi_version() == 2
+    assert _native.lib().pnp_abi_version() == 3
 
 
 @pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])
@@ -158,6 +158,36 @@ def test_bae_block_vs_reference(case):
     out = _block_via_ops(sd, 'backward_resblocks.main.0.', x, par, ew, gamma)
     ref = gu.load_golden(case['name'])['block']
     assert maxdiff(out, ref) < TOL_BLOCK
+
+
+@pytest.mark.parametrize('case', gu.BLOCK_CASES, ids=[c['name'] for c in gu.BLOCK_CASES])
+def test_whole_branch_through_the_c_abi_vs_reference(case):
+    """ResidualBlocksWithInputConvDynamic_drt.forward (basicvsr_net.py:506-519) = input conv over the 195-channel concat +
+    LeakyReLU + 8 BAE blocks, driven op by op through the C ABI (pnp_conv3x3_f32 over the virtual concat, then
+    8 x pnp_bae_block_f32), against the `branch` tensor the reference itself produced (tests/golden/block_*.npz)."""
+    from pnp_vcve_amd import ops
+    cfg, sd, x, par, ew, gamma = gu.block_case_inputs(case)
+    h, w = x.shape[-2:]
+    xin = gu.syn.uniform(case['seed'], 'xin', (1, 195, h, w), -1.0, 1.0)
+    br = 'forward_resblocks'
+    lr4 = np.concatenate([xin[:, :3], np.zeros((1, 1, h, w), np.float32)], axis=1)
+    srcs = [ops.nchw_to_nhwc(G(lr4))[0]] + [ops.nchw_to_nhwc(G(np.ascontiguousarray(xin[:, 3 + 64 * j:67 + 64 * j])))[0]
+                                             for j in range(3)]
+    wg = G(sd[f'{br}.input_conv.0.weight'])
+    packed = [ops.pack_conv3x3(wg, 0, 3)] + [ops.pack_conv3x3(wg, 3 + 64 * j, 64) for j in range(3)]
+    f = ops.conv3x3(srcs, packed, bias=G(sd[f'{br}.input_conv.0.bias']), act=2)
+    ewg, parg, gam = G(ew[0]), G(par[0]), G(gamma[0])
+    for i in range(cfg['num_blocks']):
+        p = f'{br}.main.{i}.'
+        w2 = ops.pack_conv3x3(G(sd[p + 'conv2.weight']), ew=ewg)
+        b2 = (G(sd[p + 'conv2.bias']) * ewg[:, None]).sum(0)
+        w1x1 = ops.pack_conv1x1([G(sd[p + k + '.weight']) for k in ('conv16x16', 'conv16x8', 'conv8x8')])
+        f = ops.bae_block(f, w2, b2, gam, w1x1, parg, ops.pack_conv3x3(G(sd[p + 'conv1.weight'])), G(sd[p + 'conv1.bias']))
+    out = ops.nhwc_to_nchw(f.unsqueeze(0))
+    ref = gu.load_golden(case['name'])['branch']
+    d = maxdiff(out, ref)
+    print(case['name'], 'branch max|hip - reference| =', d, 'ref max', float(np.abs(ref).max()))
+    assert out.shape == ref.shape and d < 2e-4 * max(1.0, float(np.abs(ref).max()))
 
 
 def test_bae_block_partition_branch_is_live():

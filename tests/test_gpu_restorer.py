@@ -171,7 +171,10 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
     assert d['metric'].startswith('enhanced frames/sec (1280x720') and d['dtype'] == 'f32'
     r = d['roofline']
-    assert 0 < r['frac_dense_par'] <= r['frac'] * 1.02 and 0 < r['executed_frac'] <= r['frac']
+    # frac prices EXECUTED FLOPs; algorithmic_frac (the dense reference count) can only be larger; on a dense partition map
+    # nothing is skipped, so the dense-map figure is an executed figure too
+    assert 0 < r['frac'] <= r['algorithmic_frac'] and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert 0 < r['frac_dense_par'] <= r['algorithmic_frac'] * 1.02
     assert 'U{0,1,2}' in d['config']['workload']
     sec = d['secondary']
     assert len(sec) == 6
@@ -182,6 +185,7 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm' and sec[4]['roofline']['bound'] == 'hbm'
     assert sec[2]['hip_graphs'] is True and sec[5]['vsr_x4_heads'] is True
     assert sec[3]['value'] > 3 * d['value']       # fp16 operands at the headline shape: > 3x the fp32 rate
+    assert all('cpu_baseline' not in e for e in sec)          # --no-cpu-baseline covers the secondary entries too
 
 
 def test_evaluate_refuses_a_batch_instead_of_scoring_sample_zero():
@@ -212,3 +216,115 @@ def test_bench_deform_basic_reports_the_dcn_roofline(precision):
     assert d['config']['deform'] == 'basic' and r['bound'] == 'hbm' and r['launches'] == 2 * 4       # 4 alignments per 3-frame clip
     assert abs(r['algorithmic_bytes_per_launch'] - 2240 * 128 * 128) < 1 and r['frac'] > 0
     assert ('fp16' in r['kernel']) == (precision == 'fp16')
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _rank_env(world=1, rank=0, **extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('PNP_DIST_BACKEND',)}
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(extra)
+    return env
+
+
+def test_bench_rank_path_runs_over_rccl_at_world_size_1():
+    """bench.py as a rank of a torch.distributed job with the DEFAULT backend ('nccl' = RCCL): init_process_group with
+    device_id -> barrier -> timed steps -> barrier -> all_reduce(MAX) of the elapsed time -> all_gather of the per-rank
+    metrics (device tensors) -> barrier -> destroy_process_group, all in a fresh child process.  The same code runs at
+    WORLD_SIZE=8 on the driver's node (tools/dist_test.sh:11-22, mmedit/apis/test.py:211-233)."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', '128', '--frames', '3', '--steps', '2',
+                          '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=_rank_env())
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['n_gpus'] == 1 and d['dist']['process_group'] is True and d['dist']['backend'] == 'nccl'
+    assert d['dist']['rccl_version'] and d['dist']['collectives'] == ['barrier', 'all_reduce(MAX)', 'all_gather', 'barrier']
+    assert len(d['frames_per_s_per_rank']) == 1 and d['frames_per_s_per_rank'][0] > 0
+    assert abs(d['value'] - 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    # without the environment the same command creates no process group
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', '128', '--frames', '3', '--steps', '1',
+                          '--warmup', '1', '--no-cpu-baseline', '--no-kernel-events'], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['dist'] == {'process_group': False, 'backend': None, 'rccl_version': None, 'collectives': []}
+
+
+def test_gather_clip_metrics_over_rccl_at_world_size_1(tmp_path):
+    """pnp_vcve_amd.dist: init_dist('pytorch', backend='nccl') + gather_clip_metrics on device tensors through a real
+    RCCL all_gather (world size 1), barrier, destroy -- in a child process."""
+    script = tmp_path / 'rccl_gather.py'
+    script.write_text(
+        "import sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from pnp_vcve_amd.dist import init_dist, gather_clip_metrics, get_dist_info, shard_indices\n"
+        "init_dist('pytorch', backend='nccl')\n"
+        "assert dist.get_backend() == 'nccl' and get_dist_info() == (0, 1)\n"
+        "idx = shard_indices(3, 0, 1)\n"
+        "local = [[30.0 + i, 0.9, 45.0] for i in idx]\n"
+        "calls = []\n"
+        "orig = dist.all_gather\n"
+        "def spy(parts, t, *a, **k):\n"
+        "    calls.append(t.device.type)\n"
+        "    return orig(parts, t, *a, **k)\n"
+        "dist.all_gather = spy\n"
+        "tab = gather_clip_metrics(local, 3, device=torch.device('cuda', 0))\n"
+        "assert calls == ['cuda'], calls\n"
+        "assert tab.shape == (3, 3) and tab.dtype == torch.float64 and not tab.is_cuda\n"
+        "assert tab[:, 0].tolist() == [30.0, 31.0, 32.0]\n"
+        "x = torch.ones(4, device='cuda'); dist.all_reduce(x, op=dist.ReduceOp.MAX); dist.barrier()\n"
+        "torch.cuda.synchronize(); dist.destroy_process_group(); print('RCCL_OK', torch.cuda.nccl.version())\n")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=_rank_env())
+    assert out.returncode == 0 and 'RCCL_OK' in out.stdout, out.stdout + out.stderr
+
+
+def test_dist_test_driver_one_rank_over_rccl():
+    """tools/dist_test.sh CONFIG none 1 with the config's own dist_params (backend='nccl'): the reference's launcher line,
+    RCCL process group, clip sharding, GPU forward, metric all_gather on device tensors; equals the non-distributed run."""
+    import re
+    common = ['--seed', '0', '--cfg-options', 'data.test.num_clips=3', 'data.test.num_input_frames=3',
+              'data.test.height=64', 'data.test.width=64']
+    cfgp = os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128_IPB.py')
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), cfgp, 'none'] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    env = dict(os.environ, PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    rc = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'dist_test.sh'), cfgp, 'none', '1'] + common,
+                        capture_output=True, text=True, timeout=600, env=env)
+    assert rc.returncode == 0, rc.stdout + rc.stderr
+    get = lambda s, k: re.search(rf'Eval-{k}: ([0-9.]+)', s).group(1)      # noqa: E731
+    assert 'backend nccl' in rc.stdout
+    assert get(one.stdout, 'PSNR') == get(rc.stdout, 'PSNR') and get(one.stdout, 'SSIM') == get(rc.stdout, 'SSIM')
+
+
+def test_bench_gpus_8_launches_eight_ranks():
+    """`python bench.py --gpus 8` -- the driver's scaling run -- on the one GPU of this box: eight rank processes from the
+    launcher (all on cuda:0; gloo for the tiny collectives because RCCL wants one GPU per rank), eight per-rank entries,
+    whole-job arithmetic, and a failing rank fails the launcher."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['PNP_DIST_BACKEND'] = 'gloo'
+    env['OMP_NUM_THREADS'] = '4'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--workload', '128', '--frames', '3',
+                          '--steps', '2', '--warmup', '1', '--no-kernel-events'], capture_output=True, text=True, timeout=1500,
+                         env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['parallelism'] == 'clip-sharded replicas x8' and d['scaling'] == 'weak'
+    assert len(d['frames_per_s_per_rank']) == 8 and len(set(d['psnr_per_rank'])) == 8      # rank r ran clip r
+    assert d['dist']['process_group'] is True and d['dist']['backend'] == 'gloo'
+    assert abs(d['value'] - 8 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    assert 'cpu_baseline' not in d and 'secondary' not in d
+    # rc propagation: an argument the ranks reject makes every rank exit non-zero -> the launcher does too
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', '128', '--frames', '0'],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith('{')]

@@ -293,6 +293,21 @@ def test_bench_gpus_n_spawns_ranks_and_propagates_their_failure():
     assert 'torch.distributed' in out.stderr or 'ChildFailedError' in out.stderr or 'rank' in out.stderr.lower()
 
 
+def test_bench_cpu_baseline_for_the_128_workload_states_cores_as_numbers():
+    """bench.py's CPU leg beside the 7x3x128x128 entries (north_star: "alongside the reference CPU path timed on the host
+    cores (core count stated)"): the oracle, median of 5, thread and logical-CPU counts as numeric fields."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    c = bench.cpu_baseline_128(2)           # 2 frames keep the CPU suite short; bench.py passes T = 7
+    assert c['kind'] == 'port' and c['unit'] == 'frames/s' and c['value'] > 0
+    assert isinstance(c['threads'], int) and c['cores'] == c['threads'] and 1 <= c['threads'] <= c['host_logical_cpus']
+    assert len(c['seconds_per_clip_runs']) == 5
+    assert abs(c['value'] - 2 / c['seconds_per_clip_median_of_5']) < 1e-9
+
+
 def _ssim_scipy(img1, img2, crop_border=0):
     """The reference formula (mmedit/core/evaluation/metrics.py:266-355) restated with scipy.ndimage, independently of
     pnp_vcve_amd.metrics: cv2.filter2D(img, -1, window) is a correlation with BORDER_REFLECT_101 (= scipy 'mirror'),

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert debug == set(_native.DEBUG_SIGNATURES), debug ^ set(_native.DEBUG_SIGNATURES)
     for name in declared | debug:
         assert hasattr(lib, name), name
-    assert lib.pnp_abi_version() == 2
+    assert lib.pnp_abi_version() == 3
 
 
 def test_no_undeclared_pnp_symbol_is_exported(lib):
@@ -113,7 +113,7 @@ def test_c_abi_error_codes_without_a_gpu(lib):
     for opt in range(6):                                                 # per-handle switches, default on
         assert lib.pnp_generator_get_option(h, opt) == 1
     assert lib.pnp_generator_set_option(h, 3, 0) == 0 and lib.pnp_generator_get_option(h, 3) == 0
-    assert lib.pnp_generator_set_option(h, 6, 0) == 1001 and lib.pnp_generator_get_option(h, 6) == -1
+    assert lib.pnp_generator_set_option(h, 6, 0) == 1001 and lib.pnp_generator_get_option(h, 6) == -1     # v2's fused-block switch is gone
     assert n32 % 4096 == 0 and ctx % 256 == 0
     lib.pnp_generator_destroy(h)
 

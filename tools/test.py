@@ -84,7 +84,9 @@ def main():
             print(f'Eval-{k}: {v}')
         print('{:.4f}/{:.4f}'.format(float(stats.get('PSNR', float('nan'))), float(stats.get('SSIM', float('nan')))))
         fps = [o['frames_per_s'] for o in outputs]
-        print(f'clips {len(outputs)}  world {world}  mean frames/s per clip {sum(fps) / len(fps):.2f}')
+        import torch.distributed as dist
+        backend = dist.get_backend() if dist.is_available() and dist.is_initialized() else 'none'
+        print(f'clips {len(outputs)}  world {world}  backend {backend}  mean frames/s per clip {sum(fps) / len(fps):.2f}')
         if args.out:
             torch.save(outputs, args.out)
 
