@@ -25,7 +25,7 @@ extern "C" {
 #define PNP_ERR_SIZE_ASSERT 1004 /* reference: AssertionError, h/w < 64 (iconvsr_ipb_par.py:51) */
 #define PNP_ERR_SIZE_VALUE 1005  /* reference: ValueError from flow_warp.py:27-29 (h/w % 4 != 0) */
 
-int pnp_abi_version(void); /* 3: the never-implemented fused-block option / query of v2 removed, PNP_OPT_* renumbered, PNP_OPT_SPARSE_EVAL */
+int pnp_abi_version(void); /* 3: the never-implemented fused-block option / query of v2 removed, PNP_OPT_* renumbered, PNP_OPT_SPARSE_EVAL, PNP_OPT_F16_MIRRORS */
 
 /* ------------------------------------------------------------------ generator (a1/a2)
  * Constructor kwargs of IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par
@@ -81,7 +81,11 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     sparse branch only when `self.sparse_val and not self.training` (sr_backbone_utils.py:308,322,
                                     basicvsr_net.py:511) and the dense par * conv1x1 formula otherwise (NOT bit-identical: the two
                                     differ on non-one-hot maps) */
-#define PNP_OPT_COUNT 6
+#define PNP_OPT_F16_MIRRORS 6    /* PNP_PREC_F16 (with PNP_OPT_F16_MAPS, deform 'vos'): every 64-channel map that is only read as an MFMA A
+                                    operand (the running map of a branch, the frame slots, the MV-aligned key frame) gets an fp16 copy
+                                    from its producer, and the input conv of a branch runs as ONE launch over those copies instead of
+                                    a chain of single-source launches through fp32 partial sums.  Bit-identical: same rounding points */
+#define PNP_OPT_COUNT 7
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 

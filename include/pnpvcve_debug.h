@@ -38,6 +38,21 @@ int pnp_dcn_nhwc_f32_ex(const float* x_dev, const float* om_dev, const float* fl
                         const float* w_packed_dev, const float* bias_dev, float* out_dev, int h, int w, void* trace_dev,
                         void* stream);
 
+/* The fp16-operand conv with explicit fp16 maps, as pnp_generator_forward chains its launches under PNP_OPT_F16_MAPS /
+ * PNP_OPT_F16_MIRRORS.  Bit s of src_f16_mask: srcs_dev[s] IS an fp16 NHWC64 map (else fp32); out_f16: out_dev is an fp16 map
+ * (single source, no residual); out16_dev (optional, only with an fp32 out_dev): an fp16 copy of the output written in the same
+ * pass; par_flags_dev: pnp_par_tile_flags_f32 output or NULL.  Several 64-channel sources run as ONE launch when all of them are
+ * fp16 maps (chain = 0), or -- fp32 sources only -- as the chain of single-source launches through fp32 partial sums (bit-identical). */
+int pnp_conv3x3_f16_maps(int nsrc, const void* const* srcs_dev, const int* src_channels, int src_f16_mask,
+                         const void* const* packed_w_f16_dev, const float* bias_dev, const float* gamma_dev,
+                         const void* packed_w1x1_f16_dev, const float* par_dev, const int* par_flags_dev,
+                         const float* residual_dev, int act, void* out_dev, int out_f16, void* out16_dev, int h, int w,
+                         int chain, void* trace_dev, void* stream);
+
+/* pnp_mv_warp_nhwc_f32 writing its result as an fp16 (h,w,c) map (saturating round-to-nearest-even of the fp32 value). */
+int pnp_mv_warp_nhwc_f16out(const float* feat_dev, const float* flow_x_dev, const float* flow_y_dev, void* out16_dev, int h,
+                            int w, int c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

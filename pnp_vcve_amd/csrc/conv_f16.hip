@@ -38,6 +38,7 @@
 // ds_read_b128 and the global image is copied to LDS verbatim.
 #include "conv_mfma.h"
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -73,7 +74,9 @@ struct F16Args {
     const float* residual;
     const float* lr;        // RGB head (out_mode 2 / 3): the low-quality frame, 3 NCHW planes
     long lr_plane;
-    void* out;              // fp32, or (OUT16, out_mode 0, no residual) fp16 NHWC64
+    void* out;              // fp32, or (OUT == 1, out_mode 0, no residual) fp16 NHWC64
+    void* out16;            // OUT == 2 (out_mode 0): an fp16 NHWC64 mirror of the fp32 output, written in the same pass
+    const int* par_flags;   // PAR: per 8x16 tile, bit j set <=> partition plane j is nonzero somewhere in the tile (nullptr: all)
     long w_ystride;         // halfs
     int bias_ystride;
     int res_pre;            // residual is added BEFORE the activation (partial sum of a K-split launch chain)
@@ -111,15 +114,43 @@ __device__ __forceinline__ h4 to_h4(f32x4 v) {
     return __builtin_convertvector(v, h4);
 }
 
-// SRC16 / OUT16: the source / the output is an fp16 NHWC64 map.  Used for the intermediate of a BAE block
+// fp16 mirror of a wave's 2 x 16 pixel output slice (OUT == 2).  In the fp32 epilogue lane (ec, ep) holds channels 4 ec .. 4 ec + 3
+// of pixel i (row i >> 2, column ep + 4 (i & 3)) for i = 0..7: 8 bytes of fp16 per pixel.  Lanes ec and ec ^ 1 swap one value per
+// pair of pixels (DPP quad_perm [1,0,3,2]) so that the even lane stores 16 B of pixel i and the odd lane 16 B of pixel i + 1:
+// four 16-byte stores per lane instead of eight 8-byte ones.
+__device__ __forceinline__ void store_mirror16(const h4 (&hv)[8], __amdgpu_buffer_rsrc_t r16, int row0, int tx0, int W, int ec, int ep) {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const bool odd = ec & 1;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const i32x2 send = __builtin_bit_cast(i32x2, odd ? hv[i] : hv[i + 1]);
+        i32x2 got;
+        got[0] = __builtin_amdgcn_mov_dpp(send[0], 0xB1, 0xF, 0xF, true);
+        got[1] = __builtin_amdgcn_mov_dpp(send[1], 0xB1, 0xF, 0xF, true);
+        const h4 recv = __builtin_bit_cast(h4, got);
+        const h4 lo = odd ? recv : hv[i], hi = odd ? hv[i + 1] : recv;
+        const h8 pk = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const int ii = i + (odd ? 1 : 0);
+        const int gx = tx0 + ep + 4 * (ii & 3);
+        const unsigned o = ((unsigned)(row0 + (ii >> 2)) * (unsigned)W + (unsigned)gx) * 128u + (unsigned)(ec >> 1) * 16u;
+        buf_store4(r16, gx < W ? o : OOB, __builtin_bit_cast(f32x4, pk));
+    }
+}
+
+// SRC16 / OUT == 1: the source / the output is an fp16 NHWC64 map.  Used for the intermediate of a BAE block
 // (front half writes it, back half reads it): it is consumed only as an MFMA A operand, i.e. it would be
 // rounded to fp16 by its reader anyway, so storing it rounded is bit-identical and halves its HBM traffic.
+// OUT == 2: the fp32 output AND an fp16 mirror of it (F16Args::out16).  The running feature map x of a branch is
+// needed in fp32 as the residual of the next block and in fp16 as the A operand of that block's front half (and of
+// conv_hr / the neighbouring frames' input convs): the producer writes both, so no consumer reads 256 B per halo
+// pixel only to round them to 128.
 // RGB: the conv_last head -- ONE 32-channel N tile (3 valid), output = 3 NCHW planes + the low-quality frame
 // (out_mode 2) or + its bilinear x4 upsampling (out_mode 3).
-template <bool PAR, bool LR4, bool SRC16, bool OUT16, bool RGB>
+template <bool PAR, bool LR4, bool SRC16, int OUT, bool RGB>
 __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
+    constexpr bool OUT16 = OUT == 1;
     static_assert(!(PAR && LR4), "the X region holds either the par branches or the RGB weights");
-    static_assert(!RGB || (!PAR && !LR4 && !OUT16), "the RGB head is a plain single-source conv");
+    static_assert(!RGB || (!PAR && !LR4 && OUT == 0), "the RGB head is a plain single-source conv");
     constexpr int NT = RGB ? 1 : 2;                // 32-channel N tiles per wave
     constexpr int AIT = SRC16 ? AIT16 : AIT32;
     constexpr int CPP = SRC16 ? 8 : 16;            // 16-byte slots per halo pixel
@@ -224,6 +255,11 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
     const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     const float k_pre = a.res_pre ? 1.f : 0.f, k_post = 1.f - k_pre;
 
+    // PAR: which 1x1 branches the tile whose operands were prefetched last needs.  Fetched as a plain lane value with the
+    // other tile operands (no wait here) and made wave-uniform only at the start of the matrix phase that consumes it.
+    int pfl_v = 0;
+    const __amdgpu_buffer_rsrc_t r_flags = make_rsrc((PAR && a.par_flags) ? (const void*)a.par_flags : a.src,
+                                                     (PAR && a.par_flags) ? (unsigned)ntiles * 4u : 0);
     float bco[NT], gco[NT], pv[3] = {0.f, 0.f, 0.f};
     f32x4 res4[EIT];
 #pragma unroll
@@ -283,6 +319,8 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj)
                 pv[jj] = buf_load1(r_par, (live & (gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+            // a plane that is zero over the whole tile contributes exact zeros: its 4 k-steps are skipped (value-identical)
+            pfl_v = __builtin_bit_cast(int, buf_load1(r_flags, live ? (unsigned)((y0 / TH) * tiles_x + x0 / TW) * 4u : OOB));
         }
     };
     // output addressing of the three row-wise modes as one affine form (uniform scalars, no per-store switch)
@@ -299,6 +337,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
             (int)(a.out_mode == 1 ? (yimg >> 1) * o_row + (yimg & 1) * o_pix : (a.out_mode == 4 ? 256u * (unsigned)yimg : 0u)));
         r_out = RGB ? make_rsrc(a.out, (unsigned)H * (unsigned)W * 12u) : make_rsrc(a.out, (unsigned)(o_mul * H) * o_row);
     }
+    const __amdgpu_buffer_rsrc_t r_out16 = make_rsrc(OUT == 2 ? a.out16 : a.out, OUT == 2 ? map_bytes / 2 : 0);
 
     int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     int done = 0;                       // tiles this group has finished
@@ -368,8 +407,12 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-                constexpr int NS = 36 + (LR4 ? 3 : 0) + (PAR ? 12 : 0);
+                constexpr int NS = 36 + (LR4 ? 3 : 0);   // static k-steps; PAR adds 4 per partition branch the tile needs
                 constexpr int DEPTH = LR4 ? 3 : 4;       // 3 * DEPTH <= 15 (lgkmcnt); the RGB variant is out of registers at 4
+                static_assert(!PAR || (DEPTH == 4 && NS % DEPTH == 0), "branch step q lives in fetch slot q");
+                constexpr int MID = PAR ? 21 : NS / 2;   // where the phase's middle barrier is passed
+                // wave-uniform list of the branches to run (exact zeros otherwise: value-identical)
+                const int pflags = (PAR && a.par_flags) ? (__builtin_amdgcn_readfirstlane(pfl_v) & 7) : 7;
                 h8 fa[DEPTH], fb0[DEPTH], fb1[DEPTH];
                 auto fetch = [&](int k) {       // k is a compile-time constant after unrolling
                     const int sl = k % DEPTH;
@@ -378,19 +421,21 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                         fa[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
                         fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (k * NT + 0) * UNIT);
                         if (NT == 2) fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (k * NT + 1) * UNIT);
-                    } else if (LR4) {
+                    } else {
                         const int sk = k - 36;
                         const h4 lo = *reinterpret_cast<const h4*>(sL + l_off(sk, 0));
                         const h4 hi = *reinterpret_cast<const h4*>(sL + l_off(sk, 1));
                         fa[sl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                         fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 0) * UNIT);
                         fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (sk * 2 + 1) * UNIT);
-                    } else {
-                        const int q = k - 36;
-                        fa[sl] = *reinterpret_cast<const h8*>(a_lane + RSB + PSB + 32 * (q & 3));
-                        fb0[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 0) * UNIT);
-                        fb1[sl] = *reinterpret_cast<const h8*>(x_lane + (q * 2 + 1) * UNIT);
                     }
+                };
+                // k-step q (compile time) of partition branch br (wave-uniform run-time value) -> fetch slot q
+                auto fetch_par = [&](int br, int q) {
+                    const char* xb = x_lane + br * (8 * UNIT);
+                    fa[q] = *reinterpret_cast<const h8*>(a_lane + RSB + PSB + 32 * q);
+                    fb0[q] = *reinterpret_cast<const h8*>(xb + (q * 2 + 0) * UNIT);
+                    fb1[q] = *reinterpret_cast<const h8*>(xb + (q * 2 + 1) * UNIT);
                 };
                 auto bias_gamma = [&]() {
 #pragma unroll
@@ -398,23 +443,41 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
                 };
+                const int br0 = pflags ? __builtin_ctz(pflags) : -1;       // first branch to run
 #pragma unroll
                 for (int k = 0; k < DEPTH; ++k) fetch(k);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     const int sl = k % DEPTH;
-                    h8 av = fa[sl];
+                    const h8 av = fa[sl];
                     const h8 b0 = fb0[sl], b1 = fb1[sl];
-                    if (PAR && k == 36) bias_gamma();       // (conv + bias) * gamma BEFORE the 1x1 partition branches
-                    if (PAR && k >= 36) av *= (_Float16)pv[(k - 36) >> 2];
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
                     if (NT == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[NT - 1], 0, 0, 0);
                     if (k + DEPTH < NS) fetch(k + DEPTH);
-                    if (k == NS / 2) __builtin_amdgcn_s_barrier();      // the phase's middle barrier (no LDS hand-off here)
+                    else if (PAR && br0 >= 0) fetch_par(br0, k + DEPTH - NS);
+                    if (k == MID) __builtin_amdgcn_s_barrier();         // the phase's middle barrier (no LDS hand-off here)
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (!PAR) bias_gamma();
+                bias_gamma();                  // (conv + bias) * gamma BEFORE the 1x1 partition branches
+                if (PAR) {
+#pragma unroll
+                    for (int br = 0; br < 3; ++br) {
+                        if (!((pflags >> br) & 1)) continue;
+                        const int rest = pflags >> (br + 1);
+                        const int nxt = rest ? br + 1 + __builtin_ctz(rest) : -1;      // the branch after this one, if any
+                        const _Float16 pj = (_Float16)pv[br];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const h8 av = fa[q] * pj;
+                            const h8 b0 = fb0[q], b1 = fb1[q];
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+                            acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[NT - 1], 0, 0, 0);
+                            if (nxt >= 0) fetch_par(nxt, q);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
                 acc_live = true;
                 if (a.dbg) dbg_k += __builtin_amdgcn_s_memtime() - dbg_a;
             } else {
@@ -481,6 +544,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                 }
             } else {
                 f32x4 rows[EIT];
+                h4 hv[EIT];
 #pragma unroll
                 for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];      // all reads in flight together
                 asm volatile("" ::: "memory");
@@ -492,7 +556,9 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                     const int gx = tx0 + ep + 4 * (i & 3);
                     const unsigned o = (unsigned)(ty0 + 2 * wave + (i >> 2)) * o_sy + (unsigned)gx * o_sx + o_c0 + (unsigned)ec * 16u;
                     buf_store4(r_out, gx < W ? o : OOB, v);
+                    if (OUT == 2) hv[i] = to_h4(v);
                 }
+                if (OUT == 2) store_mirror16(hv, r_out16, ty0 + 2 * wave, tx0, W, ec, ep);
             }
             acc_live = false;
             ++done;
@@ -560,8 +626,9 @@ static_assert(s_lds_bytes(1) >= 4 * 8192 && s_lds_bytes(2) >= 8 * 8192, "the epi
 
 // G = groups of 4 waves per block, each group one tile (adjacent tiles), all sharing the block's weight ring: G = 2 halves the
 // weight bytes a tile pulls from L2 (two blocks per CU); G = 1 keeps three blocks per CU for the smallest frames.
-template <bool PAR, bool SRC16, bool OUT16, int G>
+template <bool PAR, bool SRC16, int OUT, int G>
 __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_kernel(const F16Args a) {
+    constexpr bool OUT16 = OUT == 1;
     constexpr int AIT = SRC16 ? AIT16 : AIT32;
     constexpr int CPP = SRC16 ? 8 : 16;
     constexpr int NC = 9 + (PAR ? 3 : 0);                  // weight chunks
@@ -591,6 +658,11 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
     const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : a.src, a.residual ? map_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, (unsigned)H * (unsigned)W * (OUT16 ? 128u : 256u));
+    const __amdgpu_buffer_rsrc_t r_out16 = make_rsrc(OUT == 2 ? a.out16 : a.out, OUT == 2 ? map_bytes / 2 : 0);
+    // PAR: which 1x1 branches this tile needs (fetched now, made wave-uniform when the first branch chunk is scheduled)
+    const __amdgpu_buffer_rsrc_t r_flags = make_rsrc((PAR && a.par_flags) ? (const void*)a.par_flags : a.src,
+                                                     (PAR && a.par_flags) ? (unsigned)ntiles * 4u : 0);
+    const int pfl_v = PAR ? __builtin_bit_cast(int, buf_load1(r_flags, live ? (unsigned)tile * 4u : OOB)) : 0;
 
     // ---- requests: halo, the first weight chunks, residual rows / partition values
     f32x4 areg[AIT];
@@ -672,43 +744,57 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // PAR: chunks 9.. are the partition branches the tile needs, in plane order (a plane that is zero over the whole tile adds
+    // exact zeros: skipped, value-identical).  ncr = chunks to run; bsel(j) = plane of the j-th branch chunk.
+    int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
+    auto bsel = [&](int j) { return j == 0 ? bs0 : (j == 1 ? bs1 : bs2); };
+    auto bias_gamma = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+    };
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (c + 3 < NC) {
-            const f32x4* g = chunk_ptr(c + 3);
+        if (PAR && c == 6 && a.par_flags) {          // first use of the flags: chunk 9 is requested below
+            const int f0 = __builtin_amdgcn_readfirstlane(pfl_v) & 7;
+            const int f1 = f0 & (f0 - 1), f2 = f1 & (f1 - 1);
+            ncr = 9 + __builtin_popcount(f0);
+            bs0 = f0 ? __builtin_ctz(f0) : 0;
+            bs1 = f1 ? __builtin_ctz(f1) : 0;
+            bs2 = f2 ? __builtin_ctz(f2) : 0;
+        }
+        if (PAR && c >= 9 && c >= ncr) break;
+        if (c + 3 < NC && (!PAR || c + 3 < ncr)) {
+            const f32x4* g = (PAR && c + 3 >= 9) ? wgp + bsel(c + 3 - 9) * 512 : chunk_ptr(c + 3);
 #pragma unroll
             for (int i = 0; i < WPT; ++i) wreg[(c + 1) & 1][i] = g[tt + NT_ * i];
         }
         const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
         const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
-        if (PAR && c == 9) {                       // (conv + bias) * gamma BEFORE the 1x1 partition branches
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
+        _Float16 pj = (_Float16)1.f;
+        if (PAR && c >= 9) {
+            if (c == 9) bias_gamma();                  // (conv + bias) * gamma BEFORE the 1x1 partition branches
+            const int bi = bsel(c - 9);
+            pj = (_Float16)(bi == 0 ? pv[0] : (bi == 1 ? pv[1] : pv[2]));
         }
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) {
             h8 av = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
             const h8 b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
             const h8 b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
-            if (PAR && c >= 9) av *= (_Float16)pv[c - 9];
+            if (PAR && c >= 9) av *= pj;
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
         }
-        if (c + 2 < NC) {
+        if (c + 2 < NC && (!PAR || c + 2 < ncr)) {
             char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1: every wave left it at the previous barrier
 #pragma unroll
             for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (tt + NT_ * i) * 16) = wreg[c & 1][i];
         }
         lds_barrier();
     }
-    if (!PAR) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
-    }
+    if (!PAR || ncr == 9) bias_gamma();
 
     if (a.dbg) d_t2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue (the persistent kernel's, one tile): transpose through the dead LDS, activation, residual, whole pixel
@@ -742,6 +828,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
         }
     } else {
         f32x4 rows[EIT];
+        h4 hv[EIT];
 #pragma unroll
         for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
         asm volatile("" ::: "memory");
@@ -753,12 +840,248 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
             const int gx = tx0 + ep + 4 * (i & 3);
             const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 2)) * (unsigned)W + (unsigned)gx) * 256u + (unsigned)ec * 16u;
             buf_store4(r_out, (live & (gx < W)) ? o : OOB, v);
+            if (OUT == 2) hv[i] = to_h4(v);
         }
+        if (OUT == 2) store_mirror16(hv, r_out16, ty0 + 2 * wave, tx0, live ? W : 0, ec, ep);
     }
     if (a.dbg && t == 0) {      // diagnostic timeline (pnp_conv3x3_f16_ex): start, prologue end, K loop end, end (shader clock)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         d_t3 = __builtin_amdgcn_s_memtime();
         unsigned long long* d = a.dbg + ((size_t)blockIdx.x * G + grp) * 16;
+        d[0] = d_t0;
+        d[1] = d_t1;
+        d[2] = d_t2;
+        d[3] = d_t3;
+        d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+        d[7] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The input conv of a branch (basicvsr_net.py:484,515 over the concat of iconvsr_ipb_par.py:90,125) in ONE launch: up to three
+// 64-channel sources, all read through their fp16 mirrors, + the RGB frame.  The resident-weight kernel above runs such a conv
+// as a chain of single-source launches whose fp32 partial sums go through HBM (512 B per pixel and link); here a block is one
+// 8x16 tile (the small-frame kernel's structure: 3 blocks per CU, weight chunks streamed from L2 through the 3-slot ring) and
+// walks the sources one after another: source s+1's halo is requested while source s is contracted and replaces it in the A
+// tile between two chunks.  BIT-IDENTICAL to the chain: every source is accumulated from zero in its own MFMA chain (k order:
+// 9 taps x 4 k-steps, the RGB frame's 3 k-steps behind source 0) and folded as the chain's epilogues do --
+// sum = (acc_0 + bias), then sum = acc_s + sum -- activation last.
+// ---------------------------------------------------------------------------------------------------------------
+struct F16MultiArgs {
+    const void* src[3];       // fp16 NHWC64 maps
+    const _Float16* w[3];     // 72 units each
+    const float* lr4;         // NHWC4 fp32 (RGB0) or nullptr
+    const _Float16* wlr;      // 8 units
+    const float* bias;
+    float* out;               // fp32 NHWC64
+    void* out16;              // OUT == 2: fp16 mirror of out
+    int H, W, act;
+    unsigned long long* dbg;
+};
+constexpr int M_LOFF = PW * PSB;            // RGB halo row (18 px x 8 B = 144 B) in the padding behind an A-tile row (2816 - 2592 = 224 B)
+static_assert(M_LOFF + PW * 8 <= RSB, "the RGB halo row fits behind the A-tile row");
+
+template <int NW, bool LR4, int OUT>
+__global__ __launch_bounds__(256, 3) void conv3x3_f16_multi_kernel(const F16MultiArgs a) {
+    static_assert(OUT == 0 || OUT == 2, "fp32 output, optionally with its fp16 mirror");
+    constexpr int AIT = AIT16, CPP = 8;
+    constexpr int NC = 9 * NW + (LR4 ? 1 : 0);             // weight chunks: source 0's taps, [RGB], source 1's taps, ...
+    constexpr int WPT = 2;                                 // float4 of a weight chunk per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + TW - 1) / TW;
+    int tile;
+    {   // XCD-aware remap: each XCD walks a contiguous band of tiles (halo rows meet in its L2)
+        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
+        const int q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    char* const sA = smem;
+    char* const sR = smem + A_BYTES;
+    unsigned long long d_t0 = 0, d_t1 = 0, d_t2 = 0, d_t3 = 0;
+    if (a.dbg) d_t0 = __builtin_amdgcn_s_memtime();
+
+    const unsigned map16 = (unsigned)H * (unsigned)W * 128u;
+    __amdgpu_buffer_rsrc_t r_src[NW];
+#pragma unroll
+    for (int s = 0; s < NW; ++s) r_src[s] = make_rsrc(a.src[s], map16);
+    const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(LR4 ? (const void*)a.lr4 : a.src[0], LR4 ? map16 / 8 : 0);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, map16 * 2);
+    const __amdgpu_buffer_rsrc_t r_out16 = make_rsrc(OUT == 2 ? a.out16 : (void*)a.out, OUT == 2 ? map16 : 0);
+
+    // ---- halo staging: fp16 source -> A tile verbatim (16-byte slot i = t + 256 k is channel group i % 8 of halo pixel i / 8)
+    f32x4 areg[AIT];
+    const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * 128u;
+    auto halo_load = [&](int s) {
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int i = t + 256 * k;
+            const int pix = i / CPP, cs = i % CPP;
+            const int ry = pix / PW, rx = pix - ry * PW;
+            const bool ok = (pix < NPIX) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);  // rows outside the image leave the descriptor by themselves
+            areg[k] = buf_load4(r_src[s], ok ? hbase + (unsigned)(ry * W + rx) * 128u + (unsigned)cs * 16u : OOB);
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int i = t + 256 * k;
+            const int pix = i / CPP, cs = i % CPP;
+            const int ry = pix / PW, rx = pix - ry * PW;
+            if (pix < NPIX) *reinterpret_cast<f32x4*>(sA + ry * RSB + rx * PSB + cs * 16) = areg[k];
+        }
+    };
+    halo_load(0);
+    f32x4 lreg = {0.f, 0.f, 0.f, 0.f};
+    if (LR4) {
+        const int ry = t / PW, rx = t - ry * PW;
+        const bool ok = (t < NPIX) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);
+        lreg = buf_load4(r_lr, ok ? (unsigned)((ty0 - 1 + ry) * W + (tx0 - 1 + rx)) * 16u : OOB);
+    }
+    auto chunk_ptr = [&](int c) -> const f32x4* {          // 512 float4 per chunk; c is a compile-time constant after unrolling
+        if (c < 9) return reinterpret_cast<const f32x4*>(a.w[0]) + c * 512;
+        if (LR4 && c == 9) return reinterpret_cast<const f32x4*>(a.wlr);
+        const int cc = c - (LR4 ? 10 : 9);
+        return reinterpret_cast<const f32x4*>(a.w[(1 + cc / 9) < NW ? 1 + cc / 9 : NW - 1]) + (cc % 9) * 512;
+    };
+    f32x4 wreg[2][WPT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const f32x4* g = chunk_ptr(c);
+        f32x4 v[WPT];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) v[i] = g[t + 256 * i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * S_CHUNK + (t + 256 * i) * 16) = v[i];
+    }
+    {
+        const f32x4* g = chunk_ptr(2);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wreg[0][i] = g[t + 256 * i];
+    }
+    constexpr int EIT = 8;
+    const int ec = lane & 15, ep = lane >> 4, n0 = lane & 31;
+    const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    float bco[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bco[j] = a.bias ? a.bias[j * 32 + n0] : 0.f;
+    halo_store();
+    if (LR4 && t < NPIX) {
+        const int ry = t / PW, rx = t - ry * PW;
+        *reinterpret_cast<h4*>(sA + ry * RSB + M_LOFF + rx * 8) = to_h4(lreg);
+    }
+    lds_barrier();
+    if (a.dbg) d_t1 = __builtin_amdgcn_s_memtime();
+
+    const char* a_lane = sA + (2 * wave + my) * RSB + mx * PSB + 16 * h;
+    // RGB source: k = 16 s + 8 h + j  ->  tap 4 s + 2 h + (j >> 2), channel j & 3; taps beyond 8 carry zero weights and re-read
+    // tap 8 (finite values)
+    const char* l_lane = sA + (2 * wave + my) * RSB + M_LOFF + mx * 8;
+    auto l_off = [&](int sk, int u) -> int {
+        auto tap_off = [](int tap) {
+            tap = tap > 8 ? 8 : tap;
+            return (tap / 3) * RSB + (tap % 3) * 8;
+        };
+        return h ? tap_off(4 * sk + 2 + u) : tap_off(4 * sk + u);
+    };
+    f32x16 acc[2], sum[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[j][r] = 0.f;
+            sum[j][r] = 0.f;
+        }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const bool rgb = LR4 && c == 9;
+        const int cw = (LR4 && c > 9) ? c - 1 : c;             // index among the wide chunks
+        const int s = rgb ? 0 : cw / 9, tap = cw % 9;
+        if (!rgb && tap == 0 && s + 1 < NW) halo_load(s + 1);   // the next source's halo travels while this one is contracted
+        if (c + 3 < NC) {
+            const f32x4* g = chunk_ptr(c + 3);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) wreg[(c + 1) & 1][i] = g[t + 256 * i];
+        }
+        const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
+        if (!rgb) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk) {
+                const h8 av = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
+                const h8 b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
+                const h8 b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int sk = 0; sk < 3; ++sk) {
+                const h4 lo = *reinterpret_cast<const h4*>(l_lane + l_off(sk, 0));
+                const h4 hi = *reinterpret_cast<const h4*>(l_lane + l_off(sk, 1));
+                const h8 av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const h8 b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
+                const h8 b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
+            }
+        }
+        if (c + 2 < NC) {
+            char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1: every wave left it at the previous barrier
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[c & 1][i];
+        }
+        // end of a source's own MFMA chain (source 0's includes the RGB frame): fold it as the launch chain's epilogues do
+        const bool src_done = rgb || (tap == 8 && !(LR4 && s == 0));
+        if (src_done) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sum[j][r] = (s == 0) ? (acc[j][r] + bco[j]) * 1.f : acc[j][r] + sum[j][r];
+                    acc[j][r] = 0.f;
+                }
+        }
+        lds_barrier();
+        if (!rgb && tap == 8 && s + 1 < NW) {                  // every wave has left source s's A tile: bring in source s + 1
+            halo_store();
+            lds_barrier();
+        }
+    }
+
+    if (a.dbg) d_t2 = __builtin_amdgcn_s_memtime();
+    // ---- epilogue: transpose through the dead LDS, activation, whole pixel rows to HBM (+ the fp16 mirror)
+    float* sT = reinterpret_cast<float*>(smem + wave * 8192);
+    const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = sum[j][r];
+    asm volatile("" ::: "memory");
+    {
+        f32x4 rows[EIT];
+        h4 hv[EIT];
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) {
+            f32x4 v = rows[i];
+            v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+            const int gx = tx0 + ep + 4 * (i & 3);
+            const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 2)) * (unsigned)W + (unsigned)gx) * 256u + (unsigned)ec * 16u;
+            buf_store4(r_out, gx < W ? o : OOB, v);
+            if (OUT == 2) hv[i] = to_h4(v);
+        }
+        if (OUT == 2) store_mirror16(hv, r_out16, ty0 + 2 * wave, tx0, W, ec, ep);
+    }
+    if (a.dbg && t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        d_t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 16;
         d[0] = d_t0;
         d[1] = d_t1;
         d[2] = d_t2;
@@ -796,9 +1119,9 @@ int f16_grid(int grid_y) {
     return g < 8 ? 8 : g;
 }
 
-template <bool PAR, bool LR4, bool SRC16, bool OUT16, bool RGB = false>
+template <bool PAR, bool LR4, bool SRC16, int OUT, bool RGB = false>
 int launch_one(const F16Args& fa, int grid_y, hipStream_t stream) {
-    auto kern = conv3x3_f16_kernel<PAR, LR4, SRC16, OUT16, RGB>;
+    auto kern = conv3x3_f16_kernel<PAR, LR4, SRC16, OUT, RGB>;
     static PnpPerDevice once;
     const hipError_t attr_err = once.run([&](int, int&) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -833,9 +1156,14 @@ bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
     if (nwide == 0) return false;                        // an RGB-only input conv stays on the fp32 kernel
     if (nwide > 1 && (a.residual || a.gamma || grid_y != 1 || a.out_mode != 0)) return false;
     if (has_par && (a.nsrc != 1 || !a.wpar_h || !a.par || grid_y != 1)) return false;
-    if ((a.src_f16 || a.out_f16) && (a.nsrc != 1 || grid_y != 1 || a.out_mode != 0)) return false;
-    if (a.src_f16 && a.out_f16) return false;
-    if (a.out_f16 && a.residual) return false;
+    // fp16 maps (a source read through its fp16 mirror, an fp16 output, an fp16 mirror of the fp32 output)
+    if ((a.src_f16 || a.out_f16 || a.out16) && (grid_y != 1 || a.out_mode != 0)) return false;
+    if (a.out_f16 && (a.residual || a.out16 || a.nsrc != 1)) return false;
+    if (a.src_f16 && a.nsrc != 1) {          // several sources: the one-launch kernel, which reads ALL wide sources as fp16
+        for (int s = 0; s < a.nsrc; ++s)
+            if (a.src_c[s] == 64 && !((a.src_f16 >> s) & 1)) return false;
+        if (a.residual || a.gamma || has_par) return false;
+    }
     return true;
 }
 
@@ -843,12 +1171,31 @@ bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
 static bool f16_small_eligible(const ConvArgs& a, int grid_y) {
     if (a.no_small16) return false;
     const long tiles = (long)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-    return tiles < 1024 && grid_y == 1 && a.nsrc == 1 && a.src_c[0] == 64 && a.out_mode == 0 && !(a.src_f16 && a.out_f16);
+    return tiles < 1024 && grid_y == 1 && a.nsrc == 1 && a.src_c[0] == 64 && a.out_mode == 0;
 }
 
-template <bool PAR, bool SRC16, bool OUT16, int G>
+template <int NW, bool LR4, int OUT>
+static int launch_multi_t(const F16MultiArgs& fa, hipStream_t stream) {
+    auto kern = conv3x3_f16_multi_kernel<NW, LR4, OUT>;
+    static PnpPerDevice once;
+    const hipError_t attr_err = once.run([&](int, int&) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, s_lds_bytes(1));
+    });
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const int tiles = ((fa.W + TW - 1) / TW) * ((fa.H + TH - 1) / TH);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), s_lds_bytes(1), stream, fa);
+    return (int)hipGetLastError();
+}
+
+template <int NW>
+static int launch_multi(const F16MultiArgs& fa, hipStream_t stream) {
+    if (fa.lr4) return fa.out16 ? launch_multi_t<NW, true, 2>(fa, stream) : launch_multi_t<NW, true, 0>(fa, stream);
+    return fa.out16 ? launch_multi_t<NW, false, 2>(fa, stream) : launch_multi_t<NW, false, 0>(fa, stream);
+}
+
+template <bool PAR, bool SRC16, int OUT, int G>
 static int launch_small_g(const F16Args& fa, hipStream_t stream) {
-    auto kern = conv3x3_f16_small_kernel<PAR, SRC16, OUT16, G>;
+    auto kern = conv3x3_f16_small_kernel<PAR, SRC16, OUT, G>;
     static PnpPerDevice once;
     const hipError_t attr_err = once.run([&](int, int&) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, s_lds_bytes(G));
@@ -859,11 +1206,22 @@ static int launch_small_g(const F16Args& fa, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-template <bool PAR, bool SRC16, bool OUT16>
+template <bool PAR, bool SRC16, int OUT>
 static int launch_small(const F16Args& fa, hipStream_t stream) {
     // two tiles per block (shared weight ring, half the weight bytes per tile) once the frame has a tile pair per CU slot
     const int tiles = ((fa.W + TW - 1) / TW) * ((fa.H + TH - 1) / TH);
-    return tiles >= S_PAIR_TILES ? launch_small_g<PAR, SRC16, OUT16, 2>(fa, stream) : launch_small_g<PAR, SRC16, OUT16, 1>(fa, stream);
+    return tiles >= S_PAIR_TILES ? launch_small_g<PAR, SRC16, OUT, 2>(fa, stream) : launch_small_g<PAR, SRC16, OUT, 1>(fa, stream);
+}
+
+// run-time (par, fp16 source, output mode) -> compile-time template arguments
+template <class F>
+static int pick3(bool par, bool s16, int om, F f) {
+    auto l2 = [&](auto P, auto S) {
+        return om == 1 ? f(P, S, std::integral_constant<int, 1>{})
+                       : om == 2 ? f(P, S, std::integral_constant<int, 2>{}) : f(P, S, std::integral_constant<int, 0>{});
+    };
+    auto l1 = [&](auto P) { return s16 ? l2(P, std::true_type{}) : l2(P, std::false_type{}); };
+    return par ? l1(std::true_type{}) : l1(std::false_type{});
 }
 
 // A conv over several 64-channel sources runs as a chain of single-source launches that accumulate through
@@ -874,6 +1232,28 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         if (a.src_c[s] == 4) lr_idx = s;
         else wide[nwide++] = s;
     }
+    // the input conv of a branch with every wide source available as an fp16 mirror: ONE launch (bit-identical to the chain)
+    bool all16 = nwide >= 1 && nwide <= 3;
+    for (int k = 0; k < nwide; ++k) all16 = all16 && ((a.src_f16 >> wide[k]) & 1);
+    if (all16 && (nwide >= 2 || lr_idx >= 0) && !a.no_multi16 && a.out_mode == 0 && grid_y == 1 && !a.wpar_h && !a.gamma &&
+        !a.residual && !a.out_f16) {
+        F16MultiArgs f;
+        for (int k = 0; k < 3; ++k) {
+            f.src[k] = k < nwide ? a.src[wide[k]] : nullptr;
+            f.w[k] = k < nwide ? reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]) : nullptr;
+        }
+        f.lr4 = lr_idx >= 0 ? a.src[lr_idx] : nullptr;
+        f.wlr = lr_idx >= 0 ? reinterpret_cast<const _Float16*>(a.wsrc_h[lr_idx]) : nullptr;
+        f.bias = a.bias;
+        f.out = a.out;
+        f.out16 = a.out16;
+        f.H = a.H;
+        f.W = a.W;
+        f.act = a.act;
+        f.dbg = a.dbg;
+        return nwide == 1 ? launch_multi<1>(f, stream) : nwide == 2 ? launch_multi<2>(f, stream) : launch_multi<3>(f, stream);
+    }
+    if (nwide > 1 && a.src_f16) return PNP_ERR_UNSUPPORTED;      // the launch chain reads fp32 sources
     for (int k = 0; k < nwide; ++k) {
         const bool first = k == 0, last = k == nwide - 1;
         F16Args f;
@@ -899,26 +1279,28 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         f.out_mode = a.out_mode;
         f.out_cstride = a.out_cstride;
         f.dbg = a.dbg;
-        const bool s16 = a.src_f16 != 0, o16 = a.out_f16 != 0;      // single-source launches only (conv_f16_eligible)
+        f.out16 = last ? a.out16 : nullptr;
+        f.par_flags = a.par_flags;
+        // fp16 maps: single-source launches only (conv_f16_eligible).  om: 0 fp32 out, 1 fp16 out, 2 fp32 out + fp16 mirror
+        const bool s16 = (a.src_f16 >> wide[k]) & 1;
+        const int om = a.out_f16 ? 1 : (f.out16 ? 2 : 0);
         int rc;
-        if (f16_small_eligible(a, grid_y) && !(o16 && f.residual)) {
-            if (f.wpar) rc = s16 ? launch_small<true, true, false>(f, stream)
-                              : o16 ? launch_small<true, false, true>(f, stream) : launch_small<true, false, false>(f, stream);
-            else rc = s16 ? launch_small<false, true, false>(f, stream)
-                      : o16 ? launch_small<false, false, true>(f, stream) : launch_small<false, false, false>(f, stream);
+        const bool hp = f.wpar != nullptr;
+        if (f16_small_eligible(a, grid_y) && !(om == 1 && f.residual)) {
+            rc = pick3(hp, s16, om, [&](auto P, auto S, auto O) {
+                return launch_small<decltype(P)::value, decltype(S)::value, decltype(O)::value>(f, stream);
+            });
             if (rc) return rc;
             continue;
         }
         if (a.out_mode == 2 || a.out_mode == 3)
-            rc = s16 ? launch_one<false, false, true, false, true>(f, grid_y, stream)
-                     : launch_one<false, false, false, false, true>(f, grid_y, stream);
-        else if (f.lr4) rc = launch_one<false, true, false, false>(f, grid_y, stream);
-        else if (f.wpar) rc = s16 ? launch_one<true, false, true, false>(f, grid_y, stream)
-                              : o16 ? launch_one<true, false, false, true>(f, grid_y, stream)
-                                    : launch_one<true, false, false, false>(f, grid_y, stream);
-        else rc = s16 ? launch_one<false, false, true, false>(f, grid_y, stream)
-                  : o16 ? launch_one<false, false, false, true>(f, grid_y, stream)
-                        : launch_one<false, false, false, false>(f, grid_y, stream);
+            rc = s16 ? launch_one<false, false, true, 0, true>(f, grid_y, stream)
+                     : launch_one<false, false, false, 0, true>(f, grid_y, stream);
+        else if (f.lr4) rc = om == 2 ? launch_one<false, true, false, 2>(f, grid_y, stream) : launch_one<false, true, false, 0>(f, grid_y, stream);
+        else
+            rc = pick3(hp, s16, om, [&](auto P, auto S, auto O) {
+                return launch_one<decltype(P)::value, false, decltype(S)::value, decltype(O)::value>(f, grid_y, stream);
+            });
         if (rc) return rc;
     }
     return PNP_OK;

@@ -13,7 +13,10 @@ struct ConvArgs {
     const void* wsrc_h[4];  // fp16 twins of wsrc / wpar (conv_f16.hip), read only when prec == 1
     const void* wpar_h;
     int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
-    int src_f16, out_f16;   // prec 1, single source, out_mode 0: src[0] / out is an fp16 NHWC64 map
+    int src_f16, out_f16;   // prec 1, out_mode 0: bit s of src_f16: src[s] IS an fp16 NHWC64 map (the mirror its producer
+                            // wrote); out_f16: out is one (single source, no residual)
+    void* out16;            // prec 1, out_mode 0, !out_f16: additionally write an fp16 NHWC64 mirror of the fp32 output
+    int no_multi16;         // 1: several fp16 sources are refused instead of running the one-launch input-conv kernel
     const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
     const int* par_flags;   // optional, one int per 8x16 tile (row-major): bit j set <=> plane j has a nonzero value in
                             // the tile (launch_par_tile_flags).  The persistent kernel skips the 1x1 branches whose

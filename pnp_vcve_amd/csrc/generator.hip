@@ -66,7 +66,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
-    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1};   // pnp_generator_set_option (defaults: everything on)
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1};   // pnp_generator_set_option (defaults: everything on)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -339,11 +339,20 @@ struct ConvCall {
     }
     // fp16 path: 1 = the output is an fp16 map, 2 = the (single) source is one
     ConvCall& f16_map(int io16) { io16_ = io16; return *this; }
+    // fp16 path with mirrors (PNP_OPT_F16_MIRRORS): the fp16 copy its producer wrote of the source added last (read INSTEAD of
+    // the fp32 map), and an fp16 copy to write of this conv's fp32 output.  nullptr = none.
+    const void* src16_[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* out16_ = nullptr;
+    ConvCall& mirror16(const void* m) { src16_[nsrc - 1] = m; return *this; }
+    ConvCall& also16(void* m) { out16_ = m; return *this; }
 };
 
 struct Workspace {
     float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om, *parbin;
     float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 only
+    // PNP_PREC_F16 + mirrors: fp16 NHWC64 copies of the running map of a branch (x16) and of every frame's slot (slots16);
+    // the MV-aligned key frame is then fp16 only and lives in kw
+    uint16_t *x16, *slots16;
     int* parflags;    // per frame, per 8x16 tile: which partition planes are nonzero there (ConvArgs::par_flags)
     int64_t bytes;
 };
@@ -391,6 +400,9 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     W.mixw = take((int64_t)t * g->ndyn * IMG_WIDE);
     W.mixb = take((int64_t)t * g->ndyn * 64);
     W.mixh = g->prec == PNP_PREC_F16 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
+    const bool mir = g->prec == PNP_PREC_F16 && g->cfg.deform == 0;      // sized whether or not PNP_OPT_F16_MIRRORS is on
+    W.x16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32)) : nullptr;
+    W.slots16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32 * t)) : nullptr;
     W.parflags = reinterpret_cast<int*>(take((int64_t)t * ((w + 15) / 16) * ((h + 7) / 8)));
     W.bytes = off;
     return W;
@@ -571,6 +583,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixh) + (p - W.mixw);
         return nullptr;
     };
+    const bool f16_maps = g->prec == PNP_PREC_F16 && g->opt[PNP_OPT_F16_MAPS];
+    const bool par_skip = g->opt[PNP_OPT_PAR_SKIP] != 0;
+    // every 64-channel map that is only read as an MFMA A operand gets an fp16 copy from its producer
+    const bool mirrors = f16_maps && g->opt[PNP_OPT_F16_MIRRORS] && c.deform == 0 && W.x16 != nullptr;
     auto conv = [&](const ConvCall& q) -> int {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -596,6 +612,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.wvalu = g->opt[PNP_OPT_CONV_LAST_VALU] ? q.wvalu_ : nullptr;
         a.no_persist = g->opt[PNP_OPT_PERSIST] ? 0 : 1;
         a.no_small16 = g->opt[PNP_OPT_SMALL_F16] ? 0 : 1;
+        a.no_multi16 = 0;
         a.w_ystride = q.w_ystride_;
         a.bias_ystride = q.bias_ystride_;
         a.H = q.H;
@@ -605,6 +622,14 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.out_cstride = 448;
         a.out_f16 = q.io16_ == 1;
         a.src_f16 = q.io16_ == 2;
+        if (mirrors) {
+            for (int s = 0; s < q.nsrc; ++s)
+                if (q.src16_[s]) {
+                    a.src[s] = reinterpret_cast<const float*>(q.src16_[s]);
+                    a.src_f16 |= 1 << s;
+                }
+            a.out16 = q.out16_;
+        }
         // algorithmic FLOPs of this launch (reference channel counts, not padded ones)
         double kreal = 0;
         for (int s = 0; s < q.nsrc; ++s) kreal += 9.0 * (q.sc[s] == 64 ? 64 : 3);
@@ -615,15 +640,13 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         ProfScope ps(g, st, kind, 2.0 * kreal * nreal * (double)q.H * q.W * q.gy_);
         return launch_conv3x3(a, q.cfg_, q.gy_, st);
     };
-    const bool f16_maps = g->prec == PNP_PREC_F16 && g->opt[PNP_OPT_F16_MAPS];
-    const bool par_skip = g->opt[PNP_OPT_PAR_SKIP] != 0;
 
     // deform_align(feat, flow) -> W.kw  (iconvsr_ipb.py:19-24 dispatch; iconvsr_mv.py:12-84)
     auto align = [&](const float* feat, const float* fxp, const float* fyp) -> int {
         int r;
         if (c.deform == 0 || c.deform == 1) {   // 'vos', and the pre-warp of 'basic' (:69)
-            ProfScope ps(g, st, PNP_PROF_WARP, 520.0 * (double)hw);
-            r = launch_mv_warp_nhwc(feat, fxp, fyp, c.deform == 0 ? W.kw : W.tmp0, h, w, 64, st);
+            ProfScope ps(g, st, PNP_PROF_WARP, (mirrors ? 392.0 : 520.0) * (double)hw);     // 8 flow + 256 gather + 256 | 128 write
+            r = launch_mv_warp_nhwc(feat, fxp, fyp, c.deform == 0 ? W.kw : W.tmp0, h, w, 64, st, mirrors);   // mirrors: kw is fp16
             if (r || c.deform == 0) return r;
         }
         r = launch_pack_flow4(fxp, fyp, W.flow4, h, w, st);
@@ -752,12 +775,15 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const int* pflags = par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
-            int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0));
+            // fp16 mirrors: the input conv writes x16 next to x when it runs on the fp16 kernels at all (an RGB-only one does not)
+            const void* x16 = (mirrors && in.nsrc > 1) ? W.x16 : nullptr;
+            int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0).also16(const_cast<void*>(x16)));
             if (r) return r;
             const float* x = W.tmp0;
             for (int k = 0; k < c.num_blocks; ++k) {
                 const BlockPk& K = B.blocks[k];
                 float* dst = (k == c.num_blocks - 1) ? slot : W.tmp0;
+                void* dst16 = !mirrors ? nullptr : (k == c.num_blocks - 1) ? (void*)(W.slots16 + (int64_t)i * fm) : (void*)W.x16;
                 const float* w2 = W.mixw + ((int64_t)u * g->ndyn + K.dyn_conv2) * IMG_WIDE;
                 const float* b2 = W.mixb + ((int64_t)u * g->ndyn + K.dyn_conv2) * 64;
                 const float* w1 = c.one_layer ? packed + K.conv1_img
@@ -768,23 +794,29 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 // the map between the two halves is read only as an MFMA A operand: an fp16 map on the fp16 path
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
-                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).bias(b2).gamma(gam).partition(packed + K.w1x1, parp, pflags)
-                                 .act(1).to(W.tmp1).f16_map(o16));
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(gam)
+                                 .partition(packed + K.w1x1, parp, pflags).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).residual(x).to(dst)
-                                     .f16_map(s16));
+                                     .f16_map(s16).also16(dst16));
                 } else {                 // sr_backbone_utils.py:314-327
-                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).bias(b1).gamma(g1).act(1).to(W.tmp1).f16_map(o16));
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).mirror16(x16).bias(b1).gamma(g1).act(1).to(W.tmp1)
+                                 .f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(gam)
-                                     .partition(packed + K.w1x1, parp, pflags).residual(x).to(dst).f16_map(s16));
+                                     .partition(packed + K.w1x1, parp, pflags).residual(x).to(dst).f16_map(s16).also16(dst16));
                 }
                 if (r) return r;
                 x = dst;
+                x16 = dst16;
             }
             return 0;
         };
 
+        // fp16 mirrors of the sources of an input conv: the aligned key frame (fp16 ONLY in this mode, written by the warp) and
+        // the neighbouring / own slots
+        const void* kw16 = mirrors ? (const void*)W.kw : nullptr;
+        auto s16of = [&](int i) -> const void* { return mirrors ? (const void*)(W.slots16 + (int64_t)i * fm) : nullptr; };
         // ---- backward sweep (iconvsr_ipb_par.py:71-100)
         for (int i = t - 1; i >= 0; --i) {
             const BranchPk& B = g->br[0];
@@ -796,10 +828,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw, mv_b + ((int64_t)i * 4 + 3) * hw);
                 if (rc) return rc;
                 if (c.with_cat && c.align_key && k == i + 1) {     // neighbour == key frame: one source, summed weights
-                    in.source(W.kw, 64, packed + B.in_wide01);
+                    in.source(W.kw, 64, packed + B.in_wide01).mirror16(kw16);
                 } else {
-                    in.source(W.kw, 64, packed + B.in_wide[0]);
-                    if (c.with_cat) in.source(W.slots + (int64_t)(i + 1) * fm, 64, packed + B.in_wide[1]);
+                    in.source(W.kw, 64, packed + B.in_wide[0]).mirror16(kw16);
+                    if (c.with_cat) in.source(W.slots + (int64_t)(i + 1) * fm, 64, packed + B.in_wide[1]).mirror16(s16of(i + 1));
                 }
             }
             rc = run_branch(0, i, in);
@@ -816,13 +848,13 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw, mv_b + ((int64_t)i * 4 + 1) * hw);
                 if (rc) return rc;
                 if (c.with_cat && c.align_key && k == i - 1) {
-                    in.source(W.kw, 64, packed + B.in_wide01);
+                    in.source(W.kw, 64, packed + B.in_wide01).mirror16(kw16);
                 } else {
-                    in.source(W.kw, 64, packed + B.in_wide[0]);
-                    if (c.with_cat) in.source(W.slots + (int64_t)(i - 1) * fm, 64, packed + B.in_wide[1]);
+                    in.source(W.kw, 64, packed + B.in_wide[0]).mirror16(kw16);
+                    if (c.with_cat) in.source(W.slots + (int64_t)(i - 1) * fm, 64, packed + B.in_wide[1]).mirror16(s16of(i - 1));
                 }
             }
-            in.source(W.slots + (int64_t)i * fm, 64, packed + B.in_wide[B.n_wide - 1]);   // backward feature of this frame
+            in.source(W.slots + (int64_t)i * fm, 64, packed + B.in_wide[B.n_wide - 1]).mirror16(s16of(i));   // backward feature of this frame
             rc = run_branch(1, i, in);
             if (rc) return rc;
 
@@ -832,8 +864,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             // conv_hr's output feeds only conv_last: an fp16 map on the fp16 path
             const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
             if (!c.vsr) {   // :144-146
-                rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->hr_img).bias(flat + g->hr_bias).act(2)
-                              .to(W.tmp1).f16_map(o16));
+                rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->hr_img).mirror16(s16of(i)).bias(flat + g->hr_bias)
+                              .act(2).to(W.tmp1).f16_map(o16));
                 if (!rc)
                     rc = conv(ConvCall(h, w, CONV_CFG_RGB).source(W.tmp1, 64, packed + g->last_img).bias(packed + g->last_bias)
                                   .mode(2).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));
@@ -1203,6 +1235,48 @@ int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs, const int* src_channe
     if (a.wpar_h && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
     if (!conv_f16_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_f16(a, 1, (hipStream_t)st);
+}
+
+// pnpvcve_debug.h: the fp16-operand conv with explicit fp16 maps -- what pnp_generator_forward uses between its launches under
+// PNP_OPT_F16_MAPS / PNP_OPT_F16_MIRRORS -- so that tests can address every kernel variant through the ABI.
+int pnp_conv3x3_f16_maps(int nsrc, const void* const* srcs, const int* src_channels, int src_f16_mask,
+                         const void* const* packed_w_f16, const float* bias, const float* gamma, const void* packed_w1x1_f16,
+                         const float* par, const int* par_flags, const float* residual, int act, void* out, int out_f16,
+                         void* out16, int h, int w, int chain, void* trace, void* st) {
+    if (nsrc < 1 || nsrc > 4) return PNP_ERR_BAD_ARG;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = nsrc;
+    a.prec = 1;
+    for (int s = 0; s < nsrc; ++s) {
+        a.src[s] = reinterpret_cast<const float*>(srcs[s]);
+        a.src_c[s] = src_channels[s];
+        a.wsrc_h[s] = packed_w_f16[s];
+    }
+    a.src_f16 = src_f16_mask;
+    a.out_f16 = out_f16 ? 1 : 0;
+    a.out16 = out16;
+    a.no_multi16 = chain ? 1 : 0;
+    a.wpar_h = packed_w1x1_f16;
+    a.par = par;
+    a.par_flags = par_flags;
+    a.par_plane = (long)h * w;
+    a.bias = bias;
+    a.gamma = gamma;
+    a.residual = residual;
+    a.out = reinterpret_cast<float*>(out);
+    a.H = h;
+    a.W = w;
+    a.act = act;
+    a.out_mode = 0;
+    a.dbg = (unsigned long long*)trace;
+    if (a.wpar_h && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
+    if (!conv_f16_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
+    return launch_conv3x3_f16(a, 1, (hipStream_t)st);
+}
+
+int pnp_mv_warp_nhwc_f16out(const float* feat, const float* fx, const float* fy, void* out16, int h, int w, int c, void* st) {
+    return launch_mv_warp_nhwc(feat, fx, fy, out16, h, w, c, (hipStream_t)st, true);
 }
 
 }  // extern "C"

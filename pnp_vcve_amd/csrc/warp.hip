@@ -33,14 +33,21 @@ __device__ __forceinline__ void tap_setup(float x, float y, float fx, float fy, 
     wy1 = iy - fy0;
 }
 
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
 // feat/out: [H][W][C4*4] ; fxp/fyp: [H][W] planes (two channel planes of the NCHW mvs tensor)
+// OUT16: the aligned map is written as fp16 (8 B per lane).  On the fp16-operand conv path it is read only as an MFMA A
+// operand of the input conv, which would round it (saturating, round-to-nearest-even) on its way into LDS: rounding it
+// here instead is bit-identical and halves the bytes written and re-read.
+template <bool OUT16>
 __global__ __launch_bounds__(256) void mv_warp_nhwc_kernel(const float* __restrict__ feat,
                                                            const float* __restrict__ fxp,
                                                            const float* __restrict__ fyp,
-                                                           float* __restrict__ out, int H, int W, int C4,
+                                                           void* __restrict__ out, int H, int W, int C4,
                                                            long total) {
     const f32x4* f4 = reinterpret_cast<const f32x4*>(feat);
     f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    h4* o16 = reinterpret_cast<h4*>(out);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / C4;
         const int c4 = (int)(i - pix * C4);
@@ -57,7 +64,13 @@ __global__ __launch_bounds__(256) void mv_warp_nhwc_kernel(const float* __restri
         const f32x4 v01 = (vx1 & vy0) ? f4[r0 + C4] : z;
         const f32x4 v10 = (vx0 & vy1) ? f4[r1] : z;
         const f32x4 v11 = (vx1 & vy1) ? f4[r1 + C4] : z;
-        o4[i] = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+        f32x4 v = v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1);
+        if (OUT16) {
+            v = __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x4)(-65504.f)), (f32x4)(65504.f));
+            o16[i] = __builtin_convertvector(v, h4);
+        } else {
+            o4[i] = v;
+        }
     }
 }
 
@@ -94,15 +107,19 @@ __global__ __launch_bounds__(256) void flow_warp_nchw_kernel(const float* __rest
 
 }  // namespace
 
-int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, float* out, int H, int W, int C,
-                        hipStream_t stream) {
+int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, void* out, int H, int W, int C,
+                        hipStream_t stream, bool out_f16) {
     if (C % 4) return PNP_ERR_BAD_ARG;
     const long total = (long)H * W * (C / 4);
     long blocks = (total + 255) / 256;
     const long cap = 256L * 32;            // 32 blocks per CU worth of grid, grid-stride beyond
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(mv_warp_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, feat, fx, fy, out, H, W,
-                       C / 4, total);
+    if (out_f16)
+        hipLaunchKernelGGL(mv_warp_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, feat, fx, fy, out, H, W,
+                           C / 4, total);
+    else
+        hipLaunchKernelGGL(mv_warp_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, feat, fx, fy, out, H, W,
+                           C / 4, total);
     return (int)hipGetLastError();
 }
 

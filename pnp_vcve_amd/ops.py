@@ -216,6 +216,54 @@ def _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act, t
 
 
 @_on_device_of_first_tensor
+def conv3x3_f16_maps(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, par_flags=None, residual=None, act=0,
+                     out_f16=False, mirror=False, chain=False, trace=None):
+    """The fp16-operand conv with explicit fp16 maps (include/pnpvcve_debug.h, pnp_conv3x3_f16_maps): a source of dtype
+    float16 (h,w,64) is read as an fp16 map (the mirror its producer wrote), float32 sources are rounded on the fly.
+    out_f16: the output is an fp16 map; mirror: additionally return the fp16 copy of the fp32 output written in the same
+    pass -> (out, out16).  chain=True forces the chain of single-source launches for several fp32 sources."""
+    n = len(srcs)
+    mask = 0
+    for i, t in enumerate(srcs):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError('sources must be contiguous CUDA/HIP tensors')
+        if t.dtype == torch.float16:
+            mask |= 1 << i
+        elif t.dtype != torch.float32:
+            raise TypeError(f'source {i}: float32 or float16, got {t.dtype}')
+    for p in list(packed_w) + ([packed_w1x1] if packed_w1x1 is not None else []):
+        if not p.is_cuda or p.dtype != torch.float16 or not p.is_contiguous():
+            raise TypeError('fp16 conv: weight images must be contiguous CUDA float16 tensors (ops.f16_image)')
+    h, w = srcs[0].shape[:2]
+    dev = srcs[0].device
+    out = torch.empty((h, w, 64), device=dev, dtype=torch.float16 if out_f16 else torch.float32)
+    out16 = torch.empty((h, w, 64), device=dev, dtype=torch.float16) if mirror else None
+    sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    sc = (ctypes.c_int * n)(*[t.shape[2] for t in srcs])
+    wp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in packed_w])
+    keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, par, residual)]
+    if par_flags is not None and (par_flags.dtype != torch.int32 or not par_flags.is_cuda):
+        raise TypeError('par_flags: int32 CUDA tensor (ops.par_tile_flags)')
+    w1 = ctypes.c_void_p(packed_w1x1.data_ptr()) if packed_w1x1 is not None else None
+    _native.check(_native.lib().pnp_conv3x3_f16_maps(n, sp, sc, mask, wp, _ptr(keep[0]), _ptr(keep[1]), w1, _ptr(keep[2]),
+                                                     _ptr(par_flags), _ptr(keep[3]), act, _ptr(out), int(bool(out_f16)),
+                                                     _ptr(out16), h, w, int(bool(chain)), _ptr(trace), _stream()),
+                  'pnp_conv3x3_f16_maps')
+    return (out, out16) if mirror else out
+
+
+@_on_device_of_first_tensor
+def mv_warp_nhwc_f16(feat, flow_x, flow_y):
+    """mv_warp_nhwc writing an fp16 (h,w,c) map: saturating round-to-nearest-even of the fp32 result."""
+    feat, flow_x, flow_y = _chk(feat, 'feat'), _chk(flow_x, 'flow_x'), _chk(flow_y, 'flow_y')
+    h, w, c = feat.shape
+    out = torch.empty((h, w, c), device=feat.device, dtype=torch.float16)
+    _native.check(_native.lib().pnp_mv_warp_nhwc_f16out(_ptr(feat), _ptr(flow_x), _ptr(flow_y), _ptr(out), h, w, c, _stream()),
+                  'pnp_mv_warp_nhwc_f16out')
+    return out
+
+
+@_on_device_of_first_tensor
 def frames_to_rgb8(frames):
     """(n,3,h,w) fp32 CUDA frames -> (n,h,w,3) uint8 RGB CUDA tensor with tensor2img's arithmetic."""
     frames = _chk(frames, 'frames')

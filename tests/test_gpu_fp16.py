@@ -300,3 +300,212 @@ def test_small_frame_f16_kernel_is_bit_identical_to_the_persistent_one(hw):
         out = run()
         assert torch.isfinite(out).all() and torch.equal(out, ref), (hw, maps16, float((out - ref).abs().max()))
 
+
+
+# ---------------------------------------------------------------- r03: fp16 mirrors, branch skipping, one-launch input conv
+def _h16(t):
+    """the kernels' rounding of an fp32 value to an fp16 MFMA operand: saturate, round to nearest even"""
+    return t.clamp(-65504, 65504).half()
+
+
+def _block_par(seed, h, w, scale=200.0 / 255.0, empty_every=3):
+    """one-hot partition planes per 8x8 block, every `empty_every`-th block row without any record"""
+    cls = gu.syn.randint(seed, f'cls{h}x{w}', ((h + 7) // 8, (w + 7) // 8), 0, 2)
+    par = np.zeros((3, h, w), np.float32)
+    for j in range(3):
+        blk = (cls == j).astype(np.float32)
+        blk[::empty_every] = 0.0
+        par[j] = np.kron(blk, np.ones((8, 8), np.float32))[:h, :w]
+    return par * np.float32(scale)
+
+
+SIZES_F16 = [(40, 56), (180, 320), (128, 512), (256, 512)]        # small G=1 (ragged), small G=1, small G=2, persistent (1024 tiles)
+
+
+@pytest.mark.parametrize('hw', SIZES_F16, ids=lambda s: '%dx%d' % s)
+@pytest.mark.parametrize('with_par', [False, True], ids=['plain', 'par'])
+def test_f16_mirror_and_fp16_sources_are_bit_identical(hw, with_par):
+    """(1) the fp16 mirror a producer writes next to its fp32 output is exactly the consumer's operand rounding of that output;
+    (2) reading a source through its fp16 mirror instead of rounding the fp32 map on the fly changes no bit -- for fp32 output,
+    fp16 output and fp32 + mirror output, with and without the partition branches."""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x = ops.nchw_to_nhwc(G(gu.syn.uniform(51, f'x{h}x{w}', (1, 64, h, w), -1, 1)))[0]
+    res = ops.nchw_to_nhwc(G(gu.syn.uniform(51, f'r{h}x{w}', (1, 64, h, w), -1, 1)))[0]
+    wt = ops.f16_image(ops.pack_conv3x3(G(gu.syn.uniform(51, 'w', (64, 64, 3, 3), -0.06, 0.06))))
+    b, gam = G(gu.syn.uniform(51, 'b', (64,), -0.1, 0.1)), G(gu.syn.uniform(51, 'g', (64,), 0.5, 1.5))
+    kw = dict(bias=b, gamma=gam, act=1)
+    if with_par:
+        kw.update(packed_w1x1=ops.f16_image(ops.pack_conv1x1([G(gu.syn.uniform(51, f'w1_{j}', (64, 64, 1, 1), -0.1, 0.1))
+                                                              for j in range(3)])), par=G(_block_par(51, h, w)))
+    base = ops.conv3x3_f16_maps([x], [wt], residual=res, **kw)
+    assert torch.equal(base, ops.conv3x3([x], [wt], residual=res, fp16=True, **kw))          # the r02 entry point
+    out, m16 = ops.conv3x3_f16_maps([x], [wt], residual=res, mirror=True, **kw)
+    assert torch.equal(out, base) and torch.equal(m16, _h16(base))
+    x16 = _h16(x)
+    assert torch.equal(ops.conv3x3_f16_maps([x16], [wt], residual=res, **kw), base)
+    out, m16 = ops.conv3x3_f16_maps([x16], [wt], residual=res, mirror=True, **kw)
+    assert torch.equal(out, base) and torch.equal(m16, _h16(base))
+    o16 = ops.conv3x3_f16_maps([x], [wt], out_f16=True, **kw)                                   # fp16 output: no residual
+    assert torch.equal(o16, _h16(ops.conv3x3_f16_maps([x], [wt], **kw)))
+    assert torch.equal(ops.conv3x3_f16_maps([x16], [wt], out_f16=True, **kw), o16)              # fp16 in, fp16 out (new)
+
+
+@pytest.mark.parametrize('hw', SIZES_F16 + [(720, 1280)], ids=lambda s: '%dx%d' % s)
+def test_f16_partition_branch_skipping_is_value_identical(hw):
+    """fp16 kernels: a 1x1 partition branch whose plane is zero over a whole 8x16 tile adds exact zeros -- skipping its four
+    k-steps (pnp_par_tile_flags_f32) leaves every output value unchanged, for fp32 and for fp16 output, on maps where tiles
+    need 0, 1, 2 or 3 branches."""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x = torch.randn(h, w, 64, device=dev(), generator=torch.Generator(device=dev()).manual_seed(3))
+    wt = ops.f16_image(ops.pack_conv3x3(G(gu.syn.uniform(52, 'w', (64, 64, 3, 3), -0.06, 0.06))))
+    w1 = ops.f16_image(ops.pack_conv1x1([G(gu.syn.uniform(52, f'w1_{j}', (64, 64, 1, 1), -0.1, 0.1)) for j in range(3)]))
+    par = _block_par(52, h, w)
+    par[:, : h // 4] = 0.0                                   # a band without any record (an I-frame-like region)
+    par[:, h // 2: h // 2 + 8, : w // 2] = 0.3               # tiles that need all three branches, non-binary values
+    par = G(par)
+    flags = ops.par_tile_flags(par)
+    assert set(int(v) for v in flags.unique().tolist()) >= {0, 7} and flags.numel() == ((h + 7) // 8) * ((w + 15) // 16)
+    kw = dict(bias=G(gu.syn.uniform(52, 'b', (64,), -0.1, 0.1)), gamma=G(gu.syn.uniform(52, 'g', (64,), 0.5, 1.5)),
+              packed_w1x1=w1, par=par, act=1)
+    for extra in (dict(), dict(out_f16=True)):
+        a = ops.conv3x3_f16_maps([x], [wt], **kw, **extra)
+        b = ops.conv3x3_f16_maps([x], [wt], par_flags=flags, **kw, **extra)
+        assert torch.equal(a, b), (hw, extra, float((a.float() - b.float()).abs().max()))
+    # and the flags are honoured at all: a map that lies about a live plane changes the result
+    lie = torch.zeros_like(flags)
+    assert not torch.equal(ops.conv3x3_f16_maps([x], [wt], par_flags=lie, **kw), a)
+
+
+@pytest.mark.parametrize('hw', [(40, 56), (180, 320), (256, 512)], ids=lambda s: '%dx%d' % s)
+@pytest.mark.parametrize('nwide', [1, 2, 3])
+@pytest.mark.parametrize('with_lr', [False, True], ids=['wide', 'rgb+wide'])
+def test_f16_input_conv_in_one_launch_equals_the_launch_chain(hw, nwide, with_lr):
+    """conv3x3_f16_multi_kernel (all wide sources read through fp16 mirrors, one launch) against the chain of single-source
+    launches through fp32 partial sums: same MFMA chains per source, folded in the chain's order -- bit-identical, and so is
+    the fp16 mirror of the result."""
+    from pnp_vcve_amd import ops
+    if nwide == 1 and not with_lr:
+        pytest.skip('a single 64-channel source is the ordinary single-source kernel')
+    h, w = hw
+    cin = (3 if with_lr else 0) + 64 * nwide
+    lr = gu.syn.uniform(53, 'lr', (1, 3, h, w), 0, 1)
+    wides = [ops.nchw_to_nhwc(G(gu.syn.uniform(53, f's{j}_{h}', (1, 64, h, w), -1, 1)))[0] for j in range(nwide)]
+    wg = G(gu.syn.uniform(53, f'w{cin}', (64, cin, 3, 3), -0.05, 0.05))
+    b = G(gu.syn.uniform(53, 'b', (64,), -0.1, 0.1))
+    lr4 = ops.nchw_to_nhwc(G(np.concatenate([lr, np.zeros((1, 1, h, w), np.float32)], axis=1)))[0]
+    c0 = 3 if with_lr else 0
+    packed = ([ops.f16_image(ops.pack_conv3x3(wg, 0, 3))] if with_lr else []) + \
+        [ops.f16_image(ops.pack_conv3x3(wg, c0 + 64 * j, 64)) for j in range(nwide)]
+    head = [lr4] if with_lr else []
+    chain = ops.conv3x3_f16_maps(head + wides, packed, bias=b, act=2, chain=True)
+    assert torch.equal(chain, ops.conv3x3(head + wides, packed, bias=b, act=2, fp16=True))
+    one, m16 = ops.conv3x3_f16_maps(head + [_h16(s) for s in wides], packed, bias=b, act=2, mirror=True)
+    assert torch.equal(one, chain), float((one - chain).abs().max())
+    assert torch.equal(m16, _h16(chain))
+    assert torch.equal(ops.conv3x3_f16_maps(head + [_h16(s) for s in wides], packed, bias=b, act=2), chain)
+
+
+def test_warp_fp16_output_is_the_rounded_fp32_warp():
+    from pnp_vcve_amd import ops
+    h, w = 72, 120
+    feat = torch.randn(h, w, 64, device=dev()) * 3
+    feat[5, 7, 3] = 1e6                                       # saturates instead of overflowing
+    blk = (torch.randint(-32, 33, (2, h // 8, w // 8), device=dev()).float() / 4.0)
+    fl = blk.repeat_interleave(8, 1).repeat_interleave(8, 2)
+    a = ops.mv_warp_nhwc(feat, fl[0].contiguous(), fl[1].contiguous())
+    b = ops.mv_warp_nhwc_f16(feat, fl[0].contiguous(), fl[1].contiguous())
+    assert b.dtype == torch.float16 and torch.equal(b, _h16(a)) and torch.isfinite(b).all()
+
+
+def _gen_model(cfg, sd_np):
+    import pnp_vcve_amd as P
+    m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+    m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
+    return m.to(dev()).eval()
+
+
+MIRROR_CASES = [
+    ('default_180x320', dict(), dict(n=1, t=4, h=180, w=320)),
+    ('default_t1_64x96', dict(), dict(n=1, t=1, h=64, w=96)),
+    ('nocat_noalign_72x88', dict(with_cat=False, align_key=False), dict(n=1, t=3, h=72, w=88)),
+    ('channel_last_two_layer_n2', dict(channel_first=False, one_layer=False, num_blocks=2), dict(n=2, t=3, h=64, w=64)),
+    ('vsr_64x80', dict(vsr=True, num_blocks=2), dict(n=1, t=2, h=64, w=80)),
+    ('default_720p', dict(num_blocks=2), dict(n=1, t=3, h=720, w=1280)),
+]
+
+
+@pytest.mark.parametrize('name,over,shape', MIRROR_CASES, ids=[c[0] for c in MIRROR_CASES])
+def test_f16_mirrors_and_one_launch_input_conv_leave_the_clip_bit_identical(name, over, shape):
+    """PNP_OPT_F16_MIRRORS (fp16 copies of x / the slots / the aligned key frame written by their producers, input conv in one
+    launch, branch skipping on the fp16 kernels) against the r02 schedule (fp32 maps rounded by their readers, launch chain):
+    not a bit of the enhanced clip changes; neither does it with the partition flags off."""
+    from pnp_vcve_amd import _native
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, **over)
+    sd_np = gu.syn.make_state_dict(cfg, seed=141, par_gain=10.0)
+    crf = [15, 35] if shape['n'] == 2 else 25
+    clip = gu.syn.make_clip(seed=142, slices='IBBBP', block=4, par_classes=3, qp_mode='ipb', crf=crf, **shape)
+    m = _gen_model(cfg, sd_np)
+    m.fp16_enabled = True
+    a = {k: G(v) for k, v in clip.items()}
+
+    def run():
+        with torch.no_grad():
+            return m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
+
+    m.set_option(_native.OPT_F16_MIRRORS, 0)
+    m.set_option(_native.OPT_PAR_SKIP, 0)
+    ref = run().clone()
+    m.set_option(_native.OPT_PAR_SKIP, 1)
+    assert torch.equal(run(), ref), 'branch skipping alone'
+    m.set_option(_native.OPT_F16_MIRRORS, 1)
+    out = run()
+    assert torch.isfinite(out).all() and torch.equal(out, ref), float((out - ref).abs().max())
+    m.set_option(_native.OPT_PAR_SKIP, 0)
+    assert torch.equal(run(), ref)
+
+
+@pytest.mark.parametrize('hw', [(180, 320), (720, 1280)], ids=lambda s: '%dx%d' % s)
+def test_f16_kernels_are_run_to_run_deterministic(hw):
+    """conv3x3_f16_small_kernel (180x320) / conv3x3_f16_kernel (720p) and the one-launch input conv: the same clip twice,
+    and once more after other work has gone through the device, must agree bit for bit (guards the class of hazard seen in the
+    fp16 DCN kernel, csrc/dcn.hip)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    sd_np = gu.syn.make_state_dict(cfg, seed=151, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=152, n=1, t=3, h=hw[0], w=hw[1], slices='IBBBP', block=4, par_classes=3)
+    m = _gen_model(cfg, sd_np)
+    m.fp16_enabled = True
+    a = {k: G(v) for k, v in clip.items()}
+
+    def run():
+        with torch.no_grad():
+            return m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']).clone()
+
+    first = run()
+    for rep in range(3):
+        torch.randn(1 << 22, device=dev()).sin_()           # unrelated traffic between the runs
+        assert torch.equal(run(), first), rep
+
+
+def _pins():
+    import json
+    import os
+    with open(os.path.join(gu.GOLDEN_DIR, 'f16_pins_r02.json')) as f:
+        return json.load(f)['cases']
+
+
+import f16_pin_cases as _pc  # noqa: E402
+
+
+@pytest.mark.parametrize('case', _pc.PIN_CASES, ids=[c['name'] for c in _pc.PIN_CASES])
+def test_f16_path_is_bit_identical_to_the_round_2_build(case):
+    """The fp16 path of THIS build (fp16 mirrors, one-launch input conv, branch skipping, ...) against SHA-256 pins of the
+    outputs the round-2 build produced on an MI355X (tests/f16_pin_cases.py, tools/gen_f16_pins.py): same k order and rounding
+    points, hence the same bits (-0.0 canonicalised)."""
+    import pnp_vcve_amd as P
+    pin = _pins()[case['name']]
+    out = _pc.run_case(case, gu.syn, P.build_backbone, torch)
+    got = _pc.digest(out)
+    assert got['shape'] == pin['shape']
+    assert got['sha256'] == pin['sha256'], (case['name'], got['mean'], pin['mean'], got['first'], pin['first'])
