@@ -1,6 +1,10 @@
 // Shared device/host helpers for the PnP-VCVE hot-path kernels (gfx950 only).
 #pragma once
+#ifdef PNP_HOST_STUB
+#include "host_stub/hip_stub.h"   // host-only sanitizer build of the scheduler (tests/test_host_scheduler.py)
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -662,7 +662,15 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
     // PAR: which 1x1 branches this tile needs (fetched now, made wave-uniform when the first branch chunk is scheduled)
     const __amdgpu_buffer_rsrc_t r_flags = make_rsrc((PAR && a.par_flags) ? (const void*)a.par_flags : a.src,
                                                      (PAR && a.par_flags) ? (unsigned)ntiles * 4u : 0);
-    const int pfl_v = PAR ? __builtin_bit_cast(int, buf_load1(r_flags, live ? (unsigned)tile * 4u : OOB)) : 0;
+    // G = 2: the two groups of a block share the weight ring and its barriers, so they run the same chunk list -- the union of
+    // what their two tiles need (a branch the other tile alone needs adds exact zeros here: its plane is zero on this tile)
+    int pfl_v = 0;
+    if (PAR) {
+        const int t0 = tile - grp;
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq)
+            pfl_v |= __builtin_bit_cast(int, buf_load1(r_flags, (t0 + gq < ntiles) ? (unsigned)(t0 + gq) * 4u : OOB));
+    }
 
     // ---- requests: halo, the first weight chunks, residual rows / partition values
     f32x4 areg[AIT];
@@ -1140,31 +1148,6 @@ int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStrea
     hipLaunchKernelGGL(f16_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src,
                        reinterpret_cast<_Float16*>(dst), ntb, total);
     return (int)hipGetLastError();
-}
-
-bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
-    const bool has_par = a.wpar || a.wpar_h;
-    if (cfg == CONV_CFG_RGB)     // conv_last: one 64-channel source, 3 NCHW planes + the low-quality frame
-        return (a.out_mode == 2 || a.out_mode == 3) && a.nsrc == 1 && a.src_c[0] == 64 && a.wsrc_h[0] && grid_y == 1 &&
-               !has_par && !a.residual && !a.gamma && !a.out_f16 && a.lr;
-    if (a.out_mode != 0 && a.out_mode != 1 && a.out_mode != 4) return false;
-    int nwide = 0;
-    for (int s = 0; s < a.nsrc; ++s) {
-        if (a.src_c[s] == 64) ++nwide;
-        if (!a.wsrc_h[s]) return false;
-    }
-    if (nwide == 0) return false;                        // an RGB-only input conv stays on the fp32 kernel
-    if (nwide > 1 && (a.residual || a.gamma || grid_y != 1 || a.out_mode != 0)) return false;
-    if (has_par && (a.nsrc != 1 || !a.wpar_h || !a.par || grid_y != 1)) return false;
-    // fp16 maps (a source read through its fp16 mirror, an fp16 output, an fp16 mirror of the fp32 output)
-    if ((a.src_f16 || a.out_f16 || a.out16) && (grid_y != 1 || a.out_mode != 0)) return false;
-    if (a.out_f16 && (a.residual || a.out16 || a.nsrc != 1)) return false;
-    if (a.src_f16 && a.nsrc != 1) {          // several sources: the one-launch kernel, which reads ALL wide sources as fp16
-        for (int s = 0; s < a.nsrc; ++s)
-            if (a.src_c[s] == 64 && !((a.src_f16 >> s) & 1)) return false;
-        if (a.residual || a.gamma || has_par) return false;
-    }
-    return true;
 }
 
 // single-source 64 -> 64 launches on frames with fewer than 1024 tiles (what the persistent design cannot amortise)

@@ -52,7 +52,31 @@ int conv_pick_cfg(int H, int W);
 
 // fp16-operand variant (conv_f16.hip): fp32 B image -> fp16 image (same element count, chunk by chunk)
 int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t stream);
-bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y);
+// which launches the fp16-operand kernels take (a pure function of the arguments: shared with the host-only scheduler test build)
+static inline bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
+    const bool has_par = a.wpar || a.wpar_h;
+    if (cfg == CONV_CFG_RGB)     // conv_last: one 64-channel source, 3 NCHW planes + the low-quality frame
+        return (a.out_mode == 2 || a.out_mode == 3) && a.nsrc == 1 && a.src_c[0] == 64 && a.wsrc_h[0] && grid_y == 1 &&
+               !has_par && !a.residual && !a.gamma && !a.out_f16 && a.lr;
+    if (a.out_mode != 0 && a.out_mode != 1 && a.out_mode != 4) return false;
+    int nwide = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        if (a.src_c[s] == 64) ++nwide;
+        if (!a.wsrc_h[s]) return false;
+    }
+    if (nwide == 0) return false;                        // an RGB-only input conv stays on the fp32 kernel
+    if (nwide > 1 && (a.residual || a.gamma || grid_y != 1 || a.out_mode != 0)) return false;
+    if (has_par && (a.nsrc != 1 || !a.wpar_h || !a.par || grid_y != 1)) return false;
+    // fp16 maps (a source read through its fp16 mirror, an fp16 output, an fp16 mirror of the fp32 output)
+    if ((a.src_f16 || a.out_f16 || a.out16) && (grid_y != 1 || a.out_mode != 0)) return false;
+    if (a.out_f16 && (a.residual || a.out16 || a.nsrc != 1)) return false;
+    if (a.src_f16 && a.nsrc != 1) {          // several sources: the one-launch kernel, which reads ALL wide sources as fp16
+        for (int s = 0; s < a.nsrc; ++s)
+            if (a.src_c[s] == 64 && !((a.src_f16 >> s) & 1)) return false;
+        if (a.residual || a.gamma || has_par) return false;
+    }
+    return true;
+}
 int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream);
 
 // per-tile summary of a partition map for ConvArgs::par_flags (conv_persist.hip); flags: ((W+15)/16) * ((H+7)/8) ints
