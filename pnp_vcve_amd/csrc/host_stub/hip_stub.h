@@ -66,6 +66,7 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s);
 hipError_t hipGetLastError();
 hipError_t hipGetDevice(int* dev);
 hipError_t hipFuncSetAttribute(const void* fn, int attr, int value);
