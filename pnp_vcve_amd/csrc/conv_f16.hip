@@ -989,7 +989,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const F16Args 
     lds_barrier();
     if (a.dbg) d_t1 = __builtin_amdgcn_s_memtime();
 
-    // ---- K loop: chunk c from ring slot c % 3; every B fragment feeds both M tiles
+    // ---- K loop: one continuous stream of k-steps (4 per chunk; chunk c lives in ring slot c % 3); every B fragment feeds both
+    // M tiles.  Fragments are fetched DEPTH k-steps ahead ACROSS chunk boundaries: chunk c + 1 has been in the ring since the
+    // barrier that ended chunk c - 1.  Per chunk: the request for chunk c + 3 at its top, the ring write of chunk c + 2 (into
+    // the slot of chunk c - 1, which every wave left before that barrier) behind its second k-step, and ONE barrier at its end
+    // that waits only for that write (lgkmcnt counts in order: the 2 x 4 fragment reads issued after it stay in flight).
     const char* a_lane = sA + (4 * wave + my) * RSB + mx * PSB + 16 * h;
     f32x16 acc[2][2];
 #pragma unroll
@@ -1008,6 +1012,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const F16Args 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][j][r] = (acc[mt][j][r] + bco[j]) * gco[j];
     };
+    constexpr int DEPTH = 3;
+    h8 fa0[DEPTH], fa1[DEPTH], fb0[DEPTH], fb1[DEPTH];
+    auto fetch = [&](int step) {        // compile-time step; the A address of a branch chunk is the centre tap whichever branch it is
+        const int c = step >> 2, sk = step & 3, sl = step % DEPTH;
+        const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
+        const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
+        fa0[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
+        fa1[sl] = *reinterpret_cast<const h8*>(a_lane + (dy + 2) * RSB + dx * PSB + 32 * sk);
+        fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
+        fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) fetch(k);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (PAR && c == 6 && a.par_flags) {          // first use of the flags: chunk 9 is requested below
@@ -1024,8 +1042,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const F16Args 
 #pragma unroll
             for (int i = 0; i < WPT; ++i) wreg[(c + 1) & 1][i] = g[t + 256 * i];
         }
-        const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
-        const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
         _Float16 pj[2] = {(_Float16)1.f, (_Float16)1.f};
         if (PAR && c >= 9) {
             if (c == 9) bias_gamma();                  // (conv + bias) * gamma BEFORE the 1x1 partition branches
@@ -1035,10 +1051,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const F16Args 
         }
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) {
-            h8 a0 = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
-            h8 a1 = *reinterpret_cast<const h8*>(a_lane + (dy + 2) * RSB + dx * PSB + 32 * sk);
-            const h8 b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
-            const h8 b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
+            const int step = c * 4 + sk, sl = step % DEPTH;
+            h8 a0 = fa0[sl], a1 = fa1[sl];
+            const h8 b0 = fb0[sl], b1 = fb1[sl];
             if (PAR && c >= 9) {
                 a0 *= pj[0];
                 a1 *= pj[1];
@@ -1047,15 +1062,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const F16Args 
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (c + 2 < NC && (!PAR || c + 2 < ncr)) {
-            char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1: every wave left it at the previous barrier
+            if (step + DEPTH < NC * 4) fetch(step + DEPTH);       // (past the tile's last chunk: unused stale bytes)
+            if (sk == 1 && c + 2 < NC && (!PAR || c + 2 < ncr)) {
+                char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[c & 1][i];
+                for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[c & 1][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        lds_barrier();
+        // the ring write above is older than the 8 fragment reads of k-steps 2 and 3: wait for it, not for them
+        asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
     }
     if (!PAR || ncr == 9) bias_gamma();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // nobody still reads the LDS the epilogue overwrites
 
     if (a.dbg) d_t2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue, M tile by M tile: transpose through the dead LDS (8 KiB per wave and M tile), activation, residual, whole
