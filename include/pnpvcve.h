@@ -85,10 +85,7 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     operand (the running map of a branch, the frame slots, the MV-aligned key frame) gets an fp16 copy
                                     from its producer, and the input conv of a branch runs as ONE launch over those copies instead of
                                     a chain of single-source launches through fp32 partial sums.  Bit-identical: same rounding points */
-#define PNP_OPT_WIDE_F16 7       /* PNP_PREC_F16, frames with >= 1024 tiles: single-source convs whose source is an fp16 map run on the
-                                    wide kernel (16x16 tiles, 64 px x 64 ch per wave, weights streamed through an LDS ring, two
-                                    free-running blocks per CU) instead of the resident-weight kernel.  Bit-identical */
-#define PNP_OPT_COUNT 8
+#define PNP_OPT_COUNT 7
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 

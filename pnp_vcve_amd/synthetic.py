@@ -245,3 +245,74 @@ def make_clip(seed, n=1, t=7, h=128, w=128, slices='IBBBP', qp_mode='qp', crf=25
     base = (np.repeat(crfs[:, None], t, axis=1) / np.float32(255.0)).reshape(n, t, 1, 1, 1).astype(np.float32)
     return dict(lq=lq, gt=gt, mvs=np.ascontiguousarray(mvs), partitions=np.ascontiguousarray(par),
                 slices=sl, QPs=qps, base_QPs=base)
+
+
+# --------------------------------------------------------------------------
+# on-disk clips in the reference's directory layout (for the end-to-end pipeline benchmark and the dataset tests)
+# --------------------------------------------------------------------------
+def make_mv_records(seed, t, h, w, slices, block=16):
+    """Decoder-style MV records of a clip, rows (direction, w, h, x_w, y_w, x, y, motion_x, motion_y, scale) as
+    LoadImageFromFileList_ipb reads them (mmedit/datasets/pipelines/loading_ipb.py:328-369): every P / B frame is tiled by
+    `block` x `block` partitions split at random into 16x16 / 16x8 / 8x16 / 8x8 records with quarter-pel vectors
+    (h * w / 256 ... / 64 records per frame: thousands at 720p).  -> (records float32 (R, 10), frame int32 (R,))."""
+    rows, frames = [], []
+    gy, gx = (h + block - 1) // block, (w + block - 1) // block
+    for f in range(t):
+        if slices[f] == 'I':
+            continue
+        kind = randint(seed, f'kind{f}', (gy, gx), 0, 3)
+        mx = randint(seed, f'mx{f}', (gy, gx, 4), -32, 32).astype(np.float32)
+        my = randint(seed, f'my{f}', (gy, gx, 4), -32, 32).astype(np.float32)
+        dr = (randint(seed, f'dr{f}', (gy, gx, 4), 0, 1) * 2 - 1).astype(np.float32)
+        parts = {0: [(0, 0, 16, 16)], 1: [(0, 0, 16, 8), (0, 8, 16, 8)], 2: [(0, 0, 8, 16), (8, 0, 8, 16)],
+                 3: [(0, 0, 8, 8), (8, 0, 8, 8), (0, 8, 8, 8), (8, 8, 8, 8)]}
+        by, bx = np.mgrid[0:gy, 0:gx]
+        for k, plist in parts.items():
+            sel = kind == k
+            for pi, (ox, oy, bw, bh) in enumerate(plist):
+                x, y = (bx[sel] * block + ox).astype(np.float32), (by[sel] * block + oy).astype(np.float32)
+                vx, vy = mx[..., pi][sel], my[..., pi][sel]
+                n = x.shape[0]
+                r = np.stack([dr[..., pi][sel], np.full(n, bw, np.float32), np.full(n, bh, np.float32),
+                              x + np.trunc(vx / 4.0), y + np.trunc(vy / 4.0), x, y, vx, vy,
+                              np.full(n, 4.0, np.float32)], axis=1)
+                rows.append(r.astype(np.float32))
+                frames.append(np.full(n, f, np.int32))
+    if not rows:
+        return np.zeros((0, 10), np.float32), np.zeros((0,), np.int32)
+    return np.concatenate(rows), np.concatenate(frames)
+
+
+
+def write_clip_tree(root, clips=('000', '011'), t=7, h=128, w=128, crf=25, slices='IBBBP', seed=0):
+    """Write `clips` synthetic clips under `root` in the reference's REDS layout and return (lq_folder, gt_folder,
+    qp_slice_file): <root>/crfXX/png/<clip>/%08d.png, .../mv/<clip>/%08d.npy, <root>/X4/png/<clip>/%08d.png and the JSON
+    QP / slice table (configs/HR_davis_LR_128x128.py:109-131, loading_ipb.py:298-316).  Frames are smooth (fast to encode)."""
+    import json
+    import os
+    from PIL import Image
+    cdir = f'crf{crf}'
+    if isinstance(slices, str) and slices not in ('IBBBP', 'allB', 'allP'):
+        sl = list(slices[:t])                          # explicit letters, e.g. 'IBPB'
+    else:
+        sl = [chr(int(v)) for v in slice_pattern(slices, t)]
+        sl[0] = 'I' if slices == 'IBBBP' else sl[0]
+    table = {cdir: {}}
+    yy, xx = np.mgrid[0:h, 0:w]
+    for ci, clip in enumerate(clips):
+        png, mv, gt = (os.path.join(root, cdir, 'png', clip), os.path.join(root, cdir, 'mv', clip), os.path.join(root, 'X4', 'png', clip))
+        for d in (png, mv, gt):
+            os.makedirs(d, exist_ok=True)
+        rec, rf = make_mv_records(seed * 1009 + ci, t, h, w, sl)
+        table[cdir][clip] = {}
+        for f in range(t):
+            base = np.stack([(xx * (2 + ci) + yy * 3 + 17 * f) % 256, (xx + yy * (2 + f)) % 256, (xx * 5 + yy + 40 * ci) % 256], axis=-1)
+            img = base.astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(gt, f'{f:08d}.png'), compress_level=1)
+            Image.fromarray((img // 4 * 4).astype(np.uint8)).save(os.path.join(png, f'{f:08d}.png'), compress_level=1)
+            np.save(os.path.join(mv, f'{f:08d}.npy'), rec[rf == f])
+            table[cdir][clip][str(f)] = {'slice': sl[f], 'QP': 22 + (f % 12)}
+    qp = os.path.join(root, 'qp.json')
+    with open(qp, 'w') as fq:
+        json.dump(table, fq)
+    return os.path.join(root, cdir, 'png'), os.path.join(root, 'X4', 'png'), qp

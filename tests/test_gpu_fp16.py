@@ -319,8 +319,7 @@ def _block_par(seed, h, w, scale=200.0 / 255.0, empty_every=3):
     return par * np.float32(scale)
 
 
-# small G=1 (ragged), small G=1, small G=2, then >= 1024 tiles: resident-weight kernel (fp32 source) / wide kernel (fp16 source),
-# the last one ragged in both directions for 8x16 AND 16x16 tiles
+# small G=1 (ragged), small G=1, small G=2, then >= 1024 tiles (the resident-weight kernel), the last one ragged in both directions
 SIZES_F16 = [(40, 56), (180, 320), (128, 512), (256, 512), (264, 520)]
 
 
@@ -351,10 +350,6 @@ def test_f16_mirror_and_fp16_sources_are_bit_identical(hw, with_par):
     o16 = ops.conv3x3_f16_maps([x], [wt], out_f16=True, **kw)                                   # fp16 output: no residual
     assert torch.equal(o16, _h16(ops.conv3x3_f16_maps([x], [wt], **kw)))
     assert torch.equal(ops.conv3x3_f16_maps([x16], [wt], out_f16=True, **kw), o16)              # fp16 in, fp16 out (new)
-    # from 1024 tiles on an fp16 source selects the wide kernel (16x16 tiles, 64 px x 64 ch per wave); switched off, the
-    # resident-weight kernel must give the same bits
-    assert torch.equal(ops.conv3x3_f16_maps([x16], [wt], residual=res, no_wide=True, **kw), base)
-    assert torch.equal(ops.conv3x3_f16_maps([x16], [wt], out_f16=True, no_wide=True, **kw), o16)
 
 
 @pytest.mark.parametrize('hw', SIZES_F16 + [(720, 1280)], ids=lambda s: '%dx%d' % s)
@@ -375,7 +370,7 @@ def test_f16_partition_branch_skipping_is_value_identical(hw):
     assert set(int(v) for v in flags.unique().tolist()) >= {0, 7} and flags.numel() == ((h + 7) // 8) * ((w + 15) // 16)
     kw = dict(bias=G(gu.syn.uniform(52, 'b', (64,), -0.1, 0.1)), gamma=G(gu.syn.uniform(52, 'g', (64,), 0.5, 1.5)),
               packed_w1x1=w1, par=par, act=1)
-    for src in (x, _h16(x)):                                  # fp16 source: the wide kernel from 1024 tiles on
+    for src in (x, _h16(x)):                                  # fp32 source rounded on the fly / fp16 mirror
         for extra in (dict(), dict(out_f16=True)):
             a = ops.conv3x3_f16_maps([src], [wt], **kw, **extra)
             b = ops.conv3x3_f16_maps([src], [wt], par_flags=flags, **kw, **extra)
@@ -472,29 +467,6 @@ def test_f16_mirrors_and_one_launch_input_conv_leave_the_clip_bit_identical(name
     assert torch.isfinite(out).all() and torch.equal(out, ref), float((out - ref).abs().max())
     m.set_option(_native.OPT_PAR_SKIP, 0)
     assert torch.equal(run(), ref)
-
-
-@pytest.mark.parametrize('hw', [(720, 1280), (264, 520)], ids=lambda s: '%dx%d' % s)
-def test_wide_f16_kernel_leaves_the_clip_bit_identical(hw):
-    """PNP_OPT_WIDE_F16 0 / 1 on frames with >= 1024 tiles (720p; 264x520 is ragged for 8- and 16-row tiles and 16-column tiles):
-    the BAE-block convs and conv_hr on the wide kernel against the resident-weight kernel -- same bits."""
-    from pnp_vcve_amd import _native
-    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
-    sd_np = gu.syn.make_state_dict(cfg, seed=161, par_gain=10.0)
-    clip = gu.syn.make_clip(seed=162, n=1, t=3, h=hw[0], w=hw[1], slices='IBBBP', block=4, par_classes=3)
-    m = _gen_model(cfg, sd_np)
-    m.fp16_enabled = True
-    a = {k: G(v) for k, v in clip.items()}
-
-    def run():
-        with torch.no_grad():
-            return m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']).clone()
-
-    m.set_option(_native.OPT_WIDE_F16, 0)
-    ref = run()
-    m.set_option(_native.OPT_WIDE_F16, 1)
-    out = run()
-    assert torch.isfinite(out).all() and torch.equal(out, ref), float((out - ref).abs().max())
 
 
 @pytest.mark.parametrize('hw', [(180, 320), (720, 1280)], ids=lambda s: '%dx%d' % s)

@@ -206,6 +206,74 @@ def test_long_clip_720p_fits_and_runs():
     assert float((out - lq).abs().mean()) < 0.2
 
 
+def _gpu_clip(t, h, w, seed, pattern, mv_q=16):
+    """a synthetic clip made on the device (a 100-frame 720p clip is 3.7 GB of inputs: no host copies)"""
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    lq = torch.rand(1, t, 3, h, w, device='cuda', generator=g)
+    mvs = (torch.randint(-mv_q, mv_q + 1, (1, t, 4, h // 8, w // 8), device='cuda', generator=g).float() / 4
+           ).repeat_interleave(8, 3).repeat_interleave(8, 4).contiguous()
+    cls = torch.randint(0, 3, (1, t, 1, h // 8, w // 8), device='cuda', generator=g)
+    par = (torch.cat([(cls == j) for j in range(3)], dim=2).float() / 255.0).repeat_interleave(8, 3).repeat_interleave(8, 4).contiguous()
+    sl = torch.tensor(pattern, dtype=torch.float32, device='cuda').view(1, t, 1, 1, 1)
+    qp = torch.full((1, t, 1, 1, 1), 28 / 255.0, device='cuda')
+    bq = torch.full((1, t, 1, 1, 1), 25 / 255.0, device='cuda')
+    return dict(lq=lq, QPs=qp, slices=sl, mvs=mvs, base_QPs=bq, partitions=par)
+
+
+def _fwd(m, c):
+    with torch.no_grad():
+        return m(c['lq'], c['QPs'], c['slices'], c['mvs'], c['base_QPs'], c['partitions'])
+
+
+def test_reference_clip_length_t100_at_720p_shipped_config():
+    """The reference evaluates whole 100-frame REDS clips (configs/HR_davis_LR_128x128.py:202) at 1280x720: 100 live feature
+    slots = 24.5 GB of workspace + 4.8 GB of inputs and output, slot offsets far beyond 4 GiB.  Shipped configuration.  Every
+    frame depends on every other one here (neighbour features chain through all 100 frames), so no crop can reproduce it; what is
+    checked: finite output, the residual head stays near the input, and -- after the cached workspace has been overwritten with
+    NaN bit patterns -- a second forward returns the same bits (every byte the schedule reads, it wrote in this call)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    m = build(cfg, gu.syn.make_state_dict(cfg, seed=89))
+    t, h, w = 100, 720, 1280
+    c = _gpu_clip(t, h, w, 5, [73.0 if i == 0 else (80.0 if i % 4 == 0 else 66.0) for i in range(t)])
+    out = _fwd(m, c)
+    assert out.shape == (1, t, 3, h, w) and torch.isfinite(out).all()
+    assert float((out - c['lq']).abs().mean()) < 0.2
+    (key, ws), = m._workspace.items()
+    assert ws.numel() > 24 * 10**9 and key[1:4] == (t, h, w)
+    ws.fill_(0xFF)                                        # NaN bit patterns everywhere in the 24.5 GB
+    again = _fwd(m, c)
+    assert torch.equal(again, out)
+    del out, again
+    torch.cuda.empty_cache()
+
+
+def test_t100_at_720p_equals_a_crop_far_from_the_border():
+    """T = 100 at 1280x720 against T = 100 on a 384x384 crop, all frames, bit-level tolerance.  With `with_cat=False` and only the
+    clip ends as key frames (all-B slices) a frame depends on its own pixels and on the two end frames only (backward feature of
+    the last frame -> every backward feature; forward feature of frame 0 -> every forward feature): a receptive field of
+    4 x 17 convolution pixels + 2 MV hops of <= 4 px, whatever T is -- so the central 128x128 of the crop must reproduce the
+    full-frame result.  This is the full-size check of slot addressing / the long-clip schedule that the shipped configuration
+    (every frame coupled to every other one) cannot give."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, with_cat=False)
+    m = build(cfg, gu.syn.make_state_dict(cfg, seed=90, par_gain=10.0))
+    t, h, w = 100, 720, 1280
+    c = _gpu_clip(t, h, w, 6, [73.0] + [66.0] * (t - 1), mv_q=16)
+    full = _fwd(m, c)
+    assert torch.isfinite(full).all()
+    y0, x0, s = 168, 448, 384                       # crop origin on the 8x8 block grid, 128 px of margin around the compared centre
+    cc = {k: (v[..., y0:y0 + s, x0:x0 + s].contiguous() if v.shape[-1] == w else v) for k, v in c.items()}
+    crop = _fwd(m, cc)
+    a = full[..., y0 + 128:y0 + 256, x0 + 128:x0 + 256]
+    b = crop[..., 128:256, 128:256]
+    d = float((a - b).abs().max())
+    print('T=100 720p vs 384x384 crop, central 128x128, all 100 frames: max|d| =', d)
+    assert d < 1e-5
+    # and the property is not vacuous: nearer to the crop border the two DO differ (zero padding reaches in)
+    assert float((full[..., y0:y0 + 16, x0:x0 + s] - crop[..., 0:16, :]).abs().max()) > 1e-4
+    del full, crop
+    torch.cuda.empty_cache()
+
+
 def test_randomised_configs_and_shapes_vs_oracle():
     """12 seeded random draws over the constructor switches, clip length, frame size, slice pattern and batch
     size -- every draw against the pinned oracle (the reference's own option space)."""

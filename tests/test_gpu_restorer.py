@@ -177,8 +177,11 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert 0 < r['frac_dense_par'] <= r['algorithmic_frac'] * 1.02
     assert 'U{0,1,2}' in d['config']['workload']
     sec = d['secondary']
-    assert len(sec) == 6
-    for e in sec:
+    assert len(sec) == 7
+    e2e = sec[6]                                   # the whole tools/test.py loop on an on-disk tree
+    assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
+    assert e2e['seconds_total'] >= e2e['seconds_generator_forward'] > 0
+    for e in sec[:6]:
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
             assert e['roofline']['frac'] > 0 and e['launches_per_frame'] > 0

@@ -58,16 +58,12 @@ kw = dict(bias=bias, gamma=gam, packed_w1x1=p1, par=par, act=1)
 timeit('front  r02: fp32 x -> fp16 o, all branches', lambda i: F([xs[i % NB]], [pw], out_f16=True, **kw), 396)
 timeit('front     : fp32 x -> fp16 o, branch skipping', lambda i: F([xs[i % NB]], [pw], out_f16=True, par_flags=flags, **kw), 396)
 timeit('front     : fp16 x -> fp16 o, all branches', lambda i: F([xs16[i % NB]], [pw], out_f16=True, **kw), 268)
-timeit('front     : fp16 x -> fp16 o, all branches, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], out_f16=True, no_wide=True, **kw), 268)
-timeit('front     : fp16 x -> fp16 o, branch skipping, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], out_f16=True, par_flags=flags, no_wide=True, **kw), 268)
-timeit('front  r03: fp16 x -> fp16 o, branch skipping, WIDE kernel', lambda i: F([xs16[i % NB]], [pw], out_f16=True, par_flags=flags, **kw), 268)
-timeit('back   r02: fp16 o + fp32 residual -> fp32 x, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB], no_wide=True), 640)
-timeit('back      : ... + fp16 mirror, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB], mirror=True, no_wide=True), 768)
-timeit('back      : fp16 o + fp32 residual -> fp32 x, WIDE kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB]), 640)
-timeit('back   r03: ... + fp16 mirror, WIDE kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB], mirror=True), 768)
+timeit('front     : fp16 x -> fp16 o, all branches, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], out_f16=True, **kw), 268)
+timeit('front     : fp16 x -> fp16 o, branch skipping, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], out_f16=True, par_flags=flags, **kw), 268)
+timeit('back   r02: fp16 o + fp32 residual -> fp32 x, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB]), 640)
+timeit('back      : ... + fp16 mirror, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB], mirror=True), 768)
 timeit('conv_hr r02: fp32 -> fp16', lambda i: F([xs[i % NB]], [pw], bias=bias, act=2, out_f16=True), 384)
-timeit('conv_hr    : fp16 -> fp16, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, act=2, out_f16=True, no_wide=True), 256)
-timeit('conv_hr r03: fp16 -> fp16, WIDE kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, act=2, out_f16=True), 256)
+timeit('conv_hr    : fp16 -> fp16, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, act=2, out_f16=True), 256)
 for nw in (1, 2, 3):
     s32 = [xs[(j + 1) % NB] for j in range(nw)]
     s16 = [xs16[(j + 1) % NB] for j in range(nw)]
@@ -95,21 +91,5 @@ if '--trace' in sys.argv:
             print(f'    {nm:30s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}')
     if ((h + 7) // 8) * ((w + 15) // 16) >= 1024:
         trace('front r02 (fp32 x, all branches)', lambda t: F([xs[0]], [pw], out_f16=True, trace=t, **kw))
-        trace('front (fp16 x, skipping), resident-weight kernel', lambda t: F([xs16[0]], [pw], out_f16=True, par_flags=flags, no_wide=True, trace=t, **kw))
-        trace('back (+ mirror), resident-weight kernel', lambda t: F([xs16[0]], [pw], bias=bias, residual=rs[0], mirror=True, no_wide=True, trace=t))
-
-        def trace_wide(name, fn):
-            nt = ((h + 15) // 16) * ((w + 15) // 16)
-            dbg = torch.zeros(nt * 16, dtype=torch.int64, device=dev)
-            for i in range(3):
-                fn(None)
-            fn(dbg)
-            torch.cuda.synchronize()
-            d = dbg.cpu().numpy().reshape(nt, 16)
-            d = d[d[:, 7] > 0]
-            print(f'--- timeline {name}: blocks {len(d)} (one 16x16 tile each)')
-            for nm, v in (('prologue (halo, first chunks)', d[:, 1] - d[:, 0]), ('K loop', d[:, 2] - d[:, 1]), ('epilogue', d[:, 3] - d[:, 2]),
-                          ('block total', d[:, 3] - d[:, 0])):
-                print(f'    {nm:30s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}')
-        trace_wide('front WIDE (fp16 x, skipping)', lambda t: F([xs16[0]], [pw], out_f16=True, par_flags=flags, trace=t, **kw))
-        trace_wide('back WIDE (+ mirror)', lambda t: F([xs16[0]], [pw], bias=bias, residual=rs[0], mirror=True, trace=t))
+        trace('front (fp16 x, skipping), resident-weight kernel', lambda t: F([xs16[0]], [pw], out_f16=True, par_flags=flags, trace=t, **kw))
+        trace('back (+ mirror), resident-weight kernel', lambda t: F([xs16[0]], [pw], bias=bias, residual=rs[0], mirror=True, trace=t))
