@@ -33,7 +33,8 @@ int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs_dev, const int* src_ch
 
 /* The modulated deformable conv of pnpvcve.h with an optional timeline buffer: 8 u64 per wave (8 waves per block,
  * one block per CU): shader-clock sums of window fill, prologue, gather, MFMA, barrier + weight hand-over, epilogue,
- * total, tiles. */
+ * total, tiles.  The buffer must hold pnp_dcn_trace_u64s() elements (the launch has one block per CU of the current device). */
+int pnp_dcn_trace_u64s(void);
 int pnp_dcn_nhwc_f32_ex(const float* x_dev, const float* om_dev, const float* flow_x_dev, const float* flow_y_dev,
                         const float* w_packed_dev, const float* bias_dev, float* out_dev, int h, int w, void* trace_dev,
                         void* stream);

@@ -14,5 +14,7 @@ struct DcnArgs {
     unsigned long long* dbg;   // diagnostic timeline (pnp_dcn_nhwc_f32_ex): 8 u64 per wave, or nullptr
 };
 int launch_dcn(const DcnArgs& a, hipStream_t stream);
+// u64 elements DcnArgs::dbg must hold on the current device (8 per wave, 8 waves per block, one block per CU), -1 on error
+int dcn_trace_u64s();
 // fp32 B image (9 chunks) -> the fp16 image of DcnArgs::w16 (9 * 4096 halfs)
 int launch_dcn_f16_image(const float* packed_w, void* dst, hipStream_t stream);

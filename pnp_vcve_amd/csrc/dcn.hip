@@ -338,13 +338,15 @@ int launch_dcn_f16_image(const float* packed_w, void* dst, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-int launch_dcn(const DcnArgs& a, hipStream_t stream) {
+// blocks of a launch on the current device (one resident block per CU) + the one-time kernel attributes
+static hipError_t dcn_setup(int* grid_out) {
     static PnpPerDevice once;
     int grid = 256;
     const hipError_t attr_err = once.run([](int dev, int& g) {
         g = 256;
         (void)hipDeviceGetAttribute(&g, hipDeviceAttributeMultiprocessorCount, dev);      // one resident block per CU
         g -= g % 8;
+        if (g < 8) g = 8;        // a device / partition exposing fewer than 8 CUs: the strips are dealt over blockIdx.x % 8
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_window_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e == hipSuccess)
@@ -352,6 +354,18 @@ int launch_dcn(const DcnArgs& a, hipStream_t stream) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return e;
     }, &grid);
+    *grid_out = grid;
+    return attr_err;
+}
+
+int dcn_trace_u64s() {
+    int grid = 0;
+    return dcn_setup(&grid) == hipSuccess ? grid * 8 * 8 : -1;      // 8 u64 per wave, 8 waves per block
+}
+
+int launch_dcn(const DcnArgs& a, hipStream_t stream) {
+    int grid = 256;
+    const hipError_t attr_err = dcn_setup(&grid);
     if (attr_err != hipSuccess) return (int)attr_err;
     if (a.w16) hipLaunchKernelGGL(dcn_window_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, stream, a);
     else hipLaunchKernelGGL(dcn_window_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, stream, a);

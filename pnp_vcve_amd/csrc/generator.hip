@@ -1086,6 +1086,8 @@ int pnp_dcn_nhwc_f32_ex(const float* x, const float* om, const float* fx, const 
 
 int pnp_dcn_ref_channel(int packed_channel) { return pnp_dcn_ref_channel_impl(packed_channel); }
 
+int pnp_dcn_trace_u64s(void) { return dcn_trace_u64s(); }
+
 int64_t pnp_packed_conv_floats(int csrc) { return csrc == 64 ? IMG_WIDE : IMG_CHUNK; }
 
 int pnp_pack_conv3x3_f32(const float* w, const float* ew, int E, int cout, int cin_total, int cbase, int csrc,

@@ -375,6 +375,7 @@ int launch_dcn(const DcnArgs& a, hipStream_t s) {
     ++stub::dcn_calls;
     return 0;
 }
+int dcn_trace_u64s() { return 256 * 64; }
 int launch_dcn_f16_image(const float* w, void* dst, hipStream_t s) {
     stub::cur = "launch_dcn_f16_image";
     stub::note_launch(s);

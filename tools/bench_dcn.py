@@ -56,10 +56,11 @@ us = e0.elapsed_time(e1) * 100
 print(f'fp16 MFMA operands, flow=True: {us:8.1f} us  {2240 * h * w / us / 1e3:7.0f} GB/s of 2240 B/px')
 
 # per-phase shader-clock sums (include/pnpvcve_debug.h)
-dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+nq = L.pnp_dcn_trace_u64s()                # 8 u64 per wave x 8 waves per block x one block per CU of THIS device
+dbg = torch.zeros(nq, dtype=torch.int64, device=dev)
 L.pnp_dcn_nhwc_f32_ex(P(x), P(om), P(flow[0]), P(flow[1]), P(wp), P(bias), P(out), h, w, P(dbg), st)
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(256, 8, 8).astype(np.float64)
+d = dbg.cpu().numpy().reshape(nq // 64, 8, 8).astype(np.float64)
 n = np.maximum(d[..., 7], 1)
 for grp, nm in ((slice(0, 4), 'group A (gather, then MFMA)'), (slice(4, 8), 'group B (MFMA, then gather)')):
     print(nm, 'tiles/wave', n[:, grp].mean())
