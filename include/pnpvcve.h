@@ -71,7 +71,7 @@ int pnp_generator_set_precision(pnp_generator* g, int precision);
 int pnp_generator_get_precision(const pnp_generator* g);
 
 /* Per-generator execution switches (A/B and diagnostic; results are bit-identical either way unless stated).
- * value 0/1; all default to 1.  State lives in the handle. */
+ * value 0/1; all default to 1 except PNP_OPT_F16_CHAIN_MIRRORS.  State lives in the handle. */
 #define PNP_OPT_F16_MAPS 0       /* PNP_PREC_F16: the map between the two halves of a BAE block / behind conv_hr is stored fp16 */
 #define PNP_OPT_PAR_SKIP 1       /* skip 1x1 partition branches whose plane is all zero on a tile (exact zeros) */
 #define PNP_OPT_CONV_LAST_VALU 2 /* conv_last on the vector ALUs (<= 2e-6 from the MFMA kernel: other summation order) */
@@ -85,7 +85,9 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     operand (the running map of a branch, the frame slots, the MV-aligned key frame) gets an fp16 copy
                                     from its producer, and the input conv of a branch runs as ONE launch over those copies instead of
                                     a chain of single-source launches through fp32 partial sums.  Bit-identical: same rounding points */
-#define PNP_OPT_COUNT 7
+#define PNP_OPT_F16_CHAIN_MIRRORS 7 /* with PNP_OPT_F16_MIRRORS: also mirror the running map x inside a branch (default 0: measured
+                                    neutral at 720p -- the back half writes 128 B per pixel more for what the front half reads less) */
+#define PNP_OPT_COUNT 8
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 

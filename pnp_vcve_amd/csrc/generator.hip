@@ -66,7 +66,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
-    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1};   // pnp_generator_set_option (defaults: everything on)
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0};   // pnp_generator_set_option (defaults: everything on)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -593,6 +593,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     const bool par_skip = g->opt[PNP_OPT_PAR_SKIP] != 0;
     // every 64-channel map that is only read as an MFMA A operand gets an fp16 copy from its producer
     const bool mirrors = f16_maps && g->opt[PNP_OPT_F16_MIRRORS] && c.deform == 0 && W.x16 != nullptr;
+    // ... and, optionally, the running map x INSIDE a branch too (input conv and every block write x16 next to x, every front
+    // half reads it).  Measured at 720p inside the pipeline (profiles/r03_fp16_*): the front half gains what the back half loses
+    // to the extra 128 B per pixel it writes -- off by default, the frame slots keep their mirrors.
+    const bool chain16 = mirrors && g->opt[PNP_OPT_F16_CHAIN_MIRRORS];
     auto conv = [&](const ConvCall& q) -> int {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -782,14 +786,15 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
             // fp16 mirrors: the input conv writes x16 next to x when it runs on the fp16 kernels at all (an RGB-only one does not)
-            const void* x16 = (mirrors && in.nsrc > 1) ? W.x16 : nullptr;
+            const void* x16 = (chain16 && in.nsrc > 1) ? W.x16 : nullptr;
             int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0).also16(const_cast<void*>(x16)));
             if (r) return r;
             const float* x = W.tmp0;
             for (int k = 0; k < c.num_blocks; ++k) {
                 const BlockPk& K = B.blocks[k];
                 float* dst = (k == c.num_blocks - 1) ? slot : W.tmp0;
-                void* dst16 = !mirrors ? nullptr : (k == c.num_blocks - 1) ? (void*)(W.slots16 + (int64_t)i * fm) : (void*)W.x16;
+                void* dst16 = !mirrors ? nullptr : (k == c.num_blocks - 1) ? (void*)(W.slots16 + (int64_t)i * fm)
+                                                                                 : (chain16 ? (void*)W.x16 : nullptr);
                 const float* w2 = W.mixw + ((int64_t)u * g->ndyn + K.dyn_conv2) * IMG_WIDE;
                 const float* b2 = W.mixb + ((int64_t)u * g->ndyn + K.dyn_conv2) * 64;
                 const float* w1 = c.one_layer ? packed + K.conv1_img
@@ -814,7 +819,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 }
                 if (r) return r;
                 x = dst;
-                x16 = dst16;
+                x16 = chain16 ? dst16 : nullptr;
             }
             return 0;
         };

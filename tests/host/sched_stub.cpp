@@ -395,7 +395,7 @@ struct Scenario {
     pnp_generator_cfg cfg;
     int prec, n, t, h, w, contexts, forwards, profile;
     std::vector<float> slices, qps, bqs;        // n * t each
-    int mirrors;                                // PNP_OPT_F16_MIRRORS
+    int mirrors;                                // 0 none, 1 PNP_OPT_F16_MIRRORS (default), 2 + PNP_OPT_F16_CHAIN_MIRRORS
 };
 
 pnp_generator_cfg default_cfg() {
@@ -433,7 +433,8 @@ int run(const Scenario& sc) {
         return 0;
     }
     pnp_generator_set_precision(g, sc.prec);
-    pnp_generator_set_option(g, PNP_OPT_F16_MIRRORS, sc.mirrors);
+    pnp_generator_set_option(g, PNP_OPT_F16_MIRRORS, sc.mirrors >= 1);
+    pnp_generator_set_option(g, PNP_OPT_F16_CHAIN_MIRRORS, sc.mirrors >= 2);
     const int64_t flat_n = pnp_generator_flat_floats(g), packed_n = pnp_generator_packed_floats(g);
     const int64_t ctx_bytes = pnp_generator_workspace_bytes(g, sc.t, sc.h, sc.w);
     const int64_t ws_bytes = ctx_bytes * sc.contexts;
@@ -647,6 +648,9 @@ int main(int argc, char** argv) {
         add(p + "p720_t2", d, prec, 1, 2, 720, 1280, 1, {"IBBBP"}, {25});
     }
     add("f16_nomirrors_ibbbp_t7", d, 1, 1, 7, 64, 96, 1, {"IBBBP"}, {25}, 1, 0, 0);
+    add("f16_chainmirrors_ibbbp_t7", d, 1, 1, 7, 64, 96, 1, {"IBBBP"}, {25}, 1, 0, 2);
+    add("f16_chainmirrors_channel_last_two_layer_t3", chlast, 1, 1, 3, 64, 64, 1, {"IBBBP"}, {25}, 1, 0, 2);
+    add("f16_chainmirrors_p720_t2", d, 1, 1, 2, 720, 1280, 1, {"IBBBP"}, {25}, 1, 0, 2);
     int bad = 0;
     for (const Scenario& s : all) {
         bool want = argc < 2;

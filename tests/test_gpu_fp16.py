@@ -465,6 +465,8 @@ def test_f16_mirrors_and_one_launch_input_conv_leave_the_clip_bit_identical(name
     m.set_option(_native.OPT_F16_MIRRORS, 1)
     out = run()
     assert torch.isfinite(out).all() and torch.equal(out, ref), float((out - ref).abs().max())
+    m.set_option(_native.OPT_F16_CHAIN_MIRRORS, 1)          # + the running map inside a branch (off by default)
+    assert torch.equal(run(), ref), 'chain mirrors'
     m.set_option(_native.OPT_PAR_SKIP, 0)
     assert torch.equal(run(), ref)
 

@@ -61,12 +61,14 @@ def test_scheduler_is_clean_under_asan_and_ubsan(stub_run):
     exe, r, docs, env = stub_run
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr and 'LeakSanitizer' not in r.stderr, r.stderr[-4000:]
-    assert len(docs) == 2 * len(EXPECT) + 1
+    assert len(docs) == 2 * len(EXPECT) + 4
     for name, d in docs.items():
         assert d['pack_rc'] == 0 and d['forward_rc'] == 0 and d['errors'] == [], (name, d['errors'])
         # no event or stream outlives its generator; the workspace handed over is exactly contexts x the advertised size
         assert d['live_events_after_destroy'] == 0 and d['live_streams_after_destroy'] == 0, name
-        base = name.split('_', 1)[1] if not name.startswith('f16_nomirrors') else 'ibbbp_t7'
+        base = name.split('_', 1)[1]
+        for pre in ('nomirrors_', 'chainmirrors_'):
+            base = base[len(pre):] if base.startswith(pre) else base
         assert d['workspace_bytes'] == EXPECT[base][2] * d['context_bytes'] and d['context_bytes'] % 256 == 0
 
 
@@ -156,12 +158,18 @@ def test_fp16_mirrors_are_scheduled_consistently(stub_run):
     launch and writes the mirror of its output; the stub's written-range bookkeeping (errors == []) already proved that no mirror
     is read before its producer ran -- here the masks show the mirrors are really in use, and absent with the option off."""
     _, _, docs, _ = stub_run
-    d, off = docs['f16_ibbbp_t7'], docs['f16_nomirrors_ibbbp_t7']
-    assert set(d['warp_f16']) == {1} and set(off['warp_f16']) == {0}
-    multi = [(ns, m) for ns, m, f in zip(d['conv_nsrc'], d['conv_map_mask'], d['conv_f16_path']) if ns > 1]
-    assert multi and all(m & 32 for _, m in multi)                                   # one launch, + mirror of the output
-    assert all((m & 0xF) == sum(1 << s for s in range(1, ns)) for ns, m in multi)    # every wide source through its mirror
+    d, off, chain = docs['f16_ibbbp_t7'], docs['f16_nomirrors_ibbbp_t7'], docs['f16_chainmirrors_ibbbp_t7']
+    assert set(d['warp_f16']) == {1} and set(chain['warp_f16']) == {1} and set(off['warp_f16']) == {0}
+    for doc, in_branch in ((d, False), (chain, True)):
+        multi = [(ns, m) for ns, m, f in zip(doc['conv_nsrc'], doc['conv_map_mask'], doc['conv_f16_path']) if ns > 1]
+        assert multi and all((m & 0xF) == sum(1 << s for s in range(1, ns)) for ns, m in multi)    # every wide source through its mirror
+        assert all(bool(m & 32) == in_branch for _, m in multi)          # the input conv mirrors its output only for the in-branch chain
+        single = [m for ns, m in zip(doc['conv_nsrc'], doc['conv_map_mask']) if ns == 1]
+        # default: one fp32 + mirror output per branch and frame (its last block: the frame slot); chain: every back half
+        assert sum(1 for m in single if m & 32) == (2 * 7 * 8 if in_branch else 2 * 7)
     assert not any(m & (32 | 0xE) for m in off['conv_map_mask'])
-    assert d['launches_first_forward'] == off['launches_first_forward']              # same launches, different maps
+    assert d['launches_first_forward'] == off['launches_first_forward'] == chain['launches_first_forward']     # same launches, different maps
+    for nm in ('f16_chainmirrors_channel_last_two_layer_t3', 'f16_chainmirrors_p720_t2'):
+        assert docs[nm]['errors'] == [] and docs[nm]['forward_rc'] == 0
     assert set(docs['f32_ibbbp_t7']['conv_map_mask']) == {0} and set(docs['f32_ibbbp_t7']['conv_f16_path']) == {0}
     assert set(docs['f16_basic_t3']['warp_f16']) == {0}                              # DCN aligners keep the r02 schedule

@@ -52,6 +52,14 @@ def variants(src):
         '        } else {\n            mfma_tap(av);\n            stamp(d_m);\n            gather(ky, kx, oo, om, nav);\n            stamp(d_g);\n        }',
         '        } else {\n            gather(ky, kx, oo, om, nav);\n            stamp(d_g);\n            mfma_tap(av);\n            stamp(d_m);\n        }')
     yield 'run_time_branch_same_order_in_both_arms', same, []
+    # is the rare global-memory fallback of gather() (a divergent region under `if (__any(outside))`) involved?
+    yield 'bad_without_global_fallback', bad.replace('if (__any(outside)) {', 'if (false && __any(outside)) {'), []
+    yield 'bad_fallback_always_taken', bad.replace('if (__any(outside)) {', 'if (true || __any(outside)) {'), []
+    # the accumulators pinned in one register range by an empty asm after each arm (no per-arm allocation, no copies)
+    pin = 'asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));'
+    yield 'bad_acc_pinned_after_arms', bad.replace('        if (++kx > 1) {', '        ' + pin + '\n        if (++kx > 1) {'), []
+    yield 'bad_sched_barriers_around_mfma', bad.replace(MFMA_F16_HEAD, MFMA_F16_HEAD + '            __builtin_amdgcn_sched_barrier(0);\n').replace(
+        MFMA_F16_TAIL, '            __builtin_amdgcn_sched_barrier(0);\n            ' + NOPS + '\n            __builtin_amdgcn_sched_barrier(0);\n' + MFMA_F16_TAIL), []
 
 
 def mfma_neighbourhoods(asm_path):
@@ -137,6 +145,14 @@ def main():
             if (h, w) == (72, 80):
                 with open(os.path.join(args.out, f'isa_{name}.txt'), 'w') as f:
                     f.write(f'# {name}: {stats}\n' + '\n'.join(nb) + '\n')
+            if d16 > 0 and (h, w) == (72, 80):          # where are the wrong elements?
+                bad = ((outs[-1] - ref16).abs() > 1e-3)
+                ys, xs, cs = bad.nonzero(as_tuple=True)
+                def hist(v, n):
+                    return torch.bincount(v, minlength=n).tolist()
+                report.append(f'    wrong elements by channel%32: {hist(cs % 32, 32)}')
+                report.append(f'    by channel//32 (N tile): {hist(cs // 32, 2)}   by row%8 (2*wave + (m>>4)): {hist(ys % 8, 8)}   by col%16: {hist(xs % 16, 16)}')
+                report.append(f'    distinct 8x16 tiles touched: {len(set(((ys // 8) * 100 + xs // 16).tolist()))} of {((h + 7) // 8) * ((w + 15) // 16)}')
             verdict = 'OK ' if distinct == 1 and d16 == 0.0 else ('DETERMINISTIC but differs' if distinct == 1 else 'NON-DETERMINISTIC')
             report.append(f'{name:45s} {verdict:28s} runs differing from run 0: {distinct - 1:2d}/{args.reps - 1}  max|d| vs shipped fp16 {d16:.3e}  '
                           f'vs fp32 {d32:.3e}  elements off by > 1e-3: {bad_elems}  {stats}')
