@@ -8,7 +8,11 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libpnpvcve_hip.so')
 SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_f16.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
-EXTRA_FLAGS = {}      # per-source extras (none at present)
+# per-source extras.  dcn.hip: hipcc's SLP vectoriser packs the scalar coordinate / weight arithmetic of the deformable gather into
+# v_pk_*_f32 pairs; every build with that packing gave wrong, run-to-run varying samples in the fp16 instantiation under some
+# timing (the round-2 code shape rarely, others always), every build without it is correct under every perturbation tried
+# (tools/repro/dcn_f16_hazard.py, profiles/r03_dcn_hazard_report.txt).
+EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize']}
 
 
 def _stale(target, deps):

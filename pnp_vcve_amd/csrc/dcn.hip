@@ -247,14 +247,17 @@ __global__ __launch_bounds__(512) void dcn_window_kernel(const DcnArgs a) {
         oo[1] = no[1];
         om = nm;
         if (k < 7) load_om(k + 2, no, nm);
-        // fp16: the contraction is 4 MFMAs per tap -- nothing to hide behind, both groups gather first, and the choice is
-        // made at COMPILE time on purpose.  With a run-time two-armed order (each arm updating the accumulators) hipcc keeps
-        // the accumulators in different registers per arm and copies them with v_mov around the loop; in the fp16
-        // instantiation those copies sit right next to v_mfma_f32_32x32x16_f16 and the kernel then produced corrupted,
-        // non-deterministic sums on gfx950 / ROCm 7.2 (three of a lane's four samples -- the ones whose registers overlapped
-        // an MFMA destination range -- in either execution order; s_nops and barriers did not help).  The straight-line form
-        // below has no accumulator copies; tests/test_gpu_ops.py checks the fp16 kernel for run-to-run determinism and against
-        // the fp32 kernel.  The fp32 instantiation (run-time order) is deterministic and oracle-exact.
+        // fp16: the contraction is 4 MFMAs per tap -- nothing to hide behind, so both groups gather first (compile-time choice).
+        // Round 2 found the fp16 instantiation giving corrupted, run-to-run varying sums with the run-time two-armed order.
+        // Round 3 (tools/repro/dcn_f16_hazard.py + four micro-repros, profiles/r03_dcn_hazard_report.txt): what gets corrupted is
+        // the A operand -- gathered samples of lanes 16..31 / 48..63 -- not the accumulators; it needs the divergent global-memory
+        // fallback of gather() to be present and hipcc's SLP packing of the scalar gather arithmetic into v_pk_*_f32 pairs; it is
+        // timing dependent and also hits THIS code shape (rarely: 732 of 59 M elements in one of ~10 runs at 720p; always with
+        // -amdgpu-waitcnt-forcezero).  Built with -fno-slp-vectorize (pnp_vcve_amd/build_native.py) every shape, including the
+        // run-time order, is correct and bit-stable under every perturbation tried.  The hardware itself was cleared: MFMA
+        // destination registers become readable 4 / 8 / 12 wait states after issue (dst[0] / [8] / [15]; hipcc waits 12), SrcA /
+        // SrcB may be overwritten at once, SrcC (C != D) after 4, narrowing EXEC behind an MFMA is harmless, and VALU / trans /
+        // packed / DPP / v_mov_b64 / LDS work beside MFMAs of the same or the partner wave is exact.
         if (F16 || grp == 0) {
             gather(ky, kx, oo, om, nav);
             stamp(d_g);

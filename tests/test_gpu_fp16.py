@@ -514,3 +514,25 @@ def test_f16_path_is_bit_identical_to_the_round_2_build(case):
     got = _pc.digest(out)
     assert got['shape'] == pin['shape']
     assert got['sha256'] == pin['sha256'], (case['name'], got['mean'], pin['mean'], got['first'], pin['first'])
+
+
+@pytest.mark.parametrize('deform', ['basic', 'fvc'])
+def test_f16_generator_with_dcn_aligner_is_run_to_run_deterministic(deform):
+    """deform='basic' | 'fvc' in fp16 at a size with several tiles per block (264 x 520): the whole generator four times, bit
+    for bit (the DCN kernel's fp16 instantiation was the one non-deterministic kernel of round 2)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2, deform=deform)
+    sd_np = gu.syn.make_state_dict(cfg, seed=171, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=172, n=1, t=3, h=264, w=520, slices='IBBBP', block=4, par_classes=3)
+    m = _gen_model(cfg, sd_np)
+    m.fp16_enabled = True
+    a = {k: G(v) for k, v in clip.items()}
+
+    def run():
+        with torch.no_grad():
+            return m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']).clone()
+
+    first = run()
+    assert torch.isfinite(first).all()
+    for rep in range(3):
+        torch.randn(1 << 22, device=dev()).sin_()
+        assert torch.equal(run(), first), rep

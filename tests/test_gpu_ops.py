@@ -358,6 +358,33 @@ def test_modulated_deform_conv_fp16_operands_track_fp32(with_flow):
     assert 0.0 < d < 4e-3 * scale
 
 
+def test_dcn_fp16_is_bit_stable_at_720p_under_traffic():
+    """The fp16 DCN kernel at full size (28 tiles per block, global-memory fallback samples included), 10 runs with unrelated
+    device traffic in between: bit-identical every time and within operand rounding of the fp32 kernel everywhere.  Round 2's
+    build (gather arithmetic SLP-packed into v_pk_*_f32) failed this in about one run of ten with a few hundred elements off by
+    up to 0.1 (profiles/r03_dcn_hazard_report.txt); dcn.hip is built with -fno-slp-vectorize since."""
+    from pnp_vcve_amd import ops
+    h, w = 720, 1280
+    g = torch.Generator(device=dev()).manual_seed(7)
+    x = torch.randn(h, w, 64, device=dev(), generator=g)
+    off = torch.randn(288, h, w, device=dev(), generator=g) * 1.5
+    ml = torch.randn(144, h, w, device=dev(), generator=g)
+    blk = torch.randint(-16, 17, (2, h // 8, w // 8), device=dev(), generator=g).float() / 4
+    flow = blk.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()
+    wt = torch.randn(64, 64, 3, 3, device=dev(), generator=g) * 0.05
+    b = torch.randn(64, device=dev(), generator=g) * 0.1
+    o32 = ops.modulated_deform_conv_nhwc(x, off, ml, wt, b, flow=flow)
+    o16 = ops.modulated_deform_conv_nhwc(x, off, ml, wt, b, flow=flow, fp16=True)
+    scale = float(o32.abs().max())
+    assert float((o16 - o32).abs().max()) < 4e-3 * scale
+    for rep in range(10):
+        torch.randn(1 << 22, device=dev()).sin_()
+        again = ops.modulated_deform_conv_nhwc(x, off, ml, wt, b, flow=flow, fp16=True)
+        assert torch.equal(again, o16), (rep, int((again != o16).sum()))
+        if rep % 3 == 0:
+            assert torch.equal(ops.modulated_deform_conv_nhwc(x, off, ml, wt, b, flow=flow), o32)
+
+
 @pytest.mark.parametrize('fp16', [False, True], ids=['fp32', 'fp16'])
 def test_dcn_at_720p_collapses_to_the_conv_kernel_and_to_a_shifted_conv(fp16):
     """full-size properties of the DCN kernel (persistent blocks, LDS windows): with zero offsets and saturated masks it is

@@ -47,11 +47,29 @@ def variants(src):
     # the same bad source with the machine scheduler's MFMA-aware pass / hazard padding knobs
     yield 'bad_mfma_padding_100', bad, ['-mllvm', '-amdgpu-mfma-padding-ratio=100']
     yield 'bad_O1', bad, ['-O1']
+    yield 'bad_O2', bad, ['-O2']
+    # which compiler stage?  (all on the bad source)
+    yield 'bad_waitcnt_forcezero', bad, ['-mllvm', '-amdgpu-waitcnt-forcezero=1']          # s_waitcnt 0 behind every instruction
+    yield 'bad_waitcnt_force_vm', bad, ['-mllvm', '-amdgpu-waitcnt-forcevm=1']
+    yield 'bad_waitcnt_force_lgkm', bad, ['-mllvm', '-amdgpu-waitcnt-forcelgkm=1']
+    yield 'bad_no_slp', bad, ['-fno-slp-vectorize']
+    yield 'bad_no_postRA_sched', bad, ['-mllvm', '-enable-post-misched=0']
+    yield 'bad_no_misched', bad, ['-mllvm', '-enable-misched=0']
+    yield 'bad_no_machine_sink', bad, ['-mllvm', '-disable-machine-sink']
+    yield 'bad_no_exec_mask_opt', bad, ['-mllvm', '-amdgpu-enable-pre-ra-optimizations=0']
+    yield 'good_waitcnt_forcezero', src, ['-mllvm', '-amdgpu-waitcnt-forcezero=1']
+    # candidate fix: no SLP vectorisation (no v_pk_*_f32 in the gather) -- under every timing perturbation that broke the others
+    yield 'good_no_slp', src, ['-fno-slp-vectorize']
+    yield 'good_no_slp_waitcnt_forcezero', src, ['-fno-slp-vectorize', '-mllvm', '-amdgpu-waitcnt-forcezero=1']
+    yield 'bad_no_slp_waitcnt_forcezero', bad, ['-fno-slp-vectorize', '-mllvm', '-amdgpu-waitcnt-forcezero=1']
+    yield 'bad_no_slp_nops_both', bad.replace(MFMA_F16_TAIL, '            ' + NOPS + '\n' + MFMA_F16_TAIL).replace(
+        MFMA_F16_HEAD, MFMA_F16_HEAD + '            ' + NOPS + '\n'), ['-fno-slp-vectorize']
     # both arms gather first, but still selected at run time (two copies of the same arm): accumulator copies without reordering
     same = src.replace(GOOD, 'if (grp == 0) {').replace(
         '        } else {\n            mfma_tap(av);\n            stamp(d_m);\n            gather(ky, kx, oo, om, nav);\n            stamp(d_g);\n        }',
         '        } else {\n            gather(ky, kx, oo, om, nav);\n            stamp(d_g);\n            mfma_tap(av);\n            stamp(d_m);\n        }')
     yield 'run_time_branch_same_order_in_both_arms', same, []
+    yield 'same_order_no_slp', same, ['-fno-slp-vectorize']
     # is the rare global-memory fallback of gather() (a divergent region under `if (__any(outside))`) involved?
     yield 'bad_without_global_fallback', bad.replace('if (__any(outside)) {', 'if (false && __any(outside)) {'), []
     yield 'bad_fallback_always_taken', bad.replace('if (__any(outside)) {', 'if (true || __any(outside)) {'), []
@@ -153,6 +171,31 @@ def main():
                 report.append(f'    wrong elements by channel%32: {hist(cs % 32, 32)}')
                 report.append(f'    by channel//32 (N tile): {hist(cs // 32, 2)}   by row%8 (2*wave + (m>>4)): {hist(ys % 8, 8)}   by col%16: {hist(xs % 16, 16)}')
                 report.append(f'    distinct 8x16 tiles touched: {len(set(((ys // 8) * 100 + xs // 16).tolist()))} of {((h + 7) // 8) * ((w + 15) // 16)}')
+                # a wrong A operand (a sample) spoils all 64 channels of its pixel (both N tiles share it); a wrong accumulator
+                # half spoils the 32 channels of ONE N tile
+                n0_, n1_ = bad[..., :32].sum(-1), bad[..., 32:].sum(-1)
+                pix = (n0_ + n1_) > 0
+                report.append(f'    wrong pixels {int(pix.sum())}: both N tiles wrong {int(((n0_ > 0) & (n1_ > 0)).sum())}, only channels 0..31 {int(((n0_ > 0) & (n1_ == 0)).sum())}, '
+                              f'only channels 32..63 {int(((n0_ == 0) & (n1_ > 0)).sum())}; wrong channels per wrong pixel: mean {float((n0_ + n1_)[pix].float().mean()):.1f}')
+                # are whole 16-pixel rows of a wave wrong together?
+                rows = bad.any(-1)
+                rr = rows.view(h // 8 if h % 8 == 0 else -1, 8, -1) if h % 8 == 0 else None
+                if rr is not None and w % 16 == 0:
+                    seg = rows.view(h, w // 16, 16).sum(-1)
+                    report.append(f'    wrong pixels per (image row, 16-pixel segment) where any is wrong: histogram {torch.bincount(seg[seg > 0].flatten(), minlength=17).tolist()}')
+            if d16 > 0 and (h, w) == (72, 80) and name == 'bad_run_time_order':
+                # what do the wrong values look like?  candidates: the sum over taps >= k0 only (the accumulator lost what it held
+                # before tap k0: SrcC read wrong) or over taps < k0 only (updates from tap k0 on were lost)
+                o = outs[-1]
+                badm = (o - ref16).abs() > 1e-3
+                for k0 in range(1, 9):
+                    wz = wt.clone()
+                    wz.view(64, 64, 9)[:, :, :k0] = 0                      # taps 0 .. k0-1 removed
+                    tail = ops.modulated_deform_conv_nhwc(x, off, mk, wz, bias, flow=flow, fp16=True)       # bias + taps >= k0
+                    head = ref16 - tail + bias.view(1, 1, 64)                                             # bias + taps < k0
+                    m_tail = int(((o - tail).abs() < 2e-3)[badm].sum())
+                    m_head = int(((o - head).abs() < 2e-3)[badm].sum())
+                    report.append(f'    wrong elements that equal bias + taps >= {k0} only: {m_tail:6d}   bias + taps < {k0} only: {m_head:6d}   (of {int(badm.sum())})')
             verdict = 'OK ' if distinct == 1 and d16 == 0.0 else ('DETERMINISTIC but differs' if distinct == 1 else 'NON-DETERMINISTIC')
             report.append(f'{name:45s} {verdict:28s} runs differing from run 0: {distinct - 1:2d}/{args.reps - 1}  max|d| vs shipped fp16 {d16:.3e}  '
                           f'vs fp32 {d32:.3e}  elements off by > 1e-3: {bad_elems}  {stats}')
