@@ -56,7 +56,6 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-kernel HIP-event timing')
     ap.add_argument('--no-secondary', action='store_true', help='skip the other BASELINE workloads after the headline')
-    ap.add_argument('--no-wide-f16', action='store_true', help='fp16 path A/B: front halves on the resident-weight kernel (PNP_OPT_WIDE_F16 0)')
     ap.add_argument('--f16-mirrors', type=int, default=None, choices=[0, 1, 2],
                     help='fp16 path A/B: 0 no fp16 mirrors (r02 schedule), 1 frame slots + aligned key frame (default), 2 also the '
                          'running map inside a branch (PNP_OPT_F16_CHAIN_MIRRORS)')
@@ -215,7 +214,6 @@ def cpu_baseline_128(T):
 
 
 F16_MIRRORS = None      # --f16-mirrors
-NO_WIDE_F16 = False     # --no-wide-f16
 
 
 def build_model(cfg, sd_np, dev, precision, graphs=False):
@@ -226,9 +224,6 @@ def build_model(cfg, sd_np, dev, precision, graphs=False):
     m = m.to(dev).eval()
     m.fp16_enabled = precision == 'fp16'
     m.use_graphs = bool(graphs)
-    if NO_WIDE_F16:
-        from pnp_vcve_amd import _native
-        m.set_option(_native.OPT_WIDE_F16, 0)
     if F16_MIRRORS is not None:
         from pnp_vcve_amd import _native
         m.set_option(_native.OPT_F16_MIRRORS, 1 if F16_MIRRORS >= 1 else 0)
@@ -408,8 +403,8 @@ def workload_text(clips, T, h, w, workload, cfg, precision):
 
 def main():
     args = parse_args()
-    global F16_MIRRORS, NO_WIDE_F16
-    F16_MIRRORS, NO_WIDE_F16 = args.f16_mirrors, args.no_wide_f16
+    global F16_MIRRORS
+    F16_MIRRORS = args.f16_mirrors
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 

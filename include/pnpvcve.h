@@ -87,10 +87,7 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     a chain of single-source launches through fp32 partial sums.  Bit-identical: same rounding points */
 #define PNP_OPT_F16_CHAIN_MIRRORS 7 /* with PNP_OPT_F16_MIRRORS: also mirror the running map x inside a branch (default 0: measured
                                     neutral at 720p -- the back half writes 128 B per pixel more for what the front half reads less) */
-#define PNP_OPT_WIDE_F16 8       /* PNP_PREC_F16, frames with >= 1024 tiles: a single-source conv from an fp32 map to an fp16 map (the front
-                                    half of a BAE block) runs on the wide kernel (16x16 tiles, 64 px x 64 ch per wave, weights streamed
-                                    through an LDS ring, two free-running blocks per CU).  Bit-identical */
-#define PNP_OPT_COUNT 9
+#define PNP_OPT_COUNT 8
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 

@@ -43,8 +43,8 @@ int pnp_dcn_nhwc_f32_ex(const float* x_dev, const float* om_dev, const float* fl
  * PNP_OPT_F16_MIRRORS.  Bit s of src_f16_mask: srcs_dev[s] IS an fp16 NHWC64 map (else fp32); out_f16: out_dev is an fp16 map
  * (single source, no residual); out16_dev (optional, only with an fp32 out_dev): an fp16 copy of the output written in the same
  * pass; par_flags_dev: pnp_par_tile_flags_f32 output or NULL.  Several 64-channel sources run as ONE launch when all of them are
- * fp16 maps (chain = 0), or -- fp32 sources only -- as the chain of single-source launches through fp32 partial sums (chain bit 0;
- * bit-identical).  chain bit 1: never the wide kernel (PNP_OPT_WIDE_F16 0). */
+ * fp16 maps (chain = 0), or -- fp32 sources only -- as the chain of single-source launches through fp32 partial sums (chain = 1;
+ * bit-identical). */
 int pnp_conv3x3_f16_maps(int nsrc, const void* const* srcs_dev, const int* src_channels, int src_f16_mask,
                          const void* const* packed_w_f16_dev, const float* bias_dev, const float* gamma_dev,
                          const void* packed_w1x1_f16_dev, const float* par_dev, const int* par_flags_dev,

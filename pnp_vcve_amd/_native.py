@@ -95,7 +95,7 @@ DEBUG_SIGNATURES['pnp_conv3x3_f16_maps'] = (c_int, [c_int, POINTER(c_void_p), PO
 DEBUG_SIGNATURES['pnp_mv_warp_nhwc_f16out'] = (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p])
 
 # pnp_generator_set_option ids (include/pnpvcve.h)
-OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_SMALL_F16, OPT_SPARSE_EVAL, OPT_F16_MIRRORS, OPT_F16_CHAIN_MIRRORS, OPT_WIDE_F16 = range(9)
+OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_SMALL_F16, OPT_SPARSE_EVAL, OPT_F16_MIRRORS, OPT_F16_CHAIN_MIRRORS = range(8)
 CONV_AUTO, CONV_TILE, CONV_TILE_BIG = range(3)
 
 _lib = None

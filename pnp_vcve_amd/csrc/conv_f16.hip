@@ -868,292 +868,6 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Large frames, fp16 OUTPUT (the front half of a BAE block, whose fp32 source x is rounded on the way into LDS): the "wide"
-// kernel.  What bounds the resident-weight kernel's matrix phase is LDS traffic: a wave's 32 px x 64 ch tile reads 1 KiB
-// of A and 2 KiB of B fragments per 2 MFMAs (1.5 KiB per MFMA), and its two phases are coupled by block-wide barriers.  Here a
-// wave owns 64 px x 64 ch (two 32-pixel M tiles sharing every B fragment: 1 KiB per MFMA), which needs a 16x16-pixel tile per
-// 4-wave block -- 50.7 KiB of A tile, so the 96 KiB of weights cannot stay resident: they stream from L2 through the small
-// kernel's 3-slot ring (8 KiB per 3x3 tap / 1x1 branch).  75.3 KiB per block -> TWO independent blocks per CU, free-running:
-// one block's halo wait / epilogue sits under the other's MFMA stream with no barrier between them.  One tile per block (blocks
-// that start together do not stay in lockstep, unlike persistent strips -- DESIGN.md 3.4).  Same k order, fp32 accumulation and
-// epilogue arithmetic as the other two kernels: bit-identical.  Measured (r03, 720p): it beats the resident-weight kernel where
-// that one is bound by the fp32 halo it pulls through its memory phase (the front half: fp32 x -> fp16 o), not where the source
-// is an fp16 map already (conv_hr, the back half) -- so it is used for the former only.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int WTH = 16;                                     // tile rows (x TW = 16 columns)
-constexpr int W_NPIX = (WTH + 2) * PW;                      // 324 halo pixels
-constexpr int W_A_BYTES = (WTH + 2) * RSB;                  // 50,688
-constexpr int W_LDS = W_A_BYTES + S_RING * S_CHUNK;         // 75,264
-constexpr int W_AIT16 = (W_NPIX * 8 + 255) / 256;           // 11 16-byte halo slots per thread (fp16 source)
-constexpr int W_AIT32 = (W_NPIX * 16 + 255) / 256;          // 21 (fp32 source)
-static_assert(2 * W_LDS <= 160 * 1024, "two blocks per CU");
-static_assert(W_LDS >= 4 * 16384, "the epilogue transposes 16 KiB per wave through the dead LDS");
-
-template <bool PAR, bool SRC16, int OUT>
-__global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const F16Args a) {
-    constexpr bool OUT16 = OUT == 1;
-    constexpr int W_AIT = SRC16 ? W_AIT16 : W_AIT32;
-    constexpr int CPP = SRC16 ? 8 : 16;
-    constexpr int NC = 9 + (PAR ? 3 : 0);
-    constexpr int WPT = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
-    const int H = a.H, W = a.W;
-    const int tiles_x = (W + TW - 1) / TW;
-    int tile;
-    {   // XCD-aware remap: each XCD walks a contiguous band of tiles (halo rows meet in its L2)
-        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
-        const int q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
-    const int ty0 = (tile / tiles_x) * WTH, tx0 = (tile % tiles_x) * TW;
-    char* const sA = smem;
-    char* const sR = smem + W_A_BYTES;
-    unsigned long long d_t0 = 0, d_t1 = 0, d_t2 = 0, d_t3 = 0;
-    if (a.dbg) d_t0 = __builtin_amdgcn_s_memtime();
-
-    const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
-    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, SRC16 ? map_bytes / 2 : map_bytes);
-    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : a.src, a.residual ? map_bytes : 0);
-    const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
-    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, (unsigned)H * (unsigned)W * (OUT16 ? 128u : 256u));
-    const __amdgpu_buffer_rsrc_t r_out16 = make_rsrc(OUT == 2 ? a.out16 : a.out, OUT == 2 ? map_bytes / 2 : 0);
-    // PAR: the partition flags are per 8x16 tile: this tile spans two of them
-    const int ftiles = tiles_x * ((H + TH - 1) / TH);
-    const __amdgpu_buffer_rsrc_t r_flags = make_rsrc((PAR && a.par_flags) ? (const void*)a.par_flags : a.src,
-                                                     (PAR && a.par_flags) ? (unsigned)ftiles * 4u : 0);
-    int pfl_v = 0;
-    if (PAR) {
-        const unsigned f0 = (unsigned)((ty0 / TH) * tiles_x + tx0 / TW) * 4u;
-        pfl_v = __builtin_bit_cast(int, buf_load1(r_flags, f0)) | __builtin_bit_cast(int, buf_load1(r_flags, f0 + (unsigned)tiles_x * 4u));
-    }
-
-    // ---- requests: halo, the first weight chunks, residual rows / partition values
-    f32x4 areg[W_AIT];
-    const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * (SRC16 ? 128u : 256u);
-#pragma unroll
-    for (int k = 0; k < W_AIT; ++k) {
-        const int i = t + 256 * k;
-        const int pix = i / CPP, cs = i % CPP;
-        const int ry = pix / PW, rx = pix - ry * PW;
-        const bool ok = (pix < W_NPIX) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);  // rows outside the image leave the descriptor by themselves
-        areg[k] = buf_load4(r_src, ok ? hbase + (unsigned)(ry * W + rx) * (SRC16 ? 128u : 256u) + (unsigned)cs * 16u : OOB);
-    }
-    const f32x4* wg = reinterpret_cast<const f32x4*>(a.w);
-    const f32x4* wgp = reinterpret_cast<const f32x4*>(a.wpar);
-    auto chunk_ptr = [&](int c) -> const f32x4* { return (PAR && c >= 9) ? wgp + (c - 9) * 512 : wg + c * 512; };
-    f32x4 wreg[2][WPT];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const f32x4* g = chunk_ptr(c);
-        f32x4 v[WPT];
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) v[i] = g[t + 256 * i];
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * S_CHUNK + (t + 256 * i) * 16) = v[i];
-    }
-    {
-        const f32x4* g = chunk_ptr(2);
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) wreg[0][i] = g[t + 256 * i];
-    }
-    constexpr int EIT = 8;
-    const int ec = lane & 15, ep = lane >> 4, n0 = lane & 31;
-    const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
-    float bco[2], gco[2], pv[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    f32x4 res4[2][EIT];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        bco[j] = a.bias ? a.bias[j * 32 + n0] : 0.f;
-        gco[j] = a.gamma ? a.gamma[j * 32 + n0] : 1.f;
-    }
-    const unsigned row_bytes = (unsigned)W * 256u;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {            // M tile mt of the wave: rows 4 wave + 2 mt + {0, 1}
-        const int r0 = ty0 + 4 * wave + 2 * mt;
-        const unsigned rbase = ((unsigned)(r0 * W + tx0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
-#pragma unroll
-        for (int i = 0; i < (OUT16 ? 0 : EIT); ++i) {
-            const bool ok = tx0 + ep + 4 * (i & 3) < W;
-            res4[mt][i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
-        }
-        if (PAR) {
-            const int gy = r0 + my, gx = tx0 + mx;
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj)
-                pv[mt][jj] = buf_load1(r_par, ((gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
-        }
-    }
-    // ---- halo -> fp16 A tile
-#pragma unroll
-    for (int k = 0; k < W_AIT; ++k) {
-        const int i = t + 256 * k;
-        const int pix = i / CPP, cs = i % CPP;
-        const int ry = pix / PW, rx = pix - ry * PW;
-        if (pix < W_NPIX) {
-            char* d = sA + ry * RSB + rx * PSB + cs * (SRC16 ? 16 : 8);
-            if (SRC16) *reinterpret_cast<f32x4*>(d) = areg[k];
-            else *reinterpret_cast<h4*>(d) = to_h4(areg[k]);
-        }
-    }
-    lds_barrier();
-    if (a.dbg) d_t1 = __builtin_amdgcn_s_memtime();
-
-    // ---- K loop: one continuous stream of k-steps (4 per chunk; chunk c lives in ring slot c % 3); every B fragment feeds both
-    // M tiles.  Fragments are fetched DEPTH k-steps ahead ACROSS chunk boundaries: chunk c + 1 has been in the ring since the
-    // barrier that ended chunk c - 1.  Per chunk: the request for chunk c + 3 at its top, the ring write of chunk c + 2 (into
-    // the slot of chunk c - 1, which every wave left before that barrier) behind its second k-step, and ONE barrier at its end
-    // that waits only for that write (lgkmcnt counts in order: the 2 x 4 fragment reads issued after it stay in flight).
-    const char* a_lane = sA + (4 * wave + my) * RSB + mx * PSB + 16 * h;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
-    int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
-    auto bsel = [&](int j) { return j == 0 ? bs0 : (j == 1 ? bs1 : bs2); };
-    auto bias_gamma = [&]() {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][j][r] = (acc[mt][j][r] + bco[j]) * gco[j];
-    };
-    constexpr int DEPTH = 3;
-    h8 fa0[DEPTH], fa1[DEPTH], fb0[DEPTH], fb1[DEPTH];
-    auto fetch = [&](int step) {        // compile-time step; the A address of a branch chunk is the centre tap whichever branch it is
-        const int c = step >> 2, sk = step & 3, sl = step % DEPTH;
-        const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
-        const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
-        fa0[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
-        fa1[sl] = *reinterpret_cast<const h8*>(a_lane + (dy + 2) * RSB + dx * PSB + 32 * sk);
-        fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
-        fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
-    };
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) fetch(k);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (PAR && c == 6 && a.par_flags) {          // first use of the flags: chunk 9 is requested below
-            const int f0 = __builtin_amdgcn_readfirstlane(pfl_v) & 7;
-            const int f1 = f0 & (f0 - 1), f2 = f1 & (f1 - 1);
-            ncr = 9 + __builtin_popcount(f0);
-            bs0 = f0 ? __builtin_ctz(f0) : 0;
-            bs1 = f1 ? __builtin_ctz(f1) : 0;
-            bs2 = f2 ? __builtin_ctz(f2) : 0;
-        }
-        if (PAR && c >= 9 && c >= ncr) break;
-        if (c + 3 < NC && (!PAR || c + 3 < ncr)) {
-            const f32x4* g = (PAR && c + 3 >= 9) ? wgp + bsel(c + 3 - 9) * 512 : chunk_ptr(c + 3);
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) wreg[(c + 1) & 1][i] = g[t + 256 * i];
-        }
-        _Float16 pj[2] = {(_Float16)1.f, (_Float16)1.f};
-        if (PAR && c >= 9) {
-            if (c == 9) bias_gamma();                  // (conv + bias) * gamma BEFORE the 1x1 partition branches
-            const int bi = bsel(c - 9);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) pj[mt] = (_Float16)(bi == 0 ? pv[mt][0] : (bi == 1 ? pv[mt][1] : pv[mt][2]));
-        }
-#pragma unroll
-        for (int sk = 0; sk < 4; ++sk) {
-            const int step = c * 4 + sk, sl = step % DEPTH;
-            h8 a0 = fa0[sl], a1 = fa1[sl];
-            const h8 b0 = fb0[sl], b1 = fb1[sl];
-            if (PAR && c >= 9) {
-                a0 *= pj[0];
-                a1 *= pj[1];
-            }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-            if (step + DEPTH < NC * 4) fetch(step + DEPTH);       // (past the tile's last chunk: unused stale bytes)
-            if (sk == 1 && c + 2 < NC && (!PAR || c + 2 < ncr)) {
-                char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1
-#pragma unroll
-                for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[c & 1][i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the ring write above is older than the 8 fragment reads of k-steps 2 and 3: wait for it, not for them
-        asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
-    }
-    if (!PAR || ncr == 9) bias_gamma();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // nobody still reads the LDS the epilogue overwrites
-
-    if (a.dbg) d_t2 = __builtin_amdgcn_s_memtime();
-    // ---- epilogue, M tile by M tile: transpose through the dead LDS (8 KiB per wave and M tile), activation, residual, whole
-    //      pixel rows to HBM (+ the fp16 mirror)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        float* sT = reinterpret_cast<float*>(smem + (wave * 2 + mt) * 8192);
-        const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
-        const int r0 = ty0 + 4 * wave + 2 * mt;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc[mt][j][r];
-        asm volatile("" ::: "memory");
-        if (OUT16) {
-            const int ec8 = lane & 7, ep8 = lane >> 3;
-            f32x4 lo[4], hi[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lo[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8];
-                hi[i] = sT4[(ep8 + 8 * i) * 16 + 2 * ec8 + 1];
-            }
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 u = lo[i], v = hi[i];
-                u = __builtin_elementwise_max(u, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(u, (f32x4)(0.f));
-                v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
-                const h4 uh = to_h4(u), vh = to_h4(v);
-                const h8 pk = __builtin_shufflevector(uh, vh, 0, 1, 2, 3, 4, 5, 6, 7);
-                const int gx = tx0 + ep8 + 8 * (i & 1);
-                const unsigned o = ((unsigned)(r0 + (i >> 1)) * (unsigned)W + (unsigned)gx) * 128u + (unsigned)ec8 * 16u;
-                buf_store4(r_out, gx < W ? o : OOB, __builtin_bit_cast(f32x4, pk));
-            }
-        } else {
-            f32x4 rows[EIT];
-            h4 hv[EIT];
-#pragma unroll
-            for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < EIT; ++i) {
-                f32x4 v = rows[i];
-                v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
-                v += res4[mt][i];
-                const int gx = tx0 + ep + 4 * (i & 3);
-                const unsigned o = ((unsigned)(r0 + (i >> 2)) * (unsigned)W + (unsigned)gx) * 256u + (unsigned)ec * 16u;
-                buf_store4(r_out, gx < W ? o : OOB, v);
-                if (OUT == 2) hv[i] = to_h4(v);
-            }
-            if (OUT == 2) store_mirror16(hv, r_out16, r0, tx0, W, ec, ep);
-        }
-    }
-    if (a.dbg && t == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        d_t3 = __builtin_amdgcn_s_memtime();
-        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 16;
-        d[0] = d_t0;
-        d[1] = d_t1;
-        d[2] = d_t2;
-        d[3] = d_t3;
-        d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
-        d[7] = 1;
-        d[10] = __builtin_amdgcn_s_memrealtime();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // The input conv of a branch (basicvsr_net.py:484,515 over the concat of iconvsr_ipb_par.py:90,125) in ONE launch: up to three
 // 64-channel sources, all read through their fp16 mirrors, + the RGB frame.  The resident-weight kernel above runs such a conv
 // as a chain of single-source launches whose fp32 partial sums go through HBM (512 B per pixel and link); here a block is one
@@ -1445,19 +1159,6 @@ static bool f16_small_eligible(const ConvArgs& a, int grid_y) {
     return tiles < 1024 && grid_y == 1 && a.nsrc == 1 && a.src_c[0] == 64 && a.out_mode == 0;
 }
 
-template <bool PAR, bool SRC16, int OUT>
-static int launch_wide(const F16Args& fa, hipStream_t stream) {
-    auto kern = conv3x3_f16_wide_kernel<PAR, SRC16, OUT>;
-    static PnpPerDevice once;
-    const hipError_t attr_err = once.run([&](int, int&) {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
-    });
-    if (attr_err != hipSuccess) return (int)attr_err;
-    const int tiles = ((fa.W + TW - 1) / TW) * ((fa.H + WTH - 1) / WTH);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), W_LDS, stream, fa);
-    return (int)hipGetLastError();
-}
-
 template <int NW, bool LR4, int OUT>
 static int launch_multi_t(const F16MultiArgs& fa, hipStream_t stream) {
     auto kern = conv3x3_f16_multi_kernel<NW, LR4, OUT>;
@@ -1570,13 +1271,6 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream) {
         const int om = a.out_f16 ? 1 : (f.out16 ? 2 : 0);
         int rc;
         const bool hp = f.wpar != nullptr;
-        const long tiles8 = (long)((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-        if (!a.no_wide16 && !s16 && om == 1 && nwide == 1 && !f.lr4 && !f.residual && a.out_mode == 0 && grid_y == 1 && tiles8 >= 1024) {
-            // large frame, fp32 source -> fp16 map (the front half of a BAE block): 64 px x 64 ch wave tiles, two free-running blocks per CU
-            rc = hp ? launch_wide<true, false, 1>(f, stream) : launch_wide<false, false, 1>(f, stream);
-            if (rc) return rc;
-            continue;
-        }
         if (f16_small_eligible(a, grid_y) && !(om == 1 && f.residual)) {
             rc = pick3(hp, s16, om, [&](auto P, auto S, auto O) {
                 return launch_small<decltype(P)::value, decltype(S)::value, decltype(O)::value>(f, stream);

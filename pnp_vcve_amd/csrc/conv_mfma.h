@@ -17,7 +17,6 @@ struct ConvArgs {
                             // wrote); out_f16: out is one (single source, no residual)
     void* out16;            // prec 1, out_mode 0, !out_f16: additionally write an fp16 NHWC64 mirror of the fp32 output
     int no_multi16;         // 1: several fp16 sources are refused instead of running the one-launch input-conv kernel
-    int no_wide16;          // 1: never the wide (64 px x 64 ch per wave) fp16 kernel (PNP_OPT_WIDE_F16 0)
     const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
     const int* par_flags;   // optional, one int per 8x16 tile (row-major): bit j set <=> plane j has a nonzero value in
                             // the tile (launch_par_tile_flags).  The persistent kernel skips the 1x1 branches whose

@@ -66,7 +66,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
-    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1};   // pnp_generator_set_option (defaults: everything on)
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0};   // pnp_generator_set_option (defaults: everything on)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -623,7 +623,6 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.no_persist = g->opt[PNP_OPT_PERSIST] ? 0 : 1;
         a.no_small16 = g->opt[PNP_OPT_SMALL_F16] ? 0 : 1;
         a.no_multi16 = 0;
-        a.no_wide16 = g->opt[PNP_OPT_WIDE_F16] ? 0 : 1;
         a.w_ystride = q.w_ystride_;
         a.bias_ystride = q.bias_ystride_;
         a.H = q.H;
@@ -1270,8 +1269,7 @@ int pnp_conv3x3_f16_maps(int nsrc, const void* const* srcs, const int* src_chann
     a.src_f16 = src_f16_mask;
     a.out_f16 = out_f16 ? 1 : 0;
     a.out16 = out16;
-    a.no_multi16 = (chain & 1) ? 1 : 0;
-    a.no_wide16 = (chain & 2) ? 1 : 0;
+    a.no_multi16 = chain ? 1 : 0;
     a.wpar_h = packed_w1x1_f16;
     a.par = par;
     a.par_flags = par_flags;

@@ -217,12 +217,11 @@ def _conv3x3_f16(srcs, packed_w, bias, gamma, packed_w1x1, par, residual, act, t
 
 @_on_device_of_first_tensor
 def conv3x3_f16_maps(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, par_flags=None, residual=None, act=0,
-                     out_f16=False, mirror=False, chain=False, no_wide=False, trace=None):
+                     out_f16=False, mirror=False, chain=False, trace=None):
     """The fp16-operand conv with explicit fp16 maps (include/pnpvcve_debug.h, pnp_conv3x3_f16_maps): a source of dtype
     float16 (h,w,64) is read as an fp16 map (the mirror its producer wrote), float32 sources are rounded on the fly.
     out_f16: the output is an fp16 map; mirror: additionally return the fp16 copy of the fp32 output written in the same
-    pass -> (out, out16).  chain=True forces the chain of single-source launches for several fp32 sources; no_wide=True
-    keeps a large fp32 -> fp16 conv on the resident-weight kernel instead of the wide one."""
+    pass -> (out, out16).  chain=True forces the chain of single-source launches for several fp32 sources."""
     n = len(srcs)
     mask = 0
     for i, t in enumerate(srcs):
@@ -248,7 +247,7 @@ def conv3x3_f16_maps(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, pa
     w1 = ctypes.c_void_p(packed_w1x1.data_ptr()) if packed_w1x1 is not None else None
     _native.check(_native.lib().pnp_conv3x3_f16_maps(n, sp, sc, mask, wp, _ptr(keep[0]), _ptr(keep[1]), w1, _ptr(keep[2]),
                                                      _ptr(par_flags), _ptr(keep[3]), act, _ptr(out), int(bool(out_f16)),
-                                                     _ptr(out16), h, w, int(bool(chain)) | (2 if no_wide else 0), _ptr(trace), _stream()),
+                                                     _ptr(out16), h, w, int(bool(chain)), _ptr(trace), _stream()),
                   'pnp_conv3x3_f16_maps')
     return (out, out16) if mirror else out
 

@@ -350,8 +350,6 @@ def test_f16_mirror_and_fp16_sources_are_bit_identical(hw, with_par):
     o16 = ops.conv3x3_f16_maps([x], [wt], out_f16=True, **kw)                                   # fp16 output: no residual
     assert torch.equal(o16, _h16(ops.conv3x3_f16_maps([x], [wt], **kw)))
     assert torch.equal(ops.conv3x3_f16_maps([x16], [wt], out_f16=True, **kw), o16)              # fp16 in, fp16 out (new)
-    # from 1024 tiles on, fp32 -> fp16 map runs on the wide kernel (16x16 tiles, 64 px x 64 ch per wave): same bits with it off
-    assert torch.equal(ops.conv3x3_f16_maps([x], [wt], out_f16=True, no_wide=True, **kw), o16)
 
 
 @pytest.mark.parametrize('hw', SIZES_F16 + [(720, 1280)], ids=lambda s: '%dx%d' % s)
@@ -470,32 +468,6 @@ def test_f16_mirrors_and_one_launch_input_conv_leave_the_clip_bit_identical(name
     m.set_option(_native.OPT_F16_CHAIN_MIRRORS, 1)          # + the running map inside a branch (off by default)
     assert torch.equal(run(), ref), 'chain mirrors'
     m.set_option(_native.OPT_PAR_SKIP, 0)
-    assert torch.equal(run(), ref)
-
-
-@pytest.mark.parametrize('hw', [(720, 1280), (264, 520)], ids=lambda s: '%dx%d' % s)
-def test_wide_f16_kernel_leaves_the_clip_bit_identical(hw):
-    """PNP_OPT_WIDE_F16 0 / 1 on frames with >= 1024 tiles (720p; 264x520 is ragged for 8- and 16-row tiles and 16-column tiles):
-    the front halves of the BAE blocks on the wide kernel against the resident-weight kernel -- same bits, with and without the
-    in-branch mirrors (with them the front half reads an fp16 map and stays on the resident-weight kernel)."""
-    from pnp_vcve_amd import _native
-    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
-    sd_np = gu.syn.make_state_dict(cfg, seed=161, par_gain=10.0)
-    clip = gu.syn.make_clip(seed=162, n=1, t=3, h=hw[0], w=hw[1], slices='IBBBP', block=4, par_classes=3)
-    m = _gen_model(cfg, sd_np)
-    m.fp16_enabled = True
-    a = {k: G(v) for k, v in clip.items()}
-
-    def run():
-        with torch.no_grad():
-            return m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']).clone()
-
-    m.set_option(_native.OPT_WIDE_F16, 0)
-    ref = run()
-    m.set_option(_native.OPT_WIDE_F16, 1)
-    out = run()
-    assert torch.isfinite(out).all() and torch.equal(out, ref), float((out - ref).abs().max())
-    m.set_option(_native.OPT_F16_CHAIN_MIRRORS, 1)
     assert torch.equal(run(), ref)
 
 

@@ -55,15 +55,14 @@ F = ops.conv3x3_f16_maps
 print(f'frame {h}x{w}, tiles {((h + 7) // 8) * ((w + 15) // 16)}; branches needed per tile: '
       f'{sum(((flags >> j) & 1).float().mean().item() for j in range(3)):.2f}')
 kw = dict(bias=bias, gamma=gam, packed_w1x1=p1, par=par, act=1)
-timeit('front  r02: fp32 x -> fp16 o, all branches, resident-weight kernel', lambda i: F([xs[i % NB]], [pw], out_f16=True, no_wide=True, **kw), 396)
-timeit('front     : fp32 x -> fp16 o, branch skipping, resident-weight kernel', lambda i: F([xs[i % NB]], [pw], out_f16=True, par_flags=flags, no_wide=True, **kw), 396)
-timeit('front  r03: fp32 x -> fp16 o, branch skipping, WIDE kernel', lambda i: F([xs[i % NB]], [pw], out_f16=True, par_flags=flags, **kw), 396)
+timeit('front  r02: fp32 x -> fp16 o, all branches', lambda i: F([xs[i % NB]], [pw], out_f16=True, **kw), 396)
+timeit('front     : fp32 x -> fp16 o, branch skipping', lambda i: F([xs[i % NB]], [pw], out_f16=True, par_flags=flags, **kw), 396)
 timeit('front     : fp16 x -> fp16 o, all branches', lambda i: F([xs16[i % NB]], [pw], out_f16=True, **kw), 268)
 timeit('front     : fp16 x -> fp16 o, all branches, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], out_f16=True, **kw), 268)
 timeit('front     : fp16 x -> fp16 o, branch skipping, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], out_f16=True, par_flags=flags, **kw), 268)
 timeit('back   r02: fp16 o + fp32 residual -> fp32 x, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB]), 640)
 timeit('back      : ... + fp16 mirror, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB], mirror=True), 768)
-timeit('conv_hr r02: fp32 -> fp16', lambda i: F([xs[i % NB]], [pw], bias=bias, act=2, out_f16=True, no_wide=True), 384)
+timeit('conv_hr r02: fp32 -> fp16', lambda i: F([xs[i % NB]], [pw], bias=bias, act=2, out_f16=True), 384)
 timeit('conv_hr    : fp16 -> fp16, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, act=2, out_f16=True), 256)
 for nw in (1, 2, 3):
     s32 = [xs[(j + 1) % NB] for j in range(nw)]
@@ -91,6 +90,6 @@ if '--trace' in sys.argv:
                       ('  of which halo wait+cvt+LDS', d[:, 8] / n), ('barrier wait / tile', d[:, 9] / n), ('total / tile and group', tot / n)):
             print(f'    {nm:30s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}')
     if ((h + 7) // 8) * ((w + 15) // 16) >= 1024:
-        trace('front r02 (fp32 x, all branches)', lambda t: F([xs[0]], [pw], out_f16=True, no_wide=True, trace=t, **kw))
+        trace('front r02 (fp32 x, all branches)', lambda t: F([xs[0]], [pw], out_f16=True, trace=t, **kw))
         trace('front (fp16 x, skipping), resident-weight kernel', lambda t: F([xs16[0]], [pw], out_f16=True, par_flags=flags, trace=t, **kw))
         trace('back (+ mirror), resident-weight kernel', lambda t: F([xs16[0]], [pw], bias=bias, residual=rs[0], mirror=True, trace=t))
