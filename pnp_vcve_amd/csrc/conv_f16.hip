@@ -764,6 +764,25 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] + bco[j]) * gco[j];
     };
+    // One continuous stream of k-steps (4 per chunk; chunk c lives in ring slot c % 3).  Fragments are fetched DEPTH k-steps ahead
+    // ACROSS chunk boundaries -- chunk c + 1 has been in the ring since the barrier that ended chunk c - 1 -- so a chunk no longer
+    // starts with an exposed LDS round trip (r03; a tile is 9-12 chunks and a small frame is latency-, not throughput-bound).
+    // Per chunk: the request for chunk c + 3 at its top, the ring write of chunk c + 2 (into the slot of chunk c - 1, which every
+    // wave left before that barrier) behind its second k-step, and ONE barrier at its end that waits only for that write: lgkmcnt
+    // counts in order, so the 2 x 3 fragment reads issued after it may stay in flight.
+    constexpr int DEPTH = G == 2 ? 2 : 3;          // 3 h8 per k-step in flight; the register budget is 128 (G = 2) / 170 (G = 1)
+    h8 fa[DEPTH], fb0[DEPTH], fb1[DEPTH];
+    auto fetch = [&](int step) {        // compile-time step; a branch chunk reads the centre tap whichever branch it is
+        const int c = step >> 2, sk = step & 3, sl = step % DEPTH;
+        const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
+        const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
+        fa[sl] = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
+        fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
+        fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) fetch(k);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (PAR && c == 6 && a.par_flags) {          // first use of the flags: chunk 9 is requested below
@@ -780,8 +799,6 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
 #pragma unroll
             for (int i = 0; i < WPT; ++i) wreg[(c + 1) & 1][i] = g[tt + NT_ * i];
         }
-        const char* b_lane = sR + (c % S_RING) * S_CHUNK + lane * 16;
-        const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
         _Float16 pj = (_Float16)1.f;
         if (PAR && c >= 9) {
             if (c == 9) bias_gamma();                  // (conv + bias) * gamma BEFORE the 1x1 partition branches
@@ -790,20 +807,24 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
         }
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) {
-            h8 av = *reinterpret_cast<const h8*>(a_lane + dy * RSB + dx * PSB + 32 * sk);
-            const h8 b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
-            const h8 b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
+            const int step = c * 4 + sk, sl = step % DEPTH;
+            h8 av = fa[sl];
+            const h8 b0 = fb0[sl], b1 = fb1[sl];
             if (PAR && c >= 9) av *= pj;
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[1], 0, 0, 0);
-        }
-        if (c + 2 < NC && (!PAR || c + 2 < ncr)) {
-            char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1: every wave left it at the previous barrier
+            if (step + DEPTH < NC * 4) fetch(step + DEPTH);       // (past the tile's last chunk: unused stale bytes)
+            if (sk == 1 && c + 2 < NC && (!PAR || c + 2 < ncr)) {
+                char* d = sR + ((c + 2) % S_RING) * S_CHUNK;       // slot of chunk c - 1
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (tt + NT_ * i) * 16) = wreg[c & 1][i];
+                for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (tt + NT_ * i) * 16) = wreg[c & 1][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        lds_barrier();
+        // the ring write above is older than the 6 fragment reads of k-steps 2 and 3: wait for it, not for them
+        asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory");
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // nobody still reads the LDS the epilogue overwrites
     if (!PAR || ncr == 9) bias_gamma();
 
     if (a.dbg) d_t2 = __builtin_amdgcn_s_memtime();
