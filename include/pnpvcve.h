@@ -63,10 +63,16 @@ int64_t pnp_generator_packed_floats(const pnp_generator* g);
 /* Arithmetic of the 64-channel convs (BASELINE configs[4]; mmcv's wrap_fp16_model / fp16_enabled switch,
  * mmedit/models/restorers/basic_restorer.py:64 @auto_fp16).  PNP_PREC_F32 (default): exact fp32 MFMA.
  * PNP_PREC_F16: activations and weights rounded to fp16 as MFMA operands, fp32 accumulation, fp32 feature
- * maps in HBM; conv_last and an RGB-only input conv stay fp32.  Set it BEFORE sizing/packing: it changes
- * pnp_generator_packed_floats and pnp_generator_workspace_bytes. */
+ * maps in HBM; conv_last and an RGB-only input conv stay fp32.
+ * PNP_PREC_F16X3: split fp16 -- every activation and weight of the NHWC64 64-channel convs is carried as
+ * hi + lo/2048 (two fp16 numbers, 22 significand bits) and each product is three fp16 MFMAs with fp32
+ * accumulation; results agree with PNP_PREC_F32 to ~1e-6 relative per conv (inside north_star's 1e-3 gate,
+ * which PNP_PREC_F16 is not) at about a third of the fp16 matrix rate.  Feature maps stay fp32; the RGB
+ * frame, the pixel-shuffle / RGB heads and the deformable alignment stay on the exact fp32 kernels.
+ * Set it BEFORE sizing/packing: it changes pnp_generator_packed_floats and pnp_generator_workspace_bytes. */
 #define PNP_PREC_F32 0
 #define PNP_PREC_F16 1
+#define PNP_PREC_F16X3 2
 int pnp_generator_set_precision(pnp_generator* g, int precision);
 int pnp_generator_get_precision(const pnp_generator* g);
 
@@ -200,6 +206,21 @@ int pnp_conv3x3_f16(int nsrc, const float* const* srcs_dev, const int* src_chann
                     const void* const* packed_w_f16_dev, const float* bias_dev, const float* gamma_dev,
                     const void* packed_w1x1_f16_dev, const float* par_dev, const float* residual_dev,
                     int act, float* out_dev, int h, int w, void* stream);
+
+/* The same op in split fp16 (PNP_PREC_F16X3): every activation x and weight w is carried as hi + lo/2048 with
+ * hi = fp16(x), lo = fp16((x - hi) * 2048), a product is three fp16 MFMAs (hi*hi, lo*hi, hi*lo) accumulated in
+ * fp32 -- fp32-level results (~1e-6 relative to pnp_conv3x3_f32) from the fp16 matrix pipe.  fp32 sources and
+ * output.  packed_w_f32 are the fp32 images (read only for a 4-channel RGB0 source, which runs on the exact fp32
+ * kernel; may be NULL for 64-channel sources); packed_w_hi = pnp_f16_image_from_f32, packed_w_lo =
+ * pnp_f16_lo_image_from_f32 of the same fp32 images (64-channel sources and the 1x1 branches).  par_flags_dev:
+ * optional pnp_par_tile_flags_f32 output.  Restrictions as for pnp_conv3x3_f16. */
+int pnp_f16_lo_image_from_f32(const float* packed_w_dev, void* dst_dev, int nchunks, void* stream);
+int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs_dev, const int* src_channels,
+                      const float* const* packed_w_f32_dev, const void* const* packed_w_hi_dev,
+                      const void* const* packed_w_lo_dev, const float* bias_dev, const float* gamma_dev,
+                      const void* packed_w1x1_hi_dev, const void* packed_w1x1_lo_dev, const float* par_dev,
+                      const int* par_flags_dev, const float* residual_dev, int act, float* out_dev, int h, int w,
+                      void* stream);
 
 /* Per-frame sum of squared differences of the uint8-rounded frames (the statistic behind
  * psnr(tensor2img(a), tensor2img(b)), mmedit/core/misc.py:51-71 + core/evaluation/metrics.py:200-215):

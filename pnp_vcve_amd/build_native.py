@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libpnpvcve_hip.so')
-SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_f16.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
+SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_f16.hip', 'conv_f16x3.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # per-source extras.  dcn.hip: hipcc's SLP vectoriser packs the scalar coordinate / weight arithmetic of the deformable gather into
 # v_pk_*_f32 pairs; every build with that packing gave wrong, run-to-run varying samples in the fp16 instantiation under some

@@ -349,7 +349,8 @@ struct ConvCall {
 
 struct Workspace {
     float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om, *parbin;
-    float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 only
+    float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 / F16X3 only
+    float* mixl;      // PNP_PREC_F16X3: the low fp16 images of the split, fp16((w - hi) * 2048)
     // PNP_PREC_F16 + mirrors: fp16 NHWC64 copies of the running map of a branch (x16) and of every frame's slot (slots16);
     // the MV-aligned key frame is then fp16 only and lives in kw
     uint16_t *x16, *slots16;
@@ -399,7 +400,8 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     W.gamma = take((int64_t)t * 64);
     W.mixw = take((int64_t)t * g->ndyn * IMG_WIDE);
     W.mixb = take((int64_t)t * g->ndyn * 64);
-    W.mixh = g->prec == PNP_PREC_F16 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
+    W.mixh = g->prec != PNP_PREC_F32 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
+    W.mixl = g->prec == PNP_PREC_F16X3 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
     const bool mir = g->prec == PNP_PREC_F16 && g->cfg.deform == 0;      // sized whether or not PNP_OPT_F16_MIRRORS is on
     W.x16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32)) : nullptr;
     W.slots16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32 * t)) : nullptr;
@@ -442,13 +444,15 @@ int pnp_generator_param_ndim(const pnp_generator* g, int i) { return (int)g->par
 int64_t pnp_generator_param_dim(const pnp_generator* g, int i, int d) { return g->params[i].shape[d]; }
 int64_t pnp_generator_param_offset(const pnp_generator* g, int i) { return g->params[i].offset; }
 int64_t pnp_generator_flat_floats(const pnp_generator* g) { return g->flat_floats; }
-// fp32 images, then (PNP_PREC_F16) their fp16 mirror: element i of the mirror region is element i of the images
+// fp32 images, then (PNP_PREC_F16 / F16X3) their fp16 mirror: element i of the mirror region is element i of the images; then
+// (PNP_PREC_F16X3) the low fp16 images of the split, same indexing
 int64_t pnp_generator_packed_floats(const pnp_generator* g) {
-    return g->prec == PNP_PREC_F16 ? g->packed_floats + g->packed_floats / 2 : g->packed_floats;
+    const int halves = g->prec == PNP_PREC_F16 ? 1 : (g->prec == PNP_PREC_F16X3 ? 2 : 0);
+    return g->packed_floats + halves * (g->packed_floats / 2);
 }
 
 int pnp_generator_set_precision(pnp_generator* g, int precision) {
-    if (!g || (precision != PNP_PREC_F32 && precision != PNP_PREC_F16)) return PNP_ERR_BAD_ARG;
+    if (!g || (precision != PNP_PREC_F32 && precision != PNP_PREC_F16 && precision != PNP_PREC_F16X3)) return PNP_ERR_BAD_ARG;
     g->prec = precision;
     return PNP_OK;
 }
@@ -558,6 +562,12 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
             if (rc) return rc;
         }
     }
+    if (g->prec == PNP_PREC_F16X3) {     // hi and lo images of every region; only the NHWC64 64-channel convs read them
+        rc = launch_f16_image(packed, packed + g->packed_floats, (int)(g->packed_floats / IMG_CHUNK), 2, st);
+        if (rc) return rc;
+        rc = launch_f16_lo_image(packed, packed + g->packed_floats + g->packed_floats / 2, (int)(g->packed_floats / IMG_CHUNK), 2, st);
+        if (rc) return rc;
+    }
     return (int)hipGetLastError();
 }
 
@@ -583,10 +593,17 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     // fp16 mirror of a weight image that lives in `packed` or in the per-clip expert mixtures
     const int64_t n_mix = (int64_t)t * g->ndyn * IMG_WIDE;
     auto twin = [&](const float* p) -> const void* {
-        if (g->prec != PNP_PREC_F16 || !p) return nullptr;
+        if (g->prec == PNP_PREC_F32 || !p) return nullptr;
         if (p >= packed && p < packed + g->packed_floats)
             return reinterpret_cast<const uint16_t*>(packed + g->packed_floats) + (p - packed);
         if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixh) + (p - W.mixw);
+        return nullptr;
+    };
+    auto twin_lo = [&](const float* p) -> const void* {      // PNP_PREC_F16X3: the low image of the split
+        if (g->prec != PNP_PREC_F16X3 || !p) return nullptr;
+        if (p >= packed && p < packed + g->packed_floats)
+            return reinterpret_cast<const uint16_t*>(packed + g->packed_floats + g->packed_floats / 2) + (p - packed);
+        if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixl) + (p - W.mixw);
         return nullptr;
     };
     const bool f16_maps = g->prec == PNP_PREC_F16 && g->opt[PNP_OPT_F16_MAPS];
@@ -601,15 +618,17 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         a.nsrc = q.nsrc;
-        a.prec = g->prec == PNP_PREC_F16 ? 1 : 0;
+        a.prec = g->prec;                 // PNP_PREC_* are ConvArgs::prec's values
         for (int s = 0; s < q.nsrc; ++s) {
             a.src[s] = q.src[s];
             a.src_c[s] = q.sc[s];
             a.wsrc[s] = q.w[s];
             a.wsrc_h[s] = twin(q.w[s]);
+            a.wsrc_l[s] = twin_lo(q.w[s]);
         }
         a.wpar = q.wpar_;
         a.wpar_h = twin(q.wpar_);
+        a.wpar_l = twin_lo(q.wpar_);
         a.par = q.par_;
         a.par_flags = q.par_flags_;
         a.par_plane = (long)q.H * q.W;
@@ -678,7 +697,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         d.fx = c.deform == 1 ? fxp : nullptr;
         d.fy = c.deform == 1 ? fyp : nullptr;
         d.w = packed + g->dcn_img;
-        d.w16 = twin(packed + g->dcn_img);       // nullptr unless PNP_PREC_F16
+        d.w16 = g->prec == PNP_PREC_F16 ? twin(packed + g->dcn_img) : nullptr;
         d.bias = flat + g->f_dcn_b;
         d.out = W.kw;
         d.H = h;
@@ -764,9 +783,14 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 rc = launch_mix_bias(flat + g->dyn_b, W.ew + (int64_t)i * E, W.mixb + (int64_t)u * g->ndyn * 64, E, 64,
                                      g->ndyn, st);
                 if (rc) return rc;
-                if (g->prec == PNP_PREC_F16) {
+                if (g->prec != PNP_PREC_F32) {
                     rc = launch_f16_image(a.dst, reinterpret_cast<uint16_t*>(W.mixh) + (int64_t)u * g->ndyn * IMG_WIDE,
                                           g->ndyn * 9, 2, st);
+                    if (rc) return rc;
+                }
+                if (g->prec == PNP_PREC_F16X3) {
+                    rc = launch_f16_lo_image(a.dst, reinterpret_cast<uint16_t*>(W.mixl) + (int64_t)u * g->ndyn * IMG_WIDE,
+                                             g->ndyn * 9, 2, st);
                     if (rc) return rc;
                 }
             }
@@ -1248,6 +1272,46 @@ int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs, const int* src_channe
     if (a.wpar_h && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
     if (!conv_f16_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_f16(a, 1, (hipStream_t)st);
+}
+
+int pnp_f16_lo_image_from_f32(const float* packed_w, void* dst, int nchunks, void* st) {
+    if (!packed_w || !dst) return PNP_ERR_BAD_ARG;
+    return launch_f16_lo_image(packed_w, dst, nchunks, 2, (hipStream_t)st);
+}
+
+int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w_f32,
+                      const void* const* packed_w_hi, const void* const* packed_w_lo, const float* bias, const float* gamma,
+                      const void* packed_w1x1_hi, const void* packed_w1x1_lo, const float* par, const int* par_flags,
+                      const float* residual, int act, float* out, int h, int w, void* st) {
+    if (nsrc < 1 || nsrc > 4 || !srcs || !src_channels || !packed_w_hi || !packed_w_lo || !out) return PNP_ERR_BAD_ARG;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = nsrc;
+    a.prec = 2;
+    for (int s = 0; s < nsrc; ++s) {
+        a.src[s] = srcs[s];
+        a.src_c[s] = src_channels[s];
+        a.wsrc[s] = packed_w_f32 ? packed_w_f32[s] : nullptr;
+        a.wsrc_h[s] = packed_w_hi[s];
+        a.wsrc_l[s] = packed_w_lo[s];
+        if (src_channels[s] == 4 && (s != 0 || !a.wsrc[s])) return PNP_ERR_BAD_ARG;    // the RGB frame: source 0, fp32 image
+    }
+    a.wpar_h = packed_w1x1_hi;
+    a.wpar_l = packed_w1x1_lo;
+    a.par = par;
+    a.par_flags = par_flags;
+    a.par_plane = (long)h * w;
+    a.bias = bias;
+    a.gamma = gamma;
+    a.residual = residual;
+    a.out = out;
+    a.H = h;
+    a.W = w;
+    a.act = act;
+    a.out_mode = 0;
+    if (a.wpar_h && (nsrc != 1 || !par || !a.wpar_l)) return PNP_ERR_BAD_ARG;
+    if (!conv_f16x3_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
+    return launch_conv3x3_f16x3(a, conv_pick_cfg(h, w), (hipStream_t)st);
 }
 
 // pnpvcve_debug.h: the fp16-operand conv with explicit fp16 maps -- what pnp_generator_forward uses between its launches under

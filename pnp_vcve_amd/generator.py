@@ -92,8 +92,23 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
 
     @fp16_enabled.setter
     def fp16_enabled(self, value):
+        self.precision = 'fp16' if value else 'fp32'
+
+    _PRECISIONS = ('fp32', 'fp16', 'f16x3')      # PNP_PREC_F32 / F16 / F16X3
+
+    @property
+    def precision(self):
+        """'fp32' (default, exact fp32 MFMA) | 'fp16' (mmcv's fp16 switch: fp16 MFMA operands) | 'f16x3' (split fp16: every
+        operand of the 64-channel convs carried as two fp16 numbers, three MFMAs per product; fp32-level results -- inside the
+        1e-3 parity gate -- from the fp16 matrix pipe).  include/pnpvcve.h PNP_PREC_*."""
+        return self._PRECISIONS[int(_native.lib().pnp_generator_get_precision(self._handle))]
+
+    @precision.setter
+    def precision(self, value):
+        if value not in self._PRECISIONS:
+            raise ValueError(f'precision must be one of {self._PRECISIONS}, got {value!r}')
         L = _native.lib()
-        _native.check(L.pnp_generator_set_precision(self._handle, 1 if value else 0), 'pnp_generator_set_precision')
+        _native.check(L.pnp_generator_set_precision(self._handle, self._PRECISIONS.index(value)), 'pnp_generator_set_precision')
         self._packed_floats = int(L.pnp_generator_packed_floats(self._handle))
         self._flat = self._packed = None        # images and workspace are sized per precision
         self._pack_key = None

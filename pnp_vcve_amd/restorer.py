@@ -65,6 +65,15 @@ class BasicVSR(nn.Module):
     def fp16_enabled(self, value):
         self.generator.fp16_enabled = bool(value)
 
+    # the native precision switch in full ('fp32' | 'fp16' | 'f16x3'; generator.precision)
+    @property
+    def precision(self):
+        return self.generator.precision
+
+    @precision.setter
+    def precision(self, value):
+        self.generator.precision = value
+
     def check_if_mirror_extended(self, lrs):
         """basicvsr.py:52-68."""
         is_mirror_extended = False

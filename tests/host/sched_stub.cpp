@@ -105,7 +105,7 @@ struct WarpRec { const void *feat, *fx, *out; bool f16; };
 struct ConvRec {
     ConvArgs a;
     int cfg, gy, stream;
-    bool f16_path;
+    int path;          // 0 fp32 kernels | 1 fp16-operand kernels | 2 split-fp16 kernel
 };
 struct MixRec { const void* dst; int E, gy; };
 std::vector<WarpRec> warps;
@@ -194,7 +194,8 @@ int conv_pick_cfg(int H, int W) {
     return tiles_big >= 1024 ? CONV_CFG_BIG : CONV_CFG_SMALL;
 }
 
-static void conv_touch(const ConvArgs& a, int cfg, int gy, bool f16) {
+static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
+    const bool f16 = path == 1, x3 = path == 2;
     using namespace stub;
     const size_t hw = (size_t)a.H * a.W;
     const bool rgb_head = a.out_mode == 2 || a.out_mode == 3;
@@ -203,13 +204,15 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, bool f16) {
         RD("a conv source", a.src[s], hw * a.src_c[s] * (s16 ? 2 : 4));
         const size_t img = a.src_c[s] == 64 ? (rgb_head ? 9 * 2048 : 9 * 4096) : 4096;
         for (int y = 0; y < gy; ++y) {
-            if (f16) RD("an fp16 weight image", (const uint16_t*)a.wsrc_h[s] + (size_t)y * a.w_ystride, img * 2);
+            if (f16 || (x3 && a.src_c[s] == 64)) RD("an fp16 weight image", (const uint16_t*)a.wsrc_h[s] + (size_t)y * a.w_ystride, img * 2);
             else RD("a weight image", a.wsrc[s] + (size_t)y * a.w_ystride, img * 4);
+            if (x3 && a.src_c[s] == 64) RD("a low fp16 weight image of the split", (const uint16_t*)a.wsrc_l[s] + (size_t)y * a.w_ystride, img * 2);
         }
     }
     if (a.wpar || a.wpar_h) {
-        if (f16) RD("the fp16 1x1 weight images", a.wpar_h, 3 * 4096 * 2);
+        if (f16 || x3) RD("the fp16 1x1 weight images", a.wpar_h, 3 * 4096 * 2);
         else RD("the 1x1 weight images", a.wpar, 3 * 4096 * 4);
+        if (x3) RD("the low fp16 1x1 weight images of the split", a.wpar_l, 3 * 4096 * 2);
         RD("the partition planes", a.par, (size_t)(2 * a.par_plane + hw) * 4);
         if (a.par_flags) RD("the partition tile flags", a.par_flags, (size_t)((a.W + 15) / 16) * ((a.H + 7) / 8) * 4);
     }
@@ -236,19 +239,35 @@ int launch_conv3x3(const ConvArgs& a, int cfg, int gy, hipStream_t s) {
     stub::note_launch(s);
     if (a.nsrc < 1 || a.nsrc > 4) return PNP_ERR_BAD_ARG;
     const bool f16 = a.prec == 1 && conv_f16_eligible(a, cfg, gy);
+    const bool x3 = a.prec == 2 && conv_f16x3_eligible(a, cfg, gy);
     if (!f16 && (a.src_f16 || a.out_f16 || a.out16)) {
         stub::fail("a conv with fp16 maps is not eligible for the fp16 kernels (the fp32 kernel would read halfs as floats)");
         return PNP_ERR_UNSUPPORTED;
     }
-    conv_touch(a, cfg, gy, f16);
-    stub::convs.push_back({a, cfg, gy, stub::sid(s), f16});
+    conv_touch(a, cfg, gy, f16 ? 1 : (x3 ? 2 : 0));
+    stub::convs.push_back({a, cfg, gy, stub::sid(s), f16 ? 1 : (x3 ? 2 : 0)});
     return 0;
 }
 int launch_conv3x3_f16(const ConvArgs& a, int gy, hipStream_t s) {
     stub::cur = "launch_conv3x3_f16";
     stub::note_launch(s);
-    conv_touch(a, CONV_CFG_BIG, gy, true);
-    stub::convs.push_back({a, CONV_CFG_BIG, gy, stub::sid(s), true});
+    conv_touch(a, CONV_CFG_BIG, gy, 1);
+    stub::convs.push_back({a, CONV_CFG_BIG, gy, stub::sid(s), 1});
+    return 0;
+}
+int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t s) {
+    stub::cur = "launch_conv3x3_f16x3";
+    stub::note_launch(s);
+    conv_touch(a, cfg, 1, 2);
+    stub::convs.push_back({a, cfg, 1, stub::sid(s), 2});
+    return 0;
+}
+int launch_f16_lo_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t s) {
+    stub::cur = "launch_f16_lo_image";
+    stub::note_launch(s);
+    const size_t n = (size_t)nchunks * pnp_chunk_floats(ntb);
+    stub::RD("fp32 weight images", src, n * 4);
+    stub::WR("low fp16 weight images of the split", dst, n * 2);
     return 0;
 }
 int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t s) {
@@ -519,17 +538,17 @@ int run(const Scenario& sc) {
     const Workspace W0 = carve(g, ws, sc.t, sc.h, sc.w);
     for (const MixRec& m : mixes) mix_slot.push_back((int)(((const float*)m.dst - W0.mixw) % ((int64_t)ctx_bytes / 4) / ((int64_t)g->ndyn * IMG_WIDE)));
     for (const ConvRec& c : convs) {
-        conv_f16.push_back(c.f16_path ? 1 : 0);
+        conv_f16.push_back(c.path);
         conv_nsrc.push_back(c.a.nsrc);
         conv_mask.push_back(c.a.src_f16 | (c.a.out_f16 ? 16 : 0) | (c.a.out16 ? 32 : 0));
         if (!(c.a.wpar || c.a.wpar_h)) continue;
         const size_t pl = (c.a.par - par) / (3 * hw);
         block_frame.push_back((int)(pl % sc.t));
-        const float* wimg = c.f16_path ? nullptr : c.a.wsrc[0];
+        const float* wimg = c.path ? nullptr : c.a.wsrc[0];
         int u = -1;
         for (int k = 0; k < sc.contexts && u < 0; ++k) {
             const Workspace W = carve(g, ws + (int64_t)k * ctx_bytes, sc.t, sc.h, sc.w);
-            if (c.f16_path) {
+            if (c.path) {
                 const uint16_t* hh = (const uint16_t*)c.a.wsrc_h[0];
                 if (hh >= (const uint16_t*)W.mixh && hh < (const uint16_t*)W.mixh + (int64_t)sc.t * g->ndyn * IMG_WIDE)
                     u = (int)((hh - (const uint16_t*)W.mixh) / ((int64_t)g->ndyn * IMG_WIDE));
@@ -628,8 +647,8 @@ int main(int argc, char** argv) {
     qprouted.use_base_qp = 0;
     qprouted.with_bias = 0;
     qprouted.with_se = 0;
-    for (int prec = 0; prec < 2; ++prec) {
-        const std::string p = prec ? "f16_" : "f32_";
+    for (int prec = 0; prec < 3; ++prec) {
+        const std::string p = prec == 0 ? "f32_" : (prec == 1 ? "f16_" : "x3_");
         add(p + "ibbbp_t7", d, prec, 1, 7, 64, 96, 1, {"IBBBP"}, {25});
         add(p + "allB_t7", d, prec, 1, 7, 64, 64, 1, {"allB"}, {35});
         add(p + "allP_t7", d, prec, 1, 7, 64, 64, 1, {"allP"}, {15});

@@ -1,0 +1,278 @@
+"""GPU tests of the opt-in split-fp16 conv path (PNP_PREC_F16X3; csrc/conv_f16x3.hip), through the C ABI.
+
+Every operand of the 64-channel convs is carried as two fp16 numbers (hi + lo / 2048) and a product is three fp16 MFMAs with
+fp32 accumulation.  Unlike PNP_PREC_F16 the mode is held to the SAME gates as the exact fp32 path: the conv op against an fp64
+contraction of the UNROUNDED operands at the fp32 kernel's tolerance, the generator against the golden outputs of the imported
+reference at 1e-4 (north_star's gate is 1e-3).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as gu
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+TOL_CONV = 2e-5       # tests/test_gpu_ops.py's tolerance for the exact-fp32 MFMA conv
+TOL_PATH = 1e-4       # tests/test_gpu_generator.py's tolerance for the exact-fp32 path (north_star: 1e-3)
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def D(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).double()
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (24, 40), (37, 53), (64, 64), (128, 256), (180, 320)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_f16x3_conv_single_source_matches_fp64_on_unrounded_operands(hw, act):
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x = gu.syn.uniform(31, f'x{h}x{w}', (1, 64, h, w), -1, 1)
+    wt = gu.syn.uniform(31, 'w', (64, 64, 3, 3), -0.06, 0.06)
+    b = gu.syn.uniform(31, 'b', (64,), -0.1, 0.1)
+    res = gu.syn.uniform(31, f'r{h}x{w}', (1, 64, h, w), -1, 1)
+    ref = F.conv2d(D(x), D(wt), D(b), padding=1)
+    ref = [ref, F.relu(ref), F.leaky_relu(ref, 0.1)][act] + D(res)
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    rs = ops.nchw_to_nhwc(G(res))[0]
+    pw = ops.pack_conv3x3(G(wt))
+    out = ops.conv3x3_f16x3([xs], [pw], bias=G(b), residual=rs, act=act)
+    d3 = maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref)
+    d32 = maxdiff(ops.nhwc_to_nchw(ops.conv3x3([xs], [pw], bias=G(b), residual=rs, act=act).unsqueeze(0)), ref)
+    d16 = maxdiff(ops.nhwc_to_nchw(ops.conv3x3([xs], [ops.f16_image(pw)], bias=G(b), residual=rs, act=act, fp16=True).unsqueeze(0)), ref)
+    print(f'{h}x{w} act {act}: |d| vs fp64: f16x3 {d3:.2e}, fp32 MFMA {d32:.2e}, fp16 operands {d16:.2e}')
+    assert d3 < TOL_CONV / 4          # observed ~1e-6, like the fp32 kernel
+    assert d16 > 20 * d3              # plain fp16 operands are two orders worse: the split really ran
+
+
+def test_f16x3_conv_identity_weights_reproduce_22_bits_and_localise_layout_bugs():
+    """Identity weights: out = hi + lo / 2048 of x, i.e. x to 2^-22 relative; a wrong tap or channel shows as O(1)."""
+    from pnp_vcve_amd import ops
+    h, w = 24, 40
+    x = gu.syn.uniform(32, 'x', (1, 64, h, w), -1, 1)
+    perm = np.roll(np.arange(64), 5)
+    for (ky, kx) in [(1, 1), (0, 0), (2, 1), (1, 2)]:
+        wt = np.zeros((64, 64, 3, 3), np.float32)
+        wt[np.arange(64), perm, ky, kx] = 1.0
+        ref = F.conv2d(D(x), D(wt), padding=1)
+        out = ops.conv3x3_f16x3([ops.nchw_to_nhwc(G(x))[0]], [ops.pack_conv3x3(G(wt))])
+        assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) <= 2.0 ** -22, (ky, kx)
+
+
+@pytest.mark.parametrize('scale', [1e-3, 3e-5, 1e-6])
+def test_f16x3_small_magnitudes_keep_their_relative_accuracy(scale):
+    """Activations far below fp16's normal range (6.1e-5): hi underflows towards 0 and lo * 2048 carries the value."""
+    from pnp_vcve_amd import ops
+    h, w = 32, 48
+    x = gu.syn.uniform(33, 'x', (1, 64, h, w), -1, 1) * np.float32(scale)
+    wt = gu.syn.uniform(33, 'w', (64, 64, 3, 3), -0.06, 0.06)
+    ref = F.conv2d(D(x), D(wt), padding=1)
+    out = ops.conv3x3_f16x3([ops.nchw_to_nhwc(G(x))[0]], [ops.pack_conv3x3(G(wt))])
+    d = maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref)
+    print(f'scale {scale:g}: max|d| {d:.2e} of |ref|max {float(ref.abs().max()):.2e}')
+    assert d < max(1e-5 * float(ref.abs().max()), 1e-9)
+
+
+@pytest.mark.parametrize('nwide', [1, 2, 3])
+@pytest.mark.parametrize('with_lr', [False, True])
+def test_f16x3_conv_virtual_concat_is_a_launch_chain(nwide, with_lr):
+    """input_conv over [lr(3), wide...]: the RGB frame on the exact fp32 kernel, then one split launch per 64-channel source;
+    partial sums through `out`, the activation on the last link."""
+    from pnp_vcve_amd import ops
+    h, w = 40, 56
+    cin = (3 if with_lr else 0) + 64 * nwide
+    lr = gu.syn.uniform(34, 'lr', (1, 3, h, w), 0, 1)
+    wides = [gu.syn.uniform(34, f's{j}', (1, 64, h, w), -1, 1) for j in range(nwide)]
+    wt = gu.syn.uniform(34, f'w{cin}', (64, cin, 3, 3), -0.05, 0.05)
+    b = gu.syn.uniform(34, 'b', (64,), -0.1, 0.1)
+    cat = np.concatenate(([lr] if with_lr else []) + wides, axis=1)
+    ref = F.leaky_relu(F.conv2d(D(cat), D(wt), D(b), padding=1), 0.1)
+    lr4 = np.concatenate([lr, np.zeros((1, 1, h, w), np.float32)], axis=1)
+    srcs = ([ops.nchw_to_nhwc(G(lr4))[0]] if with_lr else []) + [ops.nchw_to_nhwc(G(s))[0] for s in wides]
+    wg = G(wt)
+    c0 = 3 if with_lr else 0
+    packed = ([ops.pack_conv3x3(wg, 0, 3)] if with_lr else []) + [ops.pack_conv3x3(wg, c0 + 64 * j, 64) for j in range(nwide)]
+    out = ops.conv3x3_f16x3(srcs, packed, bias=G(b), act=2)
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < TOL_CONV / 2
+
+
+def test_f16x3_conv_unsupported_shapes_are_refused_not_silently_rerouted():
+    from pnp_vcve_amd import ops
+    h, w = 16, 16
+    lr4 = torch.zeros(h, w, 4, device=dev())
+    wt = gu.syn.uniform(35, 'w', (64, 3, 3, 3), -0.05, 0.05)
+    with pytest.raises(RuntimeError):          # an RGB-only conv has no split form
+        ops.conv3x3_f16x3([lr4], [ops.pack_conv3x3(G(wt), 0, 3)])
+    x = torch.zeros(h, w, 64, device=dev())
+    w64 = ops.pack_conv3x3(G(gu.syn.uniform(35, 'w64', (64, 64, 3, 3), -0.05, 0.05)))
+    with pytest.raises(RuntimeError):          # several sources exclude a residual
+        ops.conv3x3_f16x3([x, x], [w64, w64], residual=x)
+
+
+def _front_half_inputs(seed, h, w, par_scale):
+    x = gu.syn.uniform(seed, f'x{h}', (1, 64, h, w), -1, 1)
+    wt = gu.syn.uniform(seed, 'w', (64, 64, 3, 3), -0.06, 0.06)
+    b = gu.syn.uniform(seed, 'b', (64,), -0.1, 0.1)
+    gam = gu.syn.uniform(seed, 'g', (64,), 0.5, 1.5)
+    w1 = [gu.syn.uniform(seed, f'w1_{j}', (64, 64, 1, 1), -0.1, 0.1) for j in range(3)]
+    cls = (gu.syn.uniform(seed, f'c{h}', ((h + 7) // 8, (w + 7) // 8), 0, 3).astype(np.int64)).clip(0, 2)
+    par = np.zeros((3, h, w), np.float32)
+    for j in range(3):
+        par[j] = np.kron((cls == j).astype(np.float32), np.ones((8, 8), np.float32))[:h, :w]
+    par *= np.float32(par_scale)
+    return x, wt, b, gam, w1, par
+
+
+@pytest.mark.parametrize('hw', [(32, 48), (72, 88), (37, 53)])
+@pytest.mark.parametrize('skip', [False, True])
+def test_f16x3_bae_front_half_matches_fp64(hw, skip):
+    """relu(gamma * (conv3x3(x) + b) + sum_j par_j * conv1x1_j(x)) (sr_backbone_utils.py:305-311): the split kernel sums each
+    1x1 branch on its own and scales it by par_j(pixel) on the output side, in fp32.  With and without per-tile branch
+    skipping (one-hot maps: most tiles need one or two of the three branches)."""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x, wt, b, gam, w1, par = _front_half_inputs(36, h, w, 200.0 / 255.0)
+    ref = F.conv2d(D(x), D(wt), D(b), padding=1) * D(gam).view(1, 64, 1, 1)
+    for j in range(3):
+        ref = ref + D(par[j]).view(1, 1, h, w) * F.conv2d(D(x), D(w1[j]))
+    ref = F.relu(ref)
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    pg = G(par)
+    flags = ops.par_tile_flags(pg) if skip else None
+    out = ops.conv3x3_f16x3([xs], [ops.pack_conv3x3(G(wt))], bias=G(b), gamma=G(gam),
+                            packed_w1x1=ops.pack_conv1x1([G(v) for v in w1]), par=pg, par_flags=flags, act=1)
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < TOL_CONV / 2
+
+
+def test_f16x3_dense_float_partition_map():
+    """A dense float partition map (every plane nonzero everywhere; configs with par_scale): all three branches on every tile."""
+    from pnp_vcve_amd import ops
+    h, w = 40, 64
+    x, wt, b, gam, w1, _ = _front_half_inputs(37, h, w, 1.0)
+    par = gu.syn.uniform(37, 'pd', (3, h, w), 0.05, 1.0)
+    ref = F.conv2d(D(x), D(wt), D(b), padding=1) * D(gam).view(1, 64, 1, 1)
+    for j in range(3):
+        ref = ref + D(par[j]).view(1, 1, h, w) * F.conv2d(D(x), D(w1[j]))
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    pg = G(par)
+    out = ops.conv3x3_f16x3([xs], [ops.pack_conv3x3(G(wt))], bias=G(b), gamma=G(gam),
+                            packed_w1x1=ops.pack_conv1x1([G(v) for v in w1]), par=pg, par_flags=ops.par_tile_flags(pg), act=0)
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < TOL_CONV / 2
+
+
+def test_f16x3_is_run_to_run_deterministic():
+    from pnp_vcve_amd import ops
+    h, w = 180, 320
+    x, wt, b, gam, w1, par = _front_half_inputs(38, h, w, 1.0 / 255.0)
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    pg = G(par)
+    args = dict(bias=G(b), gamma=G(gam), packed_w1x1=ops.pack_conv1x1([G(v) for v in w1]), par=pg,
+                par_flags=ops.par_tile_flags(pg), act=1)
+    pw = [ops.pack_conv3x3(G(wt))]
+    first = ops.conv3x3_f16x3([xs], pw, **args).clone()
+    for _ in range(5):
+        torch.randn(1 << 22, device=dev()).sin_()
+        assert torch.equal(ops.conv3x3_f16x3([xs], pw, **args), first)
+
+
+# ---------------------------------------------------------------- whole path
+def _run(case, precision):
+    import pnp_vcve_amd as P
+    cfg, sd_np, clip = gu.gen_case_inputs(case)
+    m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+    m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
+    m = m.to(dev()).eval()
+    m.precision = precision
+    a = {k: G(v) for k, v in clip.items()}
+    with torch.no_grad():
+        out = m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions'])
+    return out.cpu(), clip
+
+
+@pytest.mark.parametrize('case', gu.GEN_CASES, ids=[c['name'] for c in gu.GEN_CASES])
+def test_f16x3_generator_meets_the_fp32_gate_on_every_golden_case(case, record_property):
+    """Every golden case of the imported reference (tests/golden/), at the exact-fp32 path's own tolerance."""
+    ref = torch.from_numpy(gu.load_golden(case['name'])['out'])
+    out3, clip = _run(case, 'f16x3')
+    out32, _ = _run(case, 'fp32')
+    d3 = float((out3 - ref).abs().max())
+    d32 = float((out32 - ref).abs().max())
+    record_property('f16x3_maxabs', d3)
+    print(f"{case['name']}: f16x3 path max|d| = {d3:.3e} (fp32 path {d32:.3e})")
+    assert d3 < TOL_PATH
+    assert not torch.equal(out3, out32)           # the split kernels really ran
+    if ref.shape[-2:] == clip['lq'].shape[-2:]:   # north_star's statistic
+        gt = (torch.from_numpy(clip['lq']) + 0.02 * torch.from_numpy(
+            gu.syn.uniform(5, 'gt' + case['name'], clip['lq'].shape, -1, 1))).clamp(0, 1)
+        assert abs(cpu_ref.clip_psnr(ref, gt) - cpu_ref.clip_psnr(out3, gt)) < 1e-3
+
+
+def test_f16x3_precision_switch_resizes_buffers_and_round_trips():
+    import pnp_vcve_amd as P
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+    n32 = m._packed_floats
+    assert m.precision == 'fp32'
+    m.precision = 'f16x3'
+    assert m.precision == 'f16x3' and m.fp16_enabled is False and m._packed_floats == 2 * n32
+    m.precision = 'fp16'
+    assert m.fp16_enabled is True and m._packed_floats == n32 + n32 // 2
+    m.precision = 'fp32'
+    assert m._packed_floats == n32
+    with pytest.raises(ValueError):
+        m.precision = 'bf16'
+
+
+@pytest.mark.parametrize('deform', ['basic', 'fvc'])
+def test_f16x3_with_the_deformable_aligners(deform):
+    """deform='basic' | 'fvc': the offset convs and the DCN contraction stay on the exact fp32 kernels, the BAE blocks split."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2, deform=deform)
+    import pnp_vcve_amd as P
+    sd_np = gu.syn.make_state_dict(cfg, seed=181, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=182, n=1, t=3, h=72, w=104, slices='IBBBP', block=4, par_classes=3)
+    outs = {}
+    for prec in ('fp32', 'f16x3'):
+        m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+        m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
+        m = m.to(dev()).eval()
+        m.precision = prec
+        a = {k: G(v) for k, v in clip.items()}
+        with torch.no_grad():
+            outs[prec] = m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']).cpu()
+    d = float((outs['fp32'] - outs['f16x3']).abs().max())
+    print(f'deform {deform}: f16x3 vs fp32 max|d| {d:.3e}')
+    assert 0 < d < TOL_PATH
+
+
+def test_f16x3_full_width_720p_tracks_fp32():
+    """BASELINE configs[2]'s frame size (T = 2, 4 blocks): 7200 tiles per launch, every XCD band, ragged nothing."""
+    import pnp_vcve_amd as P
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=4)
+    sd_np = gu.syn.make_state_dict(cfg, seed=191, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=192, n=1, t=2, h=720, w=1280, slices='IBBBP', block=8, par_classes=3)
+    outs = {}
+    for prec in ('fp32', 'f16x3'):
+        m = P.build_backbone(dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **cfg))
+        m.load_state_dict(cpu_ref.to_torch_state(sd_np), strict=True)
+        m = m.to(dev()).eval()
+        m.precision = prec
+        a = {k: G(v) for k, v in clip.items()}
+        with torch.no_grad():
+            outs[prec] = m(a['lq'], a['QPs'], a['slices'], a['mvs'], a['base_QPs'], a['partitions']).cpu()
+    d = float((outs['fp32'] - outs['f16x3']).abs().max())
+    print(f'720p: f16x3 vs fp32 max|d| {d:.3e}')
+    assert 0 < d < TOL_PATH

@@ -61,7 +61,7 @@ def test_scheduler_is_clean_under_asan_and_ubsan(stub_run):
     exe, r, docs, env = stub_run
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr and 'LeakSanitizer' not in r.stderr, r.stderr[-4000:]
-    assert len(docs) == 2 * len(EXPECT) + 4
+    assert len(docs) == 3 * len(EXPECT) + 4
     for name, d in docs.items():
         assert d['pack_rc'] == 0 and d['forward_rc'] == 0 and d['errors'] == [], (name, d['errors'])
         # no event or stream outlives its generator; the workspace handed over is exactly contexts x the advertised size
@@ -83,7 +83,7 @@ def test_the_harness_catches_a_workspace_that_is_too_small(stub_run):
         assert any('leaves its buffer' in e for e in d['errors']), d['errors']
 
 
-@pytest.mark.parametrize('prec', ['f32', 'f16'])
+@pytest.mark.parametrize('prec', ['f32', 'f16', 'x3'])
 def test_key_frame_selection_matches_the_reference_rule(stub_run, prec):
     """iconvsr_ipb_par.py:60-62,81,116: key = slice in {I, P}, both ends forced; the backward sweep aligns the nearest key frame
     AFTER frame i, the forward sweep the nearest one BEFORE it -- read off the recorded warp launches (source slot, flow plane)."""
@@ -111,7 +111,7 @@ def test_key_frame_selection_matches_the_reference_rule(stub_run, prec):
         assert d['dcn_calls'] == (len(exp_key) if base == 'basic_t3' else 0)
 
 
-@pytest.mark.parametrize('prec', ['f32', 'f16'])
+@pytest.mark.parametrize('prec', ['f32', 'f16', 'x3'])
 def test_expert_mixtures_are_made_once_per_distinct_routing_value(stub_run, prec):
     """Dynamic_conv2d_se's mm(attention, weight) (sr_backbone_utils.py:198-202) is hoisted to once per distinct routing input of
     a clip: base_QP is constant over a clip (1 mixture per sample), QP routing (use_base_qp=False) varies per frame; every
@@ -135,7 +135,7 @@ def test_expert_mixtures_are_made_once_per_distinct_routing_value(stub_run, prec
 
 def test_event_pool_and_side_streams_are_reused(stub_run):
     _, _, docs, _ = stub_run
-    for prec in ('f32', 'f16'):
+    for prec in ('f32', 'f16', 'x3'):
         d = docs[f'{prec}_profiled_twice']
         assert d['event_pool_after_forward'][0] > 0 and d['event_pool_after_forward'][0] == d['event_pool_after_forward'][1]
         assert docs[f'{prec}_ibbbp_t7']['event_pool_after_forward'] == [0]           # no events without profiling
@@ -173,3 +173,22 @@ def test_fp16_mirrors_are_scheduled_consistently(stub_run):
         assert docs[nm]['errors'] == [] and docs[nm]['forward_rc'] == 0
     assert set(docs['f32_ibbbp_t7']['conv_map_mask']) == {0} and set(docs['f32_ibbbp_t7']['conv_f16_path']) == {0}
     assert set(docs['f16_basic_t3']['warp_f16']) == {0}                              # DCN aligners keep the r02 schedule
+
+
+def test_split_fp16_schedule_uses_the_split_kernel_where_it_applies(stub_run):
+    """PNP_PREC_F16X3: every NHWC64 conv with a 64-channel source (input convs, both halves of every BAE block, conv_hr) is handed
+    to the split kernel with both weight images (the stub checked hi and lo were written before being read); the RGB-only input
+    conv, the pixel-shuffle / RGB heads and the DCN offset convs stay on the fp32 kernels; no fp16 maps anywhere."""
+    _, _, docs, _ = stub_run
+    for name in ('x3_ibbbp_t7', 'x3_vsr_t2', 'x3_basic_t3', 'x3_p720_t2'):
+        d, f = docs[name], docs['f32_' + name[3:]]
+        assert d['errors'] == [] and set(d['conv_map_mask']) == {0} and set(d['warp_f16']) == {0}
+        assert d['conv_nsrc'] == f['conv_nsrc']                      # the same convs in the same order as the fp32 schedule
+        assert set(d['conv_f16_path']) == {0, 2} and set(f['conv_f16_path']) == {0}
+        # the convs with partition branches (BAE front halves) all run split
+        assert d['par_conv_frame'] == f['par_conv_frame']
+    d = docs['x3_ibbbp_t7']
+    n_split = sum(1 for p in d['conv_f16_path'] if p == 2)
+    # t = 7, 8 blocks: per frame and sweep 1 input conv + 16 block halves, except the last frame's backward input conv (RGB only);
+    # + conv_hr per frame; conv_last is an RGB head
+    assert n_split == 2 * 7 * 17 - 1 + 7 and len(d['conv_f16_path']) - n_split == 1 + 7
