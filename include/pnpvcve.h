@@ -211,16 +211,16 @@ int pnp_conv3x3_f16(int nsrc, const float* const* srcs_dev, const int* src_chann
  * hi = fp16(x), lo = fp16((x - hi) * 2048), a product is three fp16 MFMAs (hi*hi, lo*hi, hi*lo) accumulated in
  * fp32 -- fp32-level results (~1e-6 relative to pnp_conv3x3_f32) from the fp16 matrix pipe.  fp32 sources and
  * output.  packed_w_f32 are the fp32 images (read only for a 4-channel RGB0 source, which runs on the exact fp32
- * kernel; may be NULL for 64-channel sources); packed_w_hi = pnp_f16_image_from_f32, packed_w_lo =
- * pnp_f16_lo_image_from_f32 of the same fp32 images (64-channel sources and the 1x1 branches).  par_flags_dev:
- * optional pnp_par_tile_flags_f32 output.  Restrictions as for pnp_conv3x3_f16. */
-int pnp_f16_lo_image_from_f32(const float* packed_w_dev, void* dst_dev, int nchunks, void* stream);
+ * kernel; may be NULL for 64-channel sources); packed_w_x3 = pnp_f16x3_image_from_f32 of the same fp32 images
+ * (64-channel sources and the 1x1 branches; hi and lo halves interleaved: nchunks * 16384 bytes, nchunks as for
+ * pnp_f16_image_from_f32).  par_flags_dev: optional pnp_par_tile_flags_f32 output.  Restrictions as for
+ * pnp_conv3x3_f16. */
+int pnp_f16x3_image_from_f32(const float* packed_w_dev, void* dst_dev, int nchunks, void* stream);
 int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs_dev, const int* src_channels,
-                      const float* const* packed_w_f32_dev, const void* const* packed_w_hi_dev,
-                      const void* const* packed_w_lo_dev, const float* bias_dev, const float* gamma_dev,
-                      const void* packed_w1x1_hi_dev, const void* packed_w1x1_lo_dev, const float* par_dev,
-                      const int* par_flags_dev, const float* residual_dev, int act, float* out_dev, int h, int w,
-                      void* stream);
+                      const float* const* packed_w_f32_dev, const void* const* packed_w_x3_dev,
+                      const float* bias_dev, const float* gamma_dev, const void* packed_w1x1_x3_dev,
+                      const float* par_dev, const int* par_flags_dev, const float* residual_dev, int act,
+                      float* out_dev, int h, int w, void* stream);
 
 /* Per-frame sum of squared differences of the uint8-rounded frames (the statistic behind
  * psnr(tensor2img(a), tensor2img(b)), mmedit/core/misc.py:51-71 + core/evaluation/metrics.py:200-215):

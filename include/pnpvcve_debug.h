@@ -51,6 +51,15 @@ int pnp_conv3x3_f16_maps(int nsrc, const void* const* srcs_dev, const int* src_c
                          const float* residual_dev, int act, void* out_dev, int out_f16, void* out16_dev, int h, int w,
                          int chain, void* trace_dev, void* stream);
 
+/* pnp_conv3x3_f16x3 with the in-kernel timeline: trace_dev = 8 u64 per persistent block (512 at most): s_memtime at kernel
+ * start; cycles spent waiting for / splitting the halo into the A tiles; cycles in the K loops; s_memtime at the end; cycles in the
+ * epilogues; tiles done; block lifetime in 100 MHz s_memrealtime ticks. */
+int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs_dev, const int* src_channels,
+                         const float* const* packed_w_f32_dev, const void* const* packed_w_x3_dev, const float* bias_dev,
+                         const float* gamma_dev, const void* packed_w1x1_x3_dev, const float* par_dev,
+                         const int* par_flags_dev, const float* residual_dev, int act, float* out_dev, int h, int w,
+                         void* trace_dev, void* stream);
+
 /* pnp_mv_warp_nhwc_f32 writing its result as an fp16 (h,w,c) map (saturating round-to-nearest-even of the fp32 value). */
 int pnp_mv_warp_nhwc_f16out(const float* feat_dev, const float* flow_x_dev, const float* flow_y_dev, void* out16_dev, int h,
                             int w, int c, void* stream);

@@ -74,14 +74,17 @@ SIGNATURES = {
     'pnp_f16_image_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'pnp_conv3x3_f16': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
-    'pnp_f16_lo_image_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'pnp_f16x3_image_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'pnp_conv3x3_f16x3': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
-                                  POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_int, c_int, c_void_p]),
 }
 
 # include/pnpvcve_debug.h: kernel-variant selection / timelines for tests and tools
 DEBUG_SIGNATURES = {
+    'pnp_conv3x3_f16x3_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'pnp_conv3x3_f32_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p]),

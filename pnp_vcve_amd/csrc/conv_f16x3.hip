@@ -9,10 +9,14 @@
 // rate: ~5x fewer matrix-pipe cycles than the fp32 path.  Feature maps stay fp32 in HBM (reader and writer both): the mode
 // changes no data layout, only how a conv multiplies.  Opt-in (PNP_PREC_F16X3); the default and the headline stay exact fp32.
 //
-// Kernel: the small-frame fp16 kernel's structure (conv_f16.hip) for every frame size -- one 8x16 tile per 4-wave block, two
-// fp16 A tiles (hi, lo) converted from the fp32 halo, weight chunks streamed from L2 through a 3-slot ring: per 3x3 tap (or 1x1
-// partition branch) one chunk of hi weights (4 k-steps x {hi*hi, lo*hi} x 2 N tiles) and one of lo weights (4 k-steps x hi*lo
-// x 2 N tiles).  A partition branch is summed on its own and scaled by par_j(pixel) on the output side, in fp32.  80.9 KiB of LDS -> two blocks per CU.  LDS reads are 1 KiB per MFMA (6 fragments per 6 MFMAs).
+// Kernel: persistent 4-wave blocks, two per CU, each walking 8x16 tiles: two fp16 A tiles (hi, lo) converted from the fp32 halo
+// -- which is requested one tile ahead and rides in registers through the K loop --, weight chunks streamed from L2 through a
+// 3-slot ring.  The weight image
+// interleaves the two halves of the split so that every 8 KiB chunk is self-contained: chunk (tap, k-half) = 2 k-steps x
+// [hi N0, hi N1, lo N0, lo N1] units, i.e. per k-step 6 fragment reads (A hi, A lo, 4 x B) for 6 MFMAs -- 1 KiB of LDS reads
+// per MFMA, the ratio the matrix pipe sustains at full rate (profiles/r03_ub_lds.txt).  Chunks are requested four ahead into
+// register sets (L2 latency), written into the ring two ahead.  80.9 KiB of LDS -> two blocks per CU.  A partition branch
+// scales its A fragments by par_j(pixel) in fp32 and splits the product again (VALU work beside the MFMAs).
 #include "conv_mfma.h"
 #include "f16_util.h"
 
@@ -27,8 +31,8 @@ constexpr float X3_SCALE = 2048.f, X3_INV = 1.f / 2048.f;
 
 struct X3Args {
     const float* src;            // NHWC64 fp32
-    const _Float16 *w_hi, *w_lo; // 72 units each: fp16(w) and fp16((w - hi) * 2048) in the fp16 image layout
-    const _Float16 *wpar_hi, *wpar_lo;   // 24 units each or nullptr
+    const _Float16* w;           // split image (launch_f16x3_image): 18 chunks of 8 units
+    const _Float16* wpar;        // 6 chunks (branch, k-half) or nullptr
     const float* par;
     long par_plane;
     const int* par_flags;
@@ -36,262 +40,328 @@ struct X3Args {
     float* out;
     int res_pre;                 // residual is added BEFORE the activation (partial sum of a source chain)
     int H, W, act;
+    unsigned long long* dbg;     // timeline: 8 u64 per block or nullptr
 };
 
-template <bool PAR>
+// Halo geometry: 10 rows x 18 pixels x 16 float4.  Requests 0..9: row k, pixels 0..15 (thread t: pixel t >> 4, float4 t & 15);
+// requests 10, 11: the two right-hand pixel columns (item j = t + 256 (k - 10): row j >> 5, pixel 16 + ((j >> 4) & 1)) -- so the
+// global offset and the LDS address of request k are one per-thread base plus k times a constant (no per-request registers).
+template <bool PAR, bool DBG>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
-    constexpr int NC = 18 + (PAR ? 6 : 0);                   // chunks: (hi, lo) per tap, then (hi, lo) per partition branch
+    constexpr int NC = 18 + (PAR ? 6 : 0);                   // chunks: two k-halves per tap, then two per partition branch
+    constexpr int NSET = 4;                                  // register sets of weight chunks (chunk c travels in set c % 4)
     constexpr int WPT = 2;
+    constexpr int EIT = 8;
+    constexpr int RQC = 16;                                  // the chunk at whose top the residual rows and the next halo are requested
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned long long dbg_t0 = 0, dbg_p = 0, dbg_k = 0, dbg_e = 0;
+    int dbg_n = 0;
+    unsigned long long dbg_r0 = 0;
+    if (DBG) {
+        dbg_t0 = __builtin_amdgcn_s_memtime();
+        dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
     const int ntiles = tiles_x * ((H + TH - 1) / TH);
-    int tile;
-    {   // XCD-aware remap: each XCD walks a contiguous band of tiles (halo rows meet in its L2)
-        const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
-        const int q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
-    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-    char* const sAh = smem;
-    char* const sAl = smem + A_BYTES;
+    // Persistent blocks, two per CU.  XCD x (blockIdx & 7) owns the contiguous band of tiles [ntiles*x/8, ntiles*(x+1)/8); its
+    // blocks walk the band interleaved (block i takes tiles i, i + per, ...), so at any moment an XCD works on one window of
+    // consecutive tiles whose shared halo rows meet in its L2.
+    const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    const int band_hi = (int)((long)ntiles * (xcd + 1) / 8);
+    int tile = (int)((long)ntiles * xcd / 8) + (blockIdx.x >> 3);
+    if (tile >= band_hi) return;
     char* const sR = smem + 2 * A_BYTES;
 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
+    const unsigned row_bytes = (unsigned)W * 256u;
     const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, map_bytes);
     const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : (const void*)a.src, a.residual ? map_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : (const void*)a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, map_bytes);
     const __amdgpu_buffer_rsrc_t r_flags = make_rsrc((PAR && a.par_flags) ? (const void*)a.par_flags : (const void*)a.src,
                                                      (PAR && a.par_flags) ? (unsigned)ntiles * 4u : 0);
-    const int pfl_v = PAR ? __builtin_bit_cast(int, buf_load1(r_flags, (unsigned)tile * 4u)) : 0;
-
-    // ---- requests: fp32 halo, the first weight chunks, residual rows / partition values
-    f32x4 areg[X3_AIT];
-    const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * 256u;
-#pragma unroll
-    for (int k = 0; k < X3_AIT; ++k) {
-        const int i = t + 256 * k;
-        const int pix = i >> 4, cs = i & 15;
-        const int ry = pix / PW, rx = pix - ry * PW;
-        const bool ok = (pix < NPIX) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);  // rows outside the image leave the descriptor by themselves
-        areg[k] = buf_load4(r_src, ok ? hbase + (unsigned)(ry * W + rx) * 256u + (unsigned)cs * 16u : OOB);
-    }
-    const f32x4* whi = reinterpret_cast<const f32x4*>(a.w_hi);
-    const f32x4* wlo = reinterpret_cast<const f32x4*>(a.w_lo);
-    const f32x4* phi = reinterpret_cast<const f32x4*>(a.wpar_hi);
-    const f32x4* plo = reinterpret_cast<const f32x4*>(a.wpar_lo);
-    int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
-    auto bsel = [&](int j) { return j == 0 ? bs0 : (j == 1 ? bs1 : bs2); };
-    auto chunk_ptr = [&](int c) -> const f32x4* {          // 512 float4 per chunk; c < 18 compile-time, branch chunks via bsel
-        if (c < 18) return ((c & 1) ? wlo : whi) + (c >> 1) * 512;
-        return ((c & 1) ? plo : phi) + bsel((c - 18) >> 1) * 512;
-    };
-    f32x4 wreg[2][WPT];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const f32x4* g = chunk_ptr(c);
-        f32x4 v[WPT];
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) v[i] = g[t + 256 * i];
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * X3_CHUNK + (t + 256 * i) * 16) = v[i];
-    }
-    {
-        const f32x4* g = chunk_ptr(2);
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) wreg[0][i] = g[t + 256 * i];
-    }
-    constexpr int EIT = 8;
+    // weight chunks through descriptors too: voffset = 16 t for every load, the chunk in the SCALAR offset -- no per-chunk
+    // 64-bit address pairs for the compiler to hoist out of the tile loop and spill
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.w, 18u * X3_CHUNK);
+    const __amdgpu_buffer_rsrc_t r_wp = make_rsrc(PAR ? (const void*)a.wpar : (const void*)a.w, 6u * X3_CHUNK);
     const int ec = lane & 15, ep = lane >> 4, n0 = lane & 31;
     const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     const float k_pre = a.res_pre ? 1.f : 0.f, k_post = 1.f - k_pre;
-    float bco[2], gco[2], pv[3] = {0.f, 0.f, 0.f};
-    f32x4 res4[EIT];
+    float bco[2], gco[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         bco[j] = a.bias ? a.bias[j * 32 + n0] : 0.f;
         gco[j] = a.gamma ? a.gamma[j * 32 + n0] : 1.f;
     }
-    const unsigned row_bytes = (unsigned)W * 256u;
-    {
-        const unsigned rbase = ((unsigned)((ty0 + 2 * wave) * W + tx0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
+    const int a_off = (2 * wave + my) * RSB + mx * PSB + 16 * h;
+    // per-thread halo bases (see above)
+    const int hp = t >> 4, hcs = t & 15;
+    const int h2r = t >> 5, h2x = 16 + ((t >> 4) & 1);
+    const unsigned g_main = (unsigned)hp * 256u + (unsigned)hcs * 16u;                       // + (row k) * row_bytes
+    const unsigned g_side = (unsigned)h2r * row_bytes + (unsigned)h2x * 256u + (unsigned)hcs * 16u;   // + 8 rows for request 11
+    char* const l_main = smem + hp * PSB + hcs * 8;                                         // + k * RSB
+    // request 11 covers rows 8, 9 only (t < 64): the other threads park their (zero) value in the pad bytes of row 9
+    char* const l_side = smem + h2r * RSB + h2x * PSB + hcs * 8;
+    char* const l_side11 = t < 64 ? l_side + 8 * RSB : smem + 9 * RSB + PW * PSB + hcs * 8;
+
+    // ---- requests that travel ahead of their tile: the fp32 halo (12 x 16 B per thread) and its partition values / flags
+    f32x4 areg[X3_AIT];
+    float pvn[3] = {0.f, 0.f, 0.f};
+    int pfn = 0;
+    auto request_tile = [&](int tl, bool live) {             // !live: every offset out of range (loads return 0, no branch)
+        const int ty0 = (tl / tiles_x) * TH, tx0 = (tl % tiles_x) * TW;
+        const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * 256u;
+        const bool ok_main = live & ((unsigned)(tx0 - 1 + hp) < (unsigned)W);    // rows outside the image leave the descriptor by themselves
+        const bool ok_side = live & ((unsigned)(tx0 - 1 + h2x) < (unsigned)W);
 #pragma unroll
-        for (int i = 0; i < EIT; ++i) {
-            const bool ok = tx0 + ep + 4 * (i & 3) < W;
-            res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
-        }
+        for (int k = 0; k < 10; ++k) areg[k] = buf_load4(r_src, ok_main ? hbase + g_main + (unsigned)k * row_bytes : OOB);
+        areg[10] = buf_load4(r_src, ok_side ? hbase + g_side : OOB);
+        areg[11] = buf_load4(r_src, (ok_side & (t < 64)) ? hbase + g_side + 8u * row_bytes : OOB);
         if (PAR) {
             const int gy = ty0 + 2 * wave + my, gx = tx0 + mx;
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj)
-                pv[jj] = buf_load1(r_par, ((gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+                pvn[jj] = buf_load1(r_par, (live & (gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+            pfn = __builtin_bit_cast(int, buf_load1(r_flags, live ? (unsigned)tl * 4u : OOB));
         }
-    }
-    // ---- fp32 halo -> the two fp16 A tiles: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048)
+    };
+    int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
+    auto bsel = [&](int j) { return j == 0 ? bs0 : (j == 1 ? bs1 : bs2); };
+    f32x4 wreg[NSET][WPT];
+    auto request_chunk = [&](int c) {                       // c < 18 compile-time, branch chunks via bsel; into set c % NSET
 #pragma unroll
-    for (int k = 0; k < X3_AIT; ++k) {
-        const int i = t + 256 * k;
-        const int pix = i >> 4, cs = i & 15;
-        const int ry = pix / PW, rx = pix - ry * PW;
-        if (pix < NPIX) {
+        for (int i = 0; i < WPT; ++i) {
+            const int so = (c < 18 ? c : bsel((c - 18) >> 1) * 2 + (c & 1)) * X3_CHUNK + i * 4096;
+            wreg[c % NSET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c < 18 ? r_w : r_wp, t * 16, so, 0));
+        }
+    };
+    auto request_first_chunks = [&]() {                     // chunks 0..3 of a tile: the same images for every tile
+#pragma unroll
+        for (int c = 0; c < 4; ++c) request_chunk(c);
+    };
+    request_tile(tile, true);
+    request_first_chunks();
+
+    for (;;) {
+        unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0;
+        if (DBG) dbg_a = __builtin_amdgcn_s_memtime();
+        const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+        // ---- fp32 halo -> the two fp16 A tiles: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048); chunks 0, 1 -> ring
+#pragma unroll
+        for (int k = 0; k < X3_AIT; ++k) {
             const h4 hi = to_h4(areg[k]);
             const f32x4 rem = (areg[k] - __builtin_convertvector(hi, f32x4)) * X3_SCALE;
-            const int o = ry * RSB + rx * PSB + cs * 8;
-            *reinterpret_cast<h4*>(sAh + o) = hi;
-            *reinterpret_cast<h4*>(sAl + o) = to_h4(rem);
+            char* d = k < 10 ? l_main + k * RSB : (k == 10 ? l_side : l_side11);
+            *reinterpret_cast<h4*>(d) = hi;
+            *reinterpret_cast<h4*>(d + A_BYTES) = to_h4(rem);
         }
-    }
-    lds_barrier();
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * X3_CHUNK + (t + 256 * i) * 16) = wreg[c][i];
+        float pv[3] = {pvn[0], pvn[1], pvn[2]};
+        if (PAR) {
+            ncr = NC;
+            bs0 = 0, bs1 = 1, bs2 = 2;
+            if (a.par_flags) {
+                const int f0 = __builtin_amdgcn_readfirstlane(pfn) & 7;
+                const int f1 = f0 & (f0 - 1), f2 = f1 & (f1 - 1);
+                ncr = 18 + 2 * __builtin_popcount(f0);
+                bs0 = f0 ? __builtin_ctz(f0) : 0;
+                bs1 = f1 ? __builtin_ctz(f1) : 0;
+                bs2 = f2 ? __builtin_ctz(f2) : 0;
+            }
+        }
+        lds_barrier();
+        const int next = tile + per;
+        const bool has_next = next < band_hi;
+        if (DBG) dbg_b = __builtin_amdgcn_s_memtime();
 
-    // ---- K loop: chunk c from ring slot c % 3; even chunks hold hi weights (hi*hi -> acc_hi, lo*hi -> acc_lo), odd ones lo
-    //      weights (hi*lo -> acc_lo)
-    const int a_off = (2 * wave + my) * RSB + mx * PSB + 16 * h;
-    f32x16 acc_hi[2], acc_lo[2], br_hi[2];           // br_hi: the hi*hi sum of ONE partition branch (PAR only)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc_hi[j][r] = 0.f;
-            acc_lo[j][r] = 0.f;
-            br_hi[j][r] = 0.f;
-        }
-    auto fold = [&](bool with_bias) {          // acc_hi <- ((acc_hi + acc_lo / 2048) [+ bias]) [* gamma]; acc_lo <- 0
+        // ---- K loop: chunk c from ring slot c % 3: two k-steps of hi*hi -> acc_hi, lo*hi + hi*lo -> acc_lo
+        f32x16 acc_hi[2], acc_lo[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc_hi[j][r] + acc_lo[j][r] * X3_INV;
-                acc_hi[j][r] = with_bias ? (v + bco[j]) * gco[j] : v;
+                acc_hi[j][r] = 0.f;
                 acc_lo[j][r] = 0.f;
             }
-    };
+        auto fold = [&](bool with_bias) {          // acc_hi <- ((acc_hi + acc_lo / 2048) [+ bias]) [* gamma]; acc_lo <- 0
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (PAR && c == 15 && a.par_flags) {         // first use of the flags: chunk 18 is requested below
-            const int f0 = __builtin_amdgcn_readfirstlane(pfl_v) & 7;
-            const int f1 = f0 & (f0 - 1), f2 = f1 & (f1 - 1);
-            ncr = 18 + 2 * __builtin_popcount(f0);
-            bs0 = f0 ? __builtin_ctz(f0) : 0;
-            bs1 = f1 ? __builtin_ctz(f1) : 0;
-            bs2 = f2 ? __builtin_ctz(f2) : 0;
-        }
-        if (PAR && c >= 18 && c >= ncr) break;
-        if (c + 3 < NC && (!PAR || c + 3 < ncr)) {
-            const f32x4* g = chunk_ptr(c + 3);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) wreg[(c + 1) & 1][i] = g[t + 256 * i];
-        }
-        const char* b_lane = sR + (c % X3_RING) * X3_CHUNK + lane * 16;
-        const int tap = c >> 1, dy = c < 18 ? tap / 3 : 1, dx = c < 18 ? tap % 3 : 1;
-        const bool lo_w = c & 1;
-        if (PAR && c == 18) fold(true);                // (conv + bias) * gamma BEFORE the 1x1 partition branches
-#pragma unroll
-        for (int sk = 0; sk < 4; ++sk) {
-            const int o = a_off + dy * RSB + dx * PSB + 32 * sk;
-            const h8 ah = *reinterpret_cast<const h8*>(sAh + o);
-            const h8 b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
-            const h8 b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
-            if (!lo_w) {
-                const h8 al = *reinterpret_cast<const h8*>(sAl + o);
-                if (!PAR || c < 18) {
-                    acc_hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0, acc_hi[0], 0, 0, 0);
-                    acc_hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1, acc_hi[1], 0, 0, 0);
-                } else {
-                    br_hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0, br_hi[0], 0, 0, 0);
-                    br_hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1, br_hi[1], 0, 0, 0);
-                }
-                acc_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0, acc_lo[0], 0, 0, 0);
-                acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1, acc_lo[1], 0, 0, 0);
-            } else {
-                acc_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0, acc_lo[0], 0, 0, 0);
-                acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1, acc_lo[1], 0, 0, 0);
-            }
-        }
-        if (PAR && c >= 18 && lo_w) {                  // one branch done: out += par_j(pixel) * conv1x1_j(x), scaled on the OUTPUT
-            const int bi = bsel((c - 18) >> 1);        // side (sr_backbone_utils.py:310-311 multiplies after the conv, too)
-            const float pmine = bi == 0 ? pv[0] : (bi == 1 ? pv[1] : pv[2]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {             // accumulator register r holds pixel row (r&3) + 8*(r>>2) + 4*h: lane `row` has its value
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float pr = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(row * 4, __builtin_bit_cast(int, pmine)));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc_hi[j][r] += pr * (br_hi[j][r] + acc_lo[j][r] * X3_INV);
-                    br_hi[j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc_hi[j][r] + acc_lo[j][r] * X3_INV;
+                    acc_hi[j][r] = with_bias ? (v + bco[j]) * gco[j] : v;
                     acc_lo[j][r] = 0.f;
                 }
+        };
+        f32x4 res4[EIT];
+#pragma unroll
+        for (int i = 0; i < EIT; ++i) res4[i] = (f32x4)(0.f);
+        struct Frag { h8 ah, al, b[4]; };                    // one k-step: A hi, A lo, B hi N0 / hi N1 / lo N0 / lo N1
+        auto load_frag = [&](int c, int s2) {               // c, s2 compile-time after unrolling
+            const int tap = c >> 1, kh = c & 1, dy = c < 18 ? tap / 3 : 1, dx = c < 18 ? tap % 3 : 1;
+            const int o = a_off + dy * RSB + dx * PSB + 32 * (2 * kh + s2);
+            const char* b_lane = sR + (c % X3_RING) * X3_CHUNK + lane * 16;
+            Frag f;
+            f.ah = *reinterpret_cast<const h8*>(smem + o);
+            f.al = *reinterpret_cast<const h8*>(smem + A_BYTES + o);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f.b[u] = *reinterpret_cast<const h8*>(b_lane + (s2 * 4 + u) * UNIT);
+            return f;
+        };
+        Frag fr = load_frag(0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (PAR && c >= 18 && c >= ncr) break;
+            if (c + 4 < NC && (!PAR || c + 4 < ncr)) request_chunk(c + 4);
+            if (c == RQC) {
+                // After the last 3x3 chunk request: memory returns in order, so a halo request (HBM) ahead of a weight chunk
+                // (L2) would hold the chunk back.  Residual rows / partial sums of THIS tile first (the epilogue needs them),
+                // then the halo of the NEXT tile, which rides in registers through the rest of the loop and the epilogue.
+                if (!PAR) {
+                    const unsigned rbase = ((unsigned)((ty0 + 2 * wave) * W + tx0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
+#pragma unroll
+                    for (int i = 0; i < EIT; ++i) {
+                        const bool ok = tx0 + ep + 4 * (i & 3) < W;
+                        res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
+                    }
+                }
+                if (!PAR) request_tile(has_next ? next : tile, has_next);
             }
-        }
-        if (c + 2 < NC && (!PAR || c + 2 < ncr)) {
-            char* d = sR + ((c + 2) % X3_RING) * X3_CHUNK;     // slot of chunk c - 1: every wave left it at the previous barrier
+            float pj = 1.f;
+            if (PAR && c >= 18) {
+                if (c == 18) fold(true);                   // (conv + bias) * gamma BEFORE the 1x1 partition branches
+                const int bi = bsel((c - 18) >> 1);
+                pj = bi == 0 ? pv[0] : (bi == 1 ? pv[1] : pv[2]);
+            }
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[c & 1][i];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                // fragments of the NEXT k-step before this one's MFMAs -- across the chunk boundary too: chunk c + 1 has been
+                // in the ring since the barrier that ended chunk c - 1, the A tiles do not change
+                Frag nf;
+                if (s2 == 0) nf = load_frag(c, 1);
+                else if (c + 1 < NC) nf = load_frag(c + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);          // the reads stay AHEAD of the MFMAs (the scheduler would sink them to their use)
+                h8 ah = fr.ah, al = fr.al;
+                if (PAR && c >= 18) {
+                    // par_j(pixel) * x as a split number again: (hi + lo / 2048) is exact in fp32 (22 bits), one fp32 rounding
+                    // for the product, then the same split as the halo
+                    typedef float f32x8 __attribute__((ext_vector_type(8)));
+                    const f32x8 v = (__builtin_convertvector(ah, f32x8) + __builtin_convertvector(al, f32x8) * X3_INV) * pj;
+                    ah = __builtin_convertvector(__builtin_elementwise_min(__builtin_elementwise_max(v, (f32x8)(-65504.f)), (f32x8)(65504.f)), h8);
+                    al = __builtin_convertvector((v - __builtin_convertvector(ah, f32x8)) * X3_SCALE, h8);
+                }
+                acc_hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[0], acc_hi[0], 0, 0, 0);
+                acc_hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[1], acc_hi[1], 0, 0, 0);
+                acc_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fr.b[0], acc_lo[0], 0, 0, 0);
+                acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fr.b[1], acc_lo[1], 0, 0, 0);
+                acc_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[2], acc_lo[0], 0, 0, 0);
+                acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[3], acc_lo[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s2 == 0 || c + 1 < NC) fr = nf;
+            }
+            if (c + 2 < NC && (!PAR || c + 2 < ncr)) {
+                char* d = sR + ((c + 2) % X3_RING) * X3_CHUNK;     // slot of chunk c - 1: every wave left it at the previous barrier
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[(c + 2) % NSET][i];
+            }
+            lds_barrier();
         }
-        lds_barrier();
-    }
-    fold(!PAR || ncr == 18);         // PAR with branches: bias / gamma went in before them; otherwise here
+        if (DBG) dbg_c = __builtin_amdgcn_s_memtime();
+        // the branch chunks' VALU work (scaling and re-splitting A fragments) needs the registers: the next halo only now
+        if (PAR) request_tile(has_next ? next : tile, has_next);
+        request_first_chunks();          // every set is free again; the latency hides behind the epilogue
+        fold(!PAR || ncr == 18);         // PAR with branches: bias / gamma went in before them; otherwise here
 
-    // ---- epilogue: transpose through the dead LDS, [+ partial sum], activation, [+ residual], whole pixel rows to HBM
-    float* sT = reinterpret_cast<float*>(smem + wave * 8192);
-    const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+        // ---- epilogue: transpose through the dead A tiles, [+ partial sum], activation, [+ residual], whole pixel rows to HBM
+        float* sT = reinterpret_cast<float*>(smem + wave * 8192);
+        const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc_hi[j][r];
-    asm volatile("" ::: "memory");
-    f32x4 rows[EIT];
+            for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc_hi[j][r];
+        asm volatile("" ::: "memory");
+        f32x4 rows[EIT];
 #pragma unroll
-    for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
-    asm volatile("" ::: "memory");
+        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
+        asm volatile("" ::: "memory");
+        const unsigned obase = ((unsigned)(ty0 + 2 * wave) * (unsigned)W + (unsigned)(tx0 + ep)) * 256u + (unsigned)ec * 16u;
 #pragma unroll
-    for (int i = 0; i < EIT; ++i) {
-        f32x4 v = rows[i] + k_pre * res4[i];
-        v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
-        v += k_post * res4[i];
-        const int gx = tx0 + ep + 4 * (i & 3);
-        const unsigned o = ((unsigned)(ty0 + 2 * wave + (i >> 2)) * (unsigned)W + (unsigned)gx) * 256u + (unsigned)ec * 16u;
-        buf_store4(r_out, gx < W ? o : OOB, v);
+        for (int i = 0; i < EIT; ++i) {
+            f32x4 v = rows[i] + k_pre * res4[i];
+            v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
+            v += k_post * res4[i];
+            const bool ok = tx0 + ep + 4 * (i & 3) < W;
+            buf_store4(r_out, ok ? obase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB, v);
+        }
+        if (DBG) {
+            dbg_p += dbg_b - dbg_a;
+            dbg_k += dbg_c - dbg_b;
+            dbg_e += __builtin_amdgcn_s_memtime() - dbg_c;
+            ++dbg_n;
+        }
+        if (!has_next) break;
+        tile = next;
+        lds_barrier();                   // the transposition rows are read: the next tile may overwrite the A tiles
+    }
+    if (DBG && t == 0) {
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
+        d[0] = dbg_t0;
+        d[1] = dbg_p;
+        d[2] = dbg_k;
+        d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = dbg_e;
+        d[5] = dbg_n;
+        d[6] = __builtin_amdgcn_s_memrealtime() - dbg_r0;       // 100 MHz
     }
 }
 
-// fp32 B image -> the LOW fp16 image of the split: fp16((w - fp16(w)) * 2048), same element order as f16_image_kernel
-__global__ __launch_bounds__(256) void f16_lo_image_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int ntb, long total) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// fp32 B image -> the split image: per 64-deep chunk of the fp32 image (a tap / a 1x1 branch) two 8 KiB chunks (k-halves) of
+// 2 k-steps x [hi N0, hi N1, lo N0, lo N1] fragment units; hi = fp16(w) (saturating), lo = fp16((w - hi) * 2048)
+__global__ __launch_bounds__(256) void f16x3_image_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // index into the plain fp16 image (f16_image_kernel's order)
     if (idx >= total) return;
-    const int per_chunk = PNP_CHUNK_Q * ntb * 256;
+    constexpr int per_chunk = PNP_CHUNK_Q * 2 * 256;                   // 4096
     const long chunk = idx / per_chunk;
     const int rem = (int)(idx - chunk * per_chunk);
-    const int j = rem & 7, lane = (rem >> 3) & 63, nt = (rem >> 9) % ntb, s = rem / (512 * ntb);
+    const int j = rem & 7, lane = (rem >> 3) & 63, nt = (rem >> 9) & 1, s = rem >> 10;
     const int n = lane & 31, hh = lane >> 5;
     const int k = 16 * s + 8 * hh + j;
-    const float v = src[chunk * per_chunk + (((k >> 3) * ntb + nt) * 64 + ((k >> 2) & 1) * 32 + n) * 4 + (k & 3)];
+    const float v = src[chunk * per_chunk + (((k >> 3) * 2 + nt) * 64 + ((k >> 2) & 1) * 32 + n) * 4 + (k & 3)];
     const _Float16 hi = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-    dst[idx] = (_Float16)fminf(fmaxf((v - (float)hi) * X3_SCALE, -65504.f), 65504.f);
+    const _Float16 lo = (_Float16)fminf(fmaxf((v - (float)hi) * X3_SCALE, -65504.f), 65504.f);
+    _Float16* d = dst + chunk * (2 * per_chunk) + (s >> 1) * per_chunk + ((s & 1) * 4 + nt) * 512 + lane * 8 + j;
+    d[0] = hi;
+    d[2 * 512] = lo;
 }
 
-template <bool PAR>
+template <bool PAR, bool DBG>
 int launch_x3(const X3Args& xa, hipStream_t stream) {
-    auto kern = conv3x3_f16x3_kernel<PAR>;
+    auto kern = conv3x3_f16x3_kernel<PAR, DBG>;
     static PnpPerDevice once;
     const hipError_t attr_err = once.run([&](int, int&) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
     const int tiles = ((xa.W + TW - 1) / TW) * ((xa.H + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), X3_LDS, stream, xa);
+    int per_xcd = (tiles + 7) / 8;                // blocks per XCD: two per CU at most (32 CUs), one tile each on small frames
+    if (per_xcd > 64) per_xcd = 64;
+    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(256), X3_LDS, stream, xa);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int launch_f16_lo_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t stream) {
-    if (nchunks < 1 || (ntb != 1 && ntb != 2)) return PNP_ERR_BAD_ARG;
-    const long total = (long)nchunks * pnp_chunk_floats(ntb);
-    hipLaunchKernelGGL(f16_lo_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src,
-                       reinterpret_cast<_Float16*>(dst), ntb, total);
+int launch_f16x3_image(const float* src, void* dst, int nchunks, hipStream_t stream) {
+    if (nchunks < 1) return PNP_ERR_BAD_ARG;
+    const long total = (long)nchunks * pnp_chunk_floats(2);
+    hipLaunchKernelGGL(f16x3_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src,
+                       reinterpret_cast<_Float16*>(dst), total);
     return (int)hipGetLastError();
 }
 
@@ -321,10 +391,8 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         const bool last = k == nwide - 1;
         X3Args x;
         x.src = a.src[wide[k]];
-        x.w_hi = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]);
-        x.w_lo = reinterpret_cast<const _Float16*>(a.wsrc_l[wide[k]]);
-        x.wpar_hi = reinterpret_cast<const _Float16*>(a.wpar_h);
-        x.wpar_lo = reinterpret_cast<const _Float16*>(a.wpar_l);
+        x.w = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]);
+        x.wpar = reinterpret_cast<const _Float16*>(a.wpar_h);
         x.par = a.par;
         x.par_plane = a.par_plane;
         x.par_flags = a.par_flags;
@@ -336,7 +404,9 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         x.H = a.H;
         x.W = a.W;
         x.act = last ? a.act : 0;
-        const int rc = x.wpar_hi ? launch_x3<true>(x, stream) : launch_x3<false>(x, stream);
+        x.dbg = a.dbg;
+        const int rc = x.wpar ? (x.dbg ? launch_x3<true, true>(x, stream) : launch_x3<true, false>(x, stream))
+                              : (x.dbg ? launch_x3<false, true>(x, stream) : launch_x3<false, false>(x, stream));
         if (rc) return rc;
         have_partial = true;
     }

@@ -10,10 +10,9 @@ struct ConvArgs {
     int nsrc;
     const float* wpar;      // 3 chunks (conv16x16, conv16x8, conv8x8) or nullptr
     const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
-    const void* wsrc_h[4];  // fp16 twins of wsrc / wpar (conv_f16.hip), read only when prec == 1
+    const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo
+                            // interleaved, twice the halfs; conv_f16x3.hip launch_f16x3_image)
     const void* wpar_h;
-    const void* wsrc_l[4];  // prec == 2: the LOW fp16 images of the split, fp16((w - hi) * 2048) (conv_f16x3.hip)
-    const void* wpar_l;
     int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
                             // 2 split fp16 (hi + lo / 2048, three MFMAs per product, fp32-level results; where conv_f16x3_eligible)
     int src_f16, out_f16;   // prec 1, out_mode 0: bit s of src_f16: src[s] IS an fp16 NHWC64 map (the mirror its producer
@@ -85,18 +84,18 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream);
 // split-fp16 variant (conv_f16x3.hip): fp32 maps in and out, three fp16 MFMAs per product.  Takes the NHWC64 convs of 64-channel
 // sources (+ optionally the RGB frame, which runs on the exact fp32 kernel as the first link of the source chain); pixel-shuffle /
 // RGB heads and the DCN offset convs stay on the fp32 kernels.
-int launch_f16_lo_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t stream);
+int launch_f16x3_image(const float* src, void* dst, int nchunks, hipStream_t stream);      // nchunks * 16 KiB
 static inline bool conv_f16x3_eligible(const ConvArgs& a, int cfg, int grid_y) {
     if (cfg == CONV_CFG_RGB || a.out_mode != 0 || grid_y != 1) return false;
     int nwide = 0;
     for (int s = 0; s < a.nsrc; ++s)
         if (a.src_c[s] == 64) {
             ++nwide;
-            if (!a.wsrc_h[s] || !a.wsrc_l[s]) return false;
+            if (!a.wsrc_h[s]) return false;
         }
     if (nwide == 0) return false;
     const bool has_par = a.wpar || a.wpar_h;
-    if (has_par && (a.nsrc != 1 || !a.wpar_h || !a.wpar_l || !a.par)) return false;
+    if (has_par && (a.nsrc != 1 || !a.wpar_h || !a.par || a.residual)) return false;   // a branch conv with a residual: fp32 kernels
     if (a.nsrc > 1 && (a.residual || a.gamma)) return false;
     return !a.src_f16 && !a.out_f16 && !a.out16;
 }

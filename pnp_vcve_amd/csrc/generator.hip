@@ -349,8 +349,7 @@ struct ConvCall {
 
 struct Workspace {
     float *lr4, *slots, *kw, *tmp0, *tmp1, *u1, *u2, *u3, *ew, *gamma, *mixw, *mixb, *flow4, *om, *parbin;
-    float* mixh;      // fp16 mirror of mixw (same element count), PNP_PREC_F16 / F16X3 only
-    float* mixl;      // PNP_PREC_F16X3: the low fp16 images of the split, fp16((w - hi) * 2048)
+    float* mixh;      // PNP_PREC_F16: fp16 mirror of mixw (same element count); PNP_PREC_F16X3: its split image (twice the halfs)
     // PNP_PREC_F16 + mirrors: fp16 NHWC64 copies of the running map of a branch (x16) and of every frame's slot (slots16);
     // the MV-aligned key frame is then fp16 only and lives in kw
     uint16_t *x16, *slots16;
@@ -400,8 +399,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     W.gamma = take((int64_t)t * 64);
     W.mixw = take((int64_t)t * g->ndyn * IMG_WIDE);
     W.mixb = take((int64_t)t * g->ndyn * 64);
-    W.mixh = g->prec != PNP_PREC_F32 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
-    W.mixl = g->prec == PNP_PREC_F16X3 ? take((int64_t)t * g->ndyn * IMG_WIDE / 2) : nullptr;
+    W.mixh = g->prec != PNP_PREC_F32 ? take((int64_t)t * g->ndyn * IMG_WIDE / (g->prec == PNP_PREC_F16X3 ? 1 : 2)) : nullptr;
     const bool mir = g->prec == PNP_PREC_F16 && g->cfg.deform == 0;      // sized whether or not PNP_OPT_F16_MIRRORS is on
     W.x16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32)) : nullptr;
     W.slots16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32 * t)) : nullptr;
@@ -444,8 +442,8 @@ int pnp_generator_param_ndim(const pnp_generator* g, int i) { return (int)g->par
 int64_t pnp_generator_param_dim(const pnp_generator* g, int i, int d) { return g->params[i].shape[d]; }
 int64_t pnp_generator_param_offset(const pnp_generator* g, int i) { return g->params[i].offset; }
 int64_t pnp_generator_flat_floats(const pnp_generator* g) { return g->flat_floats; }
-// fp32 images, then (PNP_PREC_F16 / F16X3) their fp16 mirror: element i of the mirror region is element i of the images; then
-// (PNP_PREC_F16X3) the low fp16 images of the split, same indexing
+// fp32 images, then (PNP_PREC_F16) their fp16 mirror: element i of the mirror region is element i of the images; or
+// (PNP_PREC_F16X3) their split images: the 16 KiB at halfs 2 * i.. belong to the 64-deep chunk at float i
 int64_t pnp_generator_packed_floats(const pnp_generator* g) {
     const int halves = g->prec == PNP_PREC_F16 ? 1 : (g->prec == PNP_PREC_F16X3 ? 2 : 0);
     return g->packed_floats + halves * (g->packed_floats / 2);
@@ -562,10 +560,8 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
             if (rc) return rc;
         }
     }
-    if (g->prec == PNP_PREC_F16X3) {     // hi and lo images of every region; only the NHWC64 64-channel convs read them
-        rc = launch_f16_image(packed, packed + g->packed_floats, (int)(g->packed_floats / IMG_CHUNK), 2, st);
-        if (rc) return rc;
-        rc = launch_f16_lo_image(packed, packed + g->packed_floats + g->packed_floats / 2, (int)(g->packed_floats / IMG_CHUNK), 2, st);
+    if (g->prec == PNP_PREC_F16X3) {     // split image of every region; only the NHWC64 64-channel convs read theirs
+        rc = launch_f16x3_image(packed, packed + g->packed_floats, (int)(g->packed_floats / IMG_CHUNK), st);
         if (rc) return rc;
     }
     return (int)hipGetLastError();
@@ -594,16 +590,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     const int64_t n_mix = (int64_t)t * g->ndyn * IMG_WIDE;
     auto twin = [&](const float* p) -> const void* {
         if (g->prec == PNP_PREC_F32 || !p) return nullptr;
+        const int64_t halfs = g->prec == PNP_PREC_F16X3 ? 2 : 1;       // halfs of the twin per float of the image
         if (p >= packed && p < packed + g->packed_floats)
-            return reinterpret_cast<const uint16_t*>(packed + g->packed_floats) + (p - packed);
-        if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixh) + (p - W.mixw);
-        return nullptr;
-    };
-    auto twin_lo = [&](const float* p) -> const void* {      // PNP_PREC_F16X3: the low image of the split
-        if (g->prec != PNP_PREC_F16X3 || !p) return nullptr;
-        if (p >= packed && p < packed + g->packed_floats)
-            return reinterpret_cast<const uint16_t*>(packed + g->packed_floats + g->packed_floats / 2) + (p - packed);
-        if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixl) + (p - W.mixw);
+            return reinterpret_cast<const uint16_t*>(packed + g->packed_floats) + halfs * (p - packed);
+        if (p >= W.mixw && p < W.mixw + n_mix) return reinterpret_cast<const uint16_t*>(W.mixh) + halfs * (p - W.mixw);
         return nullptr;
     };
     const bool f16_maps = g->prec == PNP_PREC_F16 && g->opt[PNP_OPT_F16_MAPS];
@@ -624,11 +614,9 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             a.src_c[s] = q.sc[s];
             a.wsrc[s] = q.w[s];
             a.wsrc_h[s] = twin(q.w[s]);
-            a.wsrc_l[s] = twin_lo(q.w[s]);
         }
         a.wpar = q.wpar_;
         a.wpar_h = twin(q.wpar_);
-        a.wpar_l = twin_lo(q.wpar_);
         a.par = q.par_;
         a.par_flags = q.par_flags_;
         a.par_plane = (long)q.H * q.W;
@@ -783,14 +771,14 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 rc = launch_mix_bias(flat + g->dyn_b, W.ew + (int64_t)i * E, W.mixb + (int64_t)u * g->ndyn * 64, E, 64,
                                      g->ndyn, st);
                 if (rc) return rc;
-                if (g->prec != PNP_PREC_F32) {
+                if (g->prec == PNP_PREC_F16) {
                     rc = launch_f16_image(a.dst, reinterpret_cast<uint16_t*>(W.mixh) + (int64_t)u * g->ndyn * IMG_WIDE,
                                           g->ndyn * 9, 2, st);
                     if (rc) return rc;
                 }
                 if (g->prec == PNP_PREC_F16X3) {
-                    rc = launch_f16_lo_image(a.dst, reinterpret_cast<uint16_t*>(W.mixl) + (int64_t)u * g->ndyn * IMG_WIDE,
-                                             g->ndyn * 9, 2, st);
+                    rc = launch_f16x3_image(a.dst, reinterpret_cast<uint16_t*>(W.mixh) + (int64_t)u * g->ndyn * IMG_WIDE * 2,
+                                            g->ndyn * 9, st);
                     if (rc) return rc;
                 }
             }
@@ -1274,16 +1262,23 @@ int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs, const int* src_channe
     return launch_conv3x3_f16(a, 1, (hipStream_t)st);
 }
 
-int pnp_f16_lo_image_from_f32(const float* packed_w, void* dst, int nchunks, void* st) {
+int pnp_f16x3_image_from_f32(const float* packed_w, void* dst, int nchunks, void* st) {
     if (!packed_w || !dst) return PNP_ERR_BAD_ARG;
-    return launch_f16_lo_image(packed_w, dst, nchunks, 2, (hipStream_t)st);
+    return launch_f16x3_image(packed_w, dst, nchunks, (hipStream_t)st);
 }
 
 int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w_f32,
-                      const void* const* packed_w_hi, const void* const* packed_w_lo, const float* bias, const float* gamma,
-                      const void* packed_w1x1_hi, const void* packed_w1x1_lo, const float* par, const int* par_flags,
-                      const float* residual, int act, float* out, int h, int w, void* st) {
-    if (nsrc < 1 || nsrc > 4 || !srcs || !src_channels || !packed_w_hi || !packed_w_lo || !out) return PNP_ERR_BAD_ARG;
+                      const void* const* packed_w_x3, const float* bias, const float* gamma, const void* packed_w1x1_x3,
+                      const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w, void* st) {
+    return pnp_conv3x3_f16x3_ex(nsrc, srcs, src_channels, packed_w_f32, packed_w_x3, bias, gamma, packed_w1x1_x3, par, par_flags,
+                                residual, act, out, h, w, nullptr, st);
+}
+
+int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w_f32,
+                         const void* const* packed_w_x3, const float* bias, const float* gamma, const void* packed_w1x1_x3,
+                         const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
+                         void* trace, void* st) {
+    if (nsrc < 1 || nsrc > 4 || !srcs || !src_channels || !packed_w_x3 || !out) return PNP_ERR_BAD_ARG;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nsrc = nsrc;
@@ -1292,12 +1287,10 @@ int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs, const int* src_channel
         a.src[s] = srcs[s];
         a.src_c[s] = src_channels[s];
         a.wsrc[s] = packed_w_f32 ? packed_w_f32[s] : nullptr;
-        a.wsrc_h[s] = packed_w_hi[s];
-        a.wsrc_l[s] = packed_w_lo[s];
+        a.wsrc_h[s] = packed_w_x3[s];
         if (src_channels[s] == 4 && (s != 0 || !a.wsrc[s])) return PNP_ERR_BAD_ARG;    // the RGB frame: source 0, fp32 image
     }
-    a.wpar_h = packed_w1x1_hi;
-    a.wpar_l = packed_w1x1_lo;
+    a.wpar_h = packed_w1x1_x3;
     a.par = par;
     a.par_flags = par_flags;
     a.par_plane = (long)h * w;
@@ -1309,7 +1302,8 @@ int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs, const int* src_channel
     a.W = w;
     a.act = act;
     a.out_mode = 0;
-    if (a.wpar_h && (nsrc != 1 || !par || !a.wpar_l)) return PNP_ERR_BAD_ARG;
+    a.dbg = (unsigned long long*)trace;
+    if (a.wpar_h && (nsrc != 1 || !par)) return PNP_ERR_BAD_ARG;
     if (!conv_f16x3_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_f16x3(a, conv_pick_cfg(h, w), (hipStream_t)st);
 }

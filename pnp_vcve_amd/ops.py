@@ -166,39 +166,54 @@ def f16_image(packed):
 
 
 @_on_device_of_first_tensor
-def f16_lo_image(packed):
-    """fp32 packed weight image -> the LOW fp16 image of the split, fp16((w - fp16(w)) * 2048), for conv3x3_f16x3."""
+def f16x3_image(packed):
+    """fp32 packed weight image -> its split image for conv3x3_f16x3: hi = fp16(w), lo = fp16((w - hi) * 2048), interleaved per
+    k-step (twice the halfs of f16_image)."""
     packed = _chk(packed, 'packed')
     nchunks, rem = divmod(packed.numel(), 4096)
     if rem:
         raise ValueError('packed image must be whole 4096-float chunks')
-    dst = torch.empty(packed.numel(), device=packed.device, dtype=torch.float16)
-    _native.check(_native.lib().pnp_f16_lo_image_from_f32(_ptr(packed), ctypes.c_void_p(dst.data_ptr()), nchunks, _stream()),
-                  'pnp_f16_lo_image_from_f32')
+    dst = torch.empty(2 * packed.numel(), device=packed.device, dtype=torch.float16)
+    _native.check(_native.lib().pnp_f16x3_image_from_f32(_ptr(packed), ctypes.c_void_p(dst.data_ptr()), nchunks, _stream()),
+                  'pnp_f16x3_image_from_f32')
     return dst
 
 
 @_on_device_of_first_tensor
-def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, par_flags=None, residual=None, act=0):
-    """conv3x3 in split fp16 (pnp_conv3x3_f16x3, PNP_PREC_F16X3): packed_w / packed_w1x1 are the fp32 images of conv3x3; their
-    hi / lo fp16 images are made here.  fp32 sources, fp32 result at fp32-level accuracy."""
+def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, par_flags=None, residual=None, act=0,
+                  trace=None):
+    """conv3x3 in split fp16 (pnp_conv3x3_f16x3, PNP_PREC_F16X3): packed_w / packed_w1x1 are the fp32 images of conv3x3 (their
+    split images are made here) or, for 64-channel sources / the 1x1 branches, float16 tensors that already are f16x3_image()
+    results.  fp32 sources, fp32 result at fp32-level accuracy."""
     srcs = [_chk(s, 'src') for s in srcs]
-    packed_w = [_chk(p, 'packed_w') for p in packed_w]
     h, w = srcs[0].shape[:2]
     n = len(srcs)
-    wide = [s.shape[2] == 64 for s in srcs]
-    hi = [f16_image(p) if wd else None for p, wd in zip(packed_w, wide)]
-    lo = [f16_lo_image(p) if wd else None for p, wd in zip(packed_w, wide)]
-    p_hi = f16_image(packed_w1x1) if packed_w1x1 is not None else None
-    p_lo = f16_lo_image(packed_w1x1) if packed_w1x1 is not None else None
+
+    def split(p, wide=True):
+        if p is None or not wide:
+            return None
+        if p.dtype == torch.float16:
+            if not p.is_cuda or not p.is_contiguous():
+                raise TypeError('split weight images must be contiguous CUDA float16 tensors (ops.f16x3_image)')
+            return p
+        return f16x3_image(p)
+
+    x3 = [split(p, s.shape[2] == 64) for p, s in zip(packed_w, srcs)]
+    p_x3 = split(packed_w1x1)
+    packed_w = [(_chk(p, 'packed_w') if p.dtype == torch.float32 else None) for p in packed_w]
     vp = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
     out = torch.empty((h, w, 64), device=srcs[0].device, dtype=torch.float32)
     sc = (ctypes.c_int * n)(*[s.shape[2] for s in srcs])
     keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, par, residual)]
     one = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    _native.check(_native.lib().pnp_conv3x3_f16x3(n, vp(srcs), sc, vp(packed_w), vp(hi), vp(lo), _ptr(keep[0]), _ptr(keep[1]),
-                                                  one(p_hi), one(p_lo), _ptr(keep[2]), one(par_flags), _ptr(keep[3]), act,
-                                                  _ptr(out), h, w, _stream()), 'pnp_conv3x3_f16x3')
+    if trace is None:
+        _native.check(_native.lib().pnp_conv3x3_f16x3(n, vp(srcs), sc, vp(packed_w), vp(x3), _ptr(keep[0]), _ptr(keep[1]),
+                                                      one(p_x3), _ptr(keep[2]), one(par_flags), _ptr(keep[3]), act,
+                                                      _ptr(out), h, w, _stream()), 'pnp_conv3x3_f16x3')
+    else:       # include/pnpvcve_debug.h: in-kernel timeline
+        _native.check(_native.lib().pnp_conv3x3_f16x3_ex(n, vp(srcs), sc, vp(packed_w), vp(x3), _ptr(keep[0]), _ptr(keep[1]),
+                                                         one(p_x3), _ptr(keep[2]), one(par_flags), _ptr(keep[3]), act,
+                                                         _ptr(out), h, w, one(trace), _stream()), 'pnp_conv3x3_f16x3_ex')
     return out
 
 

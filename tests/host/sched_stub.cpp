@@ -204,15 +204,15 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
         RD("a conv source", a.src[s], hw * a.src_c[s] * (s16 ? 2 : 4));
         const size_t img = a.src_c[s] == 64 ? (rgb_head ? 9 * 2048 : 9 * 4096) : 4096;
         for (int y = 0; y < gy; ++y) {
-            if (f16 || (x3 && a.src_c[s] == 64)) RD("an fp16 weight image", (const uint16_t*)a.wsrc_h[s] + (size_t)y * a.w_ystride, img * 2);
+            if (f16) RD("an fp16 weight image", (const uint16_t*)a.wsrc_h[s] + (size_t)y * a.w_ystride, img * 2);
+            else if (x3 && a.src_c[s] == 64) RD("a split fp16 weight image", a.wsrc_h[s], img * 4);
             else RD("a weight image", a.wsrc[s] + (size_t)y * a.w_ystride, img * 4);
-            if (x3 && a.src_c[s] == 64) RD("a low fp16 weight image of the split", (const uint16_t*)a.wsrc_l[s] + (size_t)y * a.w_ystride, img * 2);
         }
     }
     if (a.wpar || a.wpar_h) {
-        if (f16 || x3) RD("the fp16 1x1 weight images", a.wpar_h, 3 * 4096 * 2);
+        if (f16) RD("the fp16 1x1 weight images", a.wpar_h, 3 * 4096 * 2);
+        else if (x3) RD("the split fp16 1x1 weight images", a.wpar_h, 3 * 4096 * 4);
         else RD("the 1x1 weight images", a.wpar, 3 * 4096 * 4);
-        if (x3) RD("the low fp16 1x1 weight images of the split", a.wpar_l, 3 * 4096 * 2);
         RD("the partition planes", a.par, (size_t)(2 * a.par_plane + hw) * 4);
         if (a.par_flags) RD("the partition tile flags", a.par_flags, (size_t)((a.W + 15) / 16) * ((a.H + 7) / 8) * 4);
     }
@@ -262,12 +262,12 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t s) {
     stub::convs.push_back({a, cfg, 1, stub::sid(s), 2});
     return 0;
 }
-int launch_f16_lo_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t s) {
-    stub::cur = "launch_f16_lo_image";
+int launch_f16x3_image(const float* src, void* dst, int nchunks, hipStream_t s) {
+    stub::cur = "launch_f16x3_image";
     stub::note_launch(s);
-    const size_t n = (size_t)nchunks * pnp_chunk_floats(ntb);
+    const size_t n = (size_t)nchunks * pnp_chunk_floats(2);
     stub::RD("fp32 weight images", src, n * 4);
-    stub::WR("low fp16 weight images of the split", dst, n * 2);
+    stub::WR("split fp16 weight images", dst, n * 4);
     return 0;
 }
 int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStream_t s) {
@@ -550,8 +550,9 @@ int run(const Scenario& sc) {
             const Workspace W = carve(g, ws + (int64_t)k * ctx_bytes, sc.t, sc.h, sc.w);
             if (c.path) {
                 const uint16_t* hh = (const uint16_t*)c.a.wsrc_h[0];
-                if (hh >= (const uint16_t*)W.mixh && hh < (const uint16_t*)W.mixh + (int64_t)sc.t * g->ndyn * IMG_WIDE)
-                    u = (int)((hh - (const uint16_t*)W.mixh) / ((int64_t)g->ndyn * IMG_WIDE));
+                const int64_t halfs = c.path == 2 ? 2 : 1;
+                if (hh >= (const uint16_t*)W.mixh && hh < (const uint16_t*)W.mixh + halfs * sc.t * g->ndyn * IMG_WIDE)
+                    u = (int)((hh - (const uint16_t*)W.mixh) / (halfs * g->ndyn * IMG_WIDE));
             } else if (wimg >= W.mixw && wimg < W.mixw + (int64_t)sc.t * g->ndyn * IMG_WIDE) {
                 u = (int)((wimg - W.mixw) / ((int64_t)g->ndyn * IMG_WIDE));
             }

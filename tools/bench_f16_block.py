@@ -23,6 +23,8 @@ xs16 = [x.half() for x in xs]
 rs = [torch.randn(h, w, 64, device=dev) for _ in range(NB)]
 pw = ops.f16_image(ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev) * 0.05))
 p1 = ops.f16_image(ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev) * 0.1 for _ in range(3)]))
+PW32 = ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev) * 0.05)
+P132 = ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev) * 0.1 for _ in range(3)])
 cls = torch.randint(0, 3, ((h + 7) // 8, (w + 7) // 8), device=dev)
 par = torch.stack([(cls == j).float() for j in range(3)]).repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :h, :w].contiguous() / 255.0
 flags = ops.par_tile_flags(par)
@@ -64,6 +66,16 @@ timeit('back   r02: fp16 o + fp32 residual -> fp32 x, resident-weight kernel', l
 timeit('back      : ... + fp16 mirror, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, residual=rs[i % NB], mirror=True), 768)
 timeit('conv_hr r02: fp32 -> fp16', lambda i: F([xs[i % NB]], [pw], bias=bias, act=2, out_f16=True), 384)
 timeit('conv_hr    : fp16 -> fp16, resident-weight kernel', lambda i: F([xs16[i % NB]], [pw], bias=bias, act=2, out_f16=True), 256)
+# split fp16 (PNP_PREC_F16X3): fp32 maps both ways, three MFMAs per product
+pw3 = ops.f16x3_image(ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev) * 0.05))
+p13 = ops.f16x3_image(ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev) * 0.1 for _ in range(3)]))
+X3 = ops.conv3x3_f16x3
+timeit('front  f16x3: fp32 x -> fp32 o, all branches', lambda i: X3([xs[i % NB]], [pw3], bias=bias, gamma=gam, packed_w1x1=p13, par=par, act=1), 524)
+timeit('front  f16x3: fp32 x -> fp32 o, branch skipping', lambda i: X3([xs[i % NB]], [pw3], bias=bias, gamma=gam, packed_w1x1=p13, par=par, par_flags=flags, act=1), 524)
+timeit('back   f16x3: fp32 o + fp32 residual -> fp32 x', lambda i: X3([xs[i % NB]], [pw3], bias=bias, residual=rs[i % NB]), 768)
+timeit('conv_hr f16x3: fp32 -> fp32', lambda i: X3([xs[i % NB]], [pw3], bias=bias, act=2), 512)
+timeit('front  fp32 (exact fp32 MFMA kernel), branch skipping', lambda i: ops.conv3x3([xs[i % NB]], [PW32], bias=bias, gamma=gam, packed_w1x1=P132, par=par, par_flags=flags, act=1), 524)
+timeit('back   fp32 (exact fp32 MFMA kernel)', lambda i: ops.conv3x3([xs[i % NB]], [PW32], bias=bias, residual=rs[i % NB]), 768)
 for nw in (1, 2, 3):
     s32 = [xs[(j + 1) % NB] for j in range(nw)]
     s16 = [xs16[(j + 1) % NB] for j in range(nw)]
