@@ -115,7 +115,7 @@ def committed_pmc_traffic(tag):
 
 def _launch_weighted_traffic(pmc, prefix):
     """launch-weighted mean HBM bytes per launch over the kernel variants whose summarised name starts with `prefix`"""
-    ks = [v for k, v in pmc.items() if k.startswith(prefix) and 'hbm_bytes_per_launch' in v]
+    ks = [v for k, v in pmc.items() if (k.startswith(prefix) or '::' + prefix in k) and 'hbm_bytes_per_launch' in v]
     if not ks:
         return None
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
@@ -419,9 +419,9 @@ def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, 
                              else 'separate pass of the same steps after the timed region'),
            'launches_per_frame': (sum(v['launches'] for v in prof.values()) / (steps * T * clips)) if prof else None}
     if prof is not None:
-        tag = ('' if precision == 'fp32' else 'fp16_') if workload == '720p' and not vsr and cfg.get('deform', 'vos') == 'vos' \
-            else f'{workload}_' + ('' if precision == 'fp32' else 'fp16_') + ('vsr_' if vsr else '') + \
-                 ('' if cfg.get('deform', 'vos') == 'vos' else cfg['deform'] + '_')
+        ptag = {'fp32': '', 'fp16': 'fp16_', 'f16x3': 'f16x3_'}[precision]
+        tag = ptag if workload == '720p' and not vsr and cfg.get('deform', 'vos') == 'vos' \
+            else f'{workload}_' + ptag + ('vsr_' if vsr else '') + ('' if cfg.get('deform', 'vos') == 'vos' else cfg['deform'] + '_')
         pmc, pmc_src = committed_pmc_traffic(tag)
         res.update(rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, dense_prof))
     return res, m, a
