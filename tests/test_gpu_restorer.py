@@ -177,17 +177,22 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert 0 < r['frac_dense_par'] <= r['algorithmic_frac'] * 1.02
     assert 'U{0,1,2}' in d['config']['workload']
     sec = d['secondary']
-    assert len(sec) == 7
-    e2e = sec[6]                                   # the whole tools/test.py loop on an on-disk tree
+    assert len(sec) == 8
+    e2e = sec[7]                                   # the whole tools/test.py loop on an on-disk tree
     assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
     assert e2e['seconds_total'] >= e2e['seconds_generator_forward'] > 0
-    for e in sec[:6]:
+    for e in sec[:7]:
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
             assert e['roofline']['frac'] > 0 and e['launches_per_frame'] > 0
-    assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm' and sec[4]['roofline']['bound'] == 'hbm'
-    assert sec[2]['hip_graphs'] is True and sec[5]['vsr_x4_heads'] is True
+    assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm' and sec[5]['roofline']['bound'] == 'hbm'
+    assert sec[2]['hip_graphs'] is True and sec[6]['vsr_x4_heads'] is True
     assert sec[3]['value'] > 3 * d['value']       # fp16 operands at the headline shape: > 3x the fp32 rate
+    # split fp16 (fp32-level results, three fp16 MFMAs per product): priced on the matrix pipe, executed = 3 x algorithmic
+    x3 = sec[4]
+    assert x3['dtype'].startswith('split f16') and x3['roofline']['bound'] == 'mfma' and x3['value'] > 1.8 * d['value']
+    assert x3['roofline']['achieved'] <= 3 * x3['roofline']['algorithmic_TFLOPs'] * 1.001
+    assert abs(x3['psnr'] - d['psnr_per_rank'][0]) < 1e-3      # same clip, same weights: the fp32 headline's PSNR
     assert all('cpu_baseline' not in e for e in sec)          # --no-cpu-baseline covers the secondary entries too
 
 
