@@ -262,15 +262,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                 acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fr.b[1], acc_lo[1], 0, 0, 0);
                 acc_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[2], acc_lo[0], 0, 0, 0);
                 acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[3], acc_lo[1], 0, 0, 0);
+                if (s2 == 0 && c + 2 < NC && (!PAR || c + 2 < ncr)) {
+                    // ring write of chunk c + 2 (into the slot of chunk c - 1, which every wave left before the previous barrier)
+                    // in the MIDDLE of the chunk: the barrier below then waits for it, not for the fragment reads behind it
+                    char* d = sR + ((c + 2) % X3_RING) * X3_CHUNK;
+#pragma unroll
+                    for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[(c + 2) % NSET][i];
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (s2 == 0 || c + 1 < NC) fr = nf;
             }
-            if (c + 2 < NC && (!PAR || c + 2 < ncr)) {
-                char* d = sR + ((c + 2) % X3_RING) * X3_CHUNK;     // slot of chunk c - 1: every wave left it at the previous barrier
-#pragma unroll
-                for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[(c + 2) % NSET][i];
-            }
-            lds_barrier();
+            // LDS operations complete in order: the 6 fragment reads of the next chunk's first k-step were issued after the ring
+            // write, so "at most 6 outstanding" means the write has landed -- and the reads stay in flight across the barrier
+            if (c + 1 < NC) asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory");
+            else lds_barrier();
         }
         if (DBG) dbg_c = __builtin_amdgcn_s_memtime();
         // the branch chunks' VALU work (scaling and re-splitting A fragments) needs the registers: the next halo only now
