@@ -137,3 +137,12 @@ def test_forward_refuses_maps_beyond_32_bit_offsets_before_touching_memory(lib):
                                        None)
         assert rc == rc_exp, (vsr, hw, deform, rc)      # 1003: passed the guard, stopped at the (null) workspace
         lib.pnp_generator_destroy(h)
+
+
+def test_dcn_is_built_without_slp_vectorisation():
+    """DESIGN.md 3.5 / profiles/r03_dcn_hazard_report.txt: every build of dcn.hip whose gather arithmetic hipcc's SLP vectoriser had
+    packed gave run-to-run varying samples in the fp16 instantiation under some timing; the flag is part of the kernel's
+    correctness, so dropping it has to fail a test (the behaviour itself is held by the -m gpu determinism tests)."""
+    from pnp_vcve_amd import build_native
+    assert '-fno-slp-vectorize' in build_native.EXTRA_FLAGS.get('dcn.hip', [])
+    assert all(src in build_native.SOURCES for src in build_native.EXTRA_FLAGS)
