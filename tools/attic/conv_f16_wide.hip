@@ -1,7 +1,9 @@
 // NOT BUILT, NOT SHIPPED.  Kept as the record of a measured experiment (last bullet): it was wired into
 // launch_conv3x3_f16 (conv_f16.hip) for single-source launches that write an fp16 map, passed bit-identity tests against the
 // resident-weight kernel on 256x512 / 264x520 / 248x1064 / 720x1280 with and without partition branches and fp16 sources, and
-// gained 0.5 % of the fp16 720p step.  To try it again: add it to build_native.SOURCES, declare launch_conv3x3_f16_wide in
+// gained 0.5 % of the fp16 720p step (first version: fragments one k-step ahead; this version: three k-steps ahead, ring write at the
+// top of the chunk, counted barrier wait -- same timings: 135.6 vs 147.0 us from an fp32 source, 104.1 vs 106.2 from an fp16 one,
+// conv_hr 113.5 / 90.7 vs 108.9 / 85.2; K loop 1074 cycles per 16-MFMA chunk either way, see profiles/r03_ub_mfma_issue.txt).  To try it again: add it to build_native.SOURCES, declare launch_conv3x3_f16_wide in
 // conv_mfma.h and call it from launch_conv3x3_f16 where `om == 1 && nwide == 1 && lr_idx < 0 && !f.residual`.
 //
 // fp16-operand 64 -> 64 conv on 8x32-pixel tiles: a wave owns 64 pixels x 64 channels (2 x 2 MFMA tiles), so a k-step is four
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const WideArgs
     // ---- weight chunks: chunk c (tap c, or the (c - 9)-th needed branch) in ring slot c % 3
     int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
     auto bsel = [&](int j) { return j == 0 ? bs0 : (j == 1 ? bs1 : bs2); };
-    f32x4 wreg[2][WPT];
+    f32x4 wreg[3][WPT];                                  // chunk c travels in set c % 3
     auto request_chunk = [&](int c, int set) {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
@@ -124,9 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const WideArgs
         }
     };
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        request_chunk(c, c);
-    }
+    for (int c = 0; c < 3; ++c) request_chunk(c, c);
     // partition values of the lane's two pixels (M tile j: columns 16 j + mx)
     float pv[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     if (PAR) {
@@ -165,10 +165,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const WideArgs
         }
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * W_CHUNK + (t + 256 * i) * 16) = wreg[c][i];
-    request_chunk(2, 0);
+    request_chunk(3, 0);
     lds_barrier();
     if (a.dbg) d_t1 = __builtin_amdgcn_s_memtime();
 
@@ -189,22 +189,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const WideArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + bco[j]) * gco[j];
     };
-    struct Frag { h8 a0, a1, b0, b1; };
-    auto load_frag = [&](int c, int sk) {                  // compile-time after unrolling; a branch chunk reads the centre tap
+    // One continuous stream of k-steps (4 per chunk; chunk c in ring slot c % 3).  Fragments are fetched DEPTH k-steps ahead of
+    // the MFMAs that use them, across chunk boundaries (chunk c + 1 has been in the ring since the barrier that ended chunk
+    // c - 1): 4 DEPTH = 12 reads in flight per wave, i.e. 12 MFMAs = 384 cycles of LDS latency covered by a wave on its own.
+    // Per chunk: at its top the ring write of chunk c + 2 (into the slot of chunk c - 1, which every wave left before the barrier
+    // just passed; requested two chunks ago) and the request for chunk c + 4; at its end one barrier that waits for nothing: LDS
+    // operations complete in order, the write is older than the 16 reads the chunk issued, of which at most 12 are outstanding.
+    constexpr int DEPTH = 3;
+    h8 fa0[DEPTH + 1], fa1[DEPTH + 1], fb0[DEPTH + 1], fb1[DEPTH + 1];      // slot = step % (DEPTH + 1)
+    auto fetch = [&](int step) {                   // compile-time step; a branch chunk reads the centre tap
+        const int c = step >> 2, sk = step & 3, sl = step % (DEPTH + 1);
         const int dy = c < 9 ? c / 3 : 1, dx = c < 9 ? c % 3 : 1;
         const int o = a_off + dy * WRSB + dx * PSB + 32 * sk;
         const char* b_lane = sR + (c % W_RING) * W_CHUNK + lane * 16;
-        Frag f;
-        f.a0 = *reinterpret_cast<const h8*>(smem + o);
-        f.a1 = *reinterpret_cast<const h8*>(smem + o + 16 * PSB);
-        f.b0 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
-        f.b1 = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
-        return f;
+        fa0[sl] = *reinterpret_cast<const h8*>(smem + o);
+        fa1[sl] = *reinterpret_cast<const h8*>(smem + o + 16 * PSB);
+        fb0[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 0) * UNIT);
+        fb1[sl] = *reinterpret_cast<const h8*>(b_lane + (sk * 2 + 1) * UNIT);
     };
-    Frag fr = load_frag(0, 0);
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) fetch(k);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (PAR && c == 6 && a.par_flags) {          // first use of the flags: chunk 9 is requested below
+        if (PAR && c == 5 && a.par_flags) {          // first use of the flags: chunk 9 is requested below
             const int f0 = (__builtin_amdgcn_readfirstlane(pfl_a) | __builtin_amdgcn_readfirstlane(pfl_b)) & 7;
             const int f1 = f0 & (f0 - 1), f2 = f1 & (f1 - 1);
             ncr = 9 + __builtin_popcount(f0);
@@ -213,7 +221,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const WideArgs
             bs2 = f2 ? __builtin_ctz(f2) : 0;
         }
         if (PAR && c >= 9 && c >= ncr) break;
-        if (c + 3 < NC && (!PAR || c + 3 < ncr)) request_chunk(c + 3, (c + 1) & 1);
+        if (c + 2 < NC && (!PAR || c + 2 < ncr) && c + 2 >= 3) {     // chunks 0..2 went in before the loop
+            char* d = sR + ((c + 2) % W_RING) * W_CHUNK;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[(c + 2) % 3][i];
+        }
+        if (c + 4 < NC && (!PAR || c + 4 < ncr)) request_chunk(c + 4, (c + 4) % 3);
         _Float16 pj0 = (_Float16)1.f, pj1 = (_Float16)1.f;
         if (PAR && c >= 9) {
             if (c == 9) bias_gamma();                  // (conv + bias) * gamma BEFORE the 1x1 partition branches
@@ -223,29 +236,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_wide_kernel(const WideArgs
         }
 #pragma unroll
         for (int sk = 0; sk < 4; ++sk) {
-            Frag nf;
-            if (sk < 3) nf = load_frag(c, sk + 1);
-            else if (c + 1 < NC) nf = load_frag(c + 1, 0);     // chunk c + 1 has been in the ring since the barrier that ended c - 1
+            const int step = c * 4 + sk, sl = step % (DEPTH + 1);
+            if (step + DEPTH < NC * 4) fetch(step + DEPTH);       // (past the tile's last chunk: unused stale bytes)
             __builtin_amdgcn_sched_barrier(0);
-            h8 a0 = fr.a0, a1 = fr.a1;
+            h8 a0 = fa0[sl], a1 = fa1[sl];
+            const h8 b0 = fb0[sl], b1 = fb1[sl];
             if (PAR && c >= 9) {
                 a0 *= pj0;
                 a1 *= pj1;
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, fr.b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, fr.b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, fr.b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, fr.b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (sk < 3 || c + 1 < NC) fr = nf;
         }
-        if (c + 2 < NC && (!PAR || c + 2 < ncr)) {
-            char* d = sR + ((c + 2) % W_RING) * W_CHUNK;       // slot of chunk c - 1: every wave left it at the previous barrier
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[c & 1][i];
-        }
-        lds_barrier();
+        asm volatile("s_waitcnt lgkmcnt(12)\n\ts_barrier" ::: "memory");
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // nobody still reads the LDS the epilogue overwrites
     if (!PAR || ncr == 9) bias_gamma();
     if (a.dbg) d_t2 = __builtin_amdgcn_s_memtime();
 
