@@ -329,9 +329,10 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
             'traffic': f16_traffic, 'traffic_source': pmc_src, 'launches': cb['launches'],
             'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
             'matrix_TFLOPs': ach, 'matrix_peak_TFLOPs': PEAK_F16_MFMA_TFLOPS, 'device_ms_per_step': dev_ms,
-            'note': 'priced against HBM because that is the smaller of the two roofs at the fp16 matrix rate; the in-kernel '
-                    'timeline (tools/trace_f16.py, DESIGN.md 3.4) shows what actually bounds it: the matrix phase reads 192 of the '
-                    "LDS's 256 B/clk in fragments and is balanced against the memory phase of the partner group"}
+            'note': 'priced against HBM because that is the smaller of the two roofs at the fp16 matrix rate; what actually bounds it '
+                    '(DESIGN.md 3.4 item 5, profiles/r03_ub_mfma_issue.txt): a wave issues in order and each 1-KiB fragment read costs '
+                    'it 16 cycles of issue, so one wave per SIMD at 1.5 reads per MFMA runs 60 cycles per MFMA (two waves: 44.7 per '
+                    'SIMD); the matrix phase at that rate is balanced against the memory phase of the partner group'}
     if wp['launches']:
         gbs = wp['work'] / (wp['ms'] * 1e-3) / 1e9
         res['roofline_mv_warp'] = {'kernel': 'mv_warp_nhwc_kernel (MV-guided bilinear alignment)', 'bound': 'hbm',
