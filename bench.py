@@ -545,7 +545,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pipeline_e2e(dev, T, clips=3, workers=16):
+def pipeline_e2e(dev, T, clips=6, workers=16):
     """The whole evaluation loop of tools/test.py on an on-disk tree in the reference's REDS layout (restorers/basicvsr.py:155-231,
     apis/test.py:100-119): PNG + MV-record decode on a loader thread and H2D on a side stream one clip ahead (ClipPrefetcher),
     MV / partition maps painted on the GPU (pnp_rasterise_side_info_f32), the fp32 generator, PSNR + SSIM on the device, enhanced
@@ -606,6 +606,7 @@ def pipeline_e2e(dev, T, clips=3, workers=16):
         return {'name': f'end-to-end tools/test.py loop on an on-disk REDS-layout tree: {n} clips x {T}x3x{h}x{w} fp32 (PNG + MV records from '
                         f'disk -> GPU rasteriser -> generator -> PSNR + SSIM on the device -> async PNG write-back)',
                 'metric': f'enhanced frames/sec ({w}x{h}, {T}-frame window), whole pipeline', 'value': n * T / total, 'unit': 'frames/s',
+                'frames_per_s_before_the_final_png_drain': n * T / t_loop,
                 'clips': n, 'frames': n * T, 'seconds_total': total, 'seconds_generator_forward': fwd,
                 'seconds_main_thread_waiting_for_loader_h2d': sum(stall),
                 'seconds_main_thread_waiting_for_loader_h2d_per_clip': stall[:-1],

@@ -10,6 +10,12 @@ def _to_device(data, device):
     """Host -> device; when the clip carries raw decoder MV records (CompressedClipFolderDataset) the dense
     motion / partition maps are painted on the GPU (pnp_rasterise_side_info_f32) instead of on the host."""
     out = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in data.items()}
+    for k in ('lq', 'gt'):
+        if k + '_u8' in out:       # frames uploaded as uint8 (dataset.get_uint8): RescaleToZeroOne + FramesToTensor on the device.
+            # The 256 possible values come from the host's own fp32 division (a device-side `x / 255.0` multiplies by a rounded
+            # reciprocal and is not bit-equal): a table lookup reproduces numpy's bits by construction
+            lut = (torch.arange(256, dtype=torch.float32) / 255.0).to(out[k + '_u8'].device)
+            out[k] = lut[out.pop(k + '_u8').permute(0, 1, 4, 2, 3).contiguous().long()]
     if 'mv_records' in out:
         from .ops import rasterise_side_info
         rec, rf = out.pop('mv_records'), out.pop('rec_frame')
@@ -39,8 +45,9 @@ class ClipPrefetcher:
 
     def _work(self):
         try:
+            u8 = self.cuda and hasattr(self.dataset, 'get_uint8')      # frames travel as uint8, /255 + HWC->CHW on the device
             for i in self.indices:
-                data = collate([self.dataset[i]])
+                data = collate([self.dataset.get_uint8(i) if u8 else self.dataset[i]])
                 if self.cuda:
                     data = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in data.items()}
                     with torch.cuda.stream(self.stream):

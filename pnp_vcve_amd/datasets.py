@@ -101,7 +101,18 @@ class CompressedClipFolderDataset(_EvalMixin, torch.utils.data.Dataset):
         from PIL import Image
         return np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8)
 
-    def __getitem__(self, idx):
+    #: PNG / record files of a clip are decoded on this many threads (PIL and numpy release the GIL while they inflate / read)
+    decode_workers = 8
+
+    def _pool(self):
+        pool = getattr(self, '_decode_pool', None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self._decode_pool = ThreadPoolExecutor(max_workers=self.decode_workers, thread_name_prefix='pnp-decode')
+        return pool
+
+    def _read_clip(self, idx):
+        """host side of one clip: uint8 HWC frames, side info and raw MV records (files decoded in parallel)"""
         import os
         import numpy as np
         key = self.keys[idx]
@@ -109,10 +120,13 @@ class CompressedClipFolderDataset(_EvalMixin, torch.utils.data.Dataset):
         names = sorted(f for f in os.listdir(d) if f.endswith('.png'))[:self.num_input_frames]
         crf_dir = self.lq_folder.rstrip('/').split('/')[-2] if '/' in self.lq_folder.rstrip('/') else ''
         base_qp = int(crf_dir.split('crf')[1]) if 'crf' in crf_dir else 0          # loading_ipb.py:239
-        lq, gt, slices, qps, recs, rec_frame = [], [], [], [], [], []
-        for t, name in enumerate(names):
-            lq.append(self._png(os.path.join(d, name)))
-            gt.append(self._png(os.path.join(self.gt_folder, key, name)))
+        pool = self._pool()
+        lq_f = [pool.submit(self._png, os.path.join(d, name)) for name in names]
+        gt_f = [pool.submit(self._png, os.path.join(self.gt_folder, key, name)) for name in names]
+        mv_f = [pool.submit(np.load, os.path.join(d, name).replace('.png', '.npy').replace('png', 'mv'))    # loading_ipb.py:326
+                for name in names]
+        slices, qps = [], []
+        for name in names:
             frame = str(int(name.split('.')[0]))
             if crf_dir.startswith('crf') and self.table is not None:                # loading_ipb.py:298-312
                 e = self.table[crf_dir][key][frame]
@@ -123,19 +137,29 @@ class CompressedClipFolderDataset(_EvalMixin, torch.utils.data.Dataset):
                 qp = ord(sl) if self.replace_qp else 0.0
             slices.append(float(ord(sl)))
             qps.append(float(qp) / 255.0)
-            mv_path = os.path.join(d, name).replace('.png', '.npy').replace('png', 'mv')   # loading_ipb.py:326
-            r = np.load(mv_path).astype(np.float32).reshape(-1, 10)
-            recs.append(r)
-            rec_frame.append(np.full((r.shape[0],), t, np.int32))
+        recs = [f.result().astype(np.float32).reshape(-1, 10) for f in mv_f]
+        rec_frame = [np.full((r.shape[0],), t, np.int32) for t, r in enumerate(recs)]
         T = len(names)
-        f32 = lambda a: torch.from_numpy(np.stack(a).astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous()
-        return dict(lq=f32(lq), gt=f32(gt),
-                    slices=torch.tensor(slices, dtype=torch.float32).view(T, 1, 1, 1),
+        side = dict(slices=torch.tensor(slices, dtype=torch.float32).view(T, 1, 1, 1),
                     QPs=torch.tensor(qps, dtype=torch.float32).view(T, 1, 1, 1),
                     base_QPs=torch.full((T, 1, 1, 1), base_qp / 255.0, dtype=torch.float32),
                     mv_records=torch.from_numpy(np.concatenate(recs) if recs else np.zeros((0, 10), np.float32)),
                     rec_frame=torch.from_numpy(np.concatenate(rec_frame) if rec_frame else np.zeros((0,), np.int32)),
                     meta=dict(key=f'{key}/{0:08d}', lq_path=d, gt_path=os.path.join(self.gt_folder, key)))
+        return np.stack([f.result() for f in lq_f]), np.stack([f.result() for f in gt_f]), side
+
+    def __getitem__(self, idx):
+        """the reference pipeline's sample: RescaleToZeroOne + FramesToTensor give float32 (T,3,H,W) frames in [0,1]"""
+        import numpy as np
+        lq, gt, side = self._read_clip(idx)
+        f32 = lambda a: torch.from_numpy(a.astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous()
+        return dict(lq=f32(lq), gt=f32(gt), **side)
+
+    def get_uint8(self, idx):
+        """the same sample with the frames still uint8 (T,H,W,3) under lq_u8 / gt_u8: a quarter of the host and PCIe bytes; the
+        consumer (apis.ClipPrefetcher) divides by 255 and transposes on the device -- the same IEEE fp32 division, bit-identical"""
+        lq, gt, side = self._read_clip(idx)
+        return dict(lq_u8=torch.from_numpy(lq), gt_u8=torch.from_numpy(gt), **side)
 
 
 def collate(batch):

@@ -446,11 +446,20 @@ def test_conv_last_on_the_vector_alus_matches_the_mfma_kernel(vsr):
 # BASELINE configs[4] sizes (HR_davis_LR_128x128_IPB_LR_test.py: 180x320 frames, +x4 heads, mixed crf15/25/35)
 # and the headline size directly against the oracle
 # ------------------------------------------------------------------------------------------------------------
-def _oracle(cfg, sd_np, clip):
+_ORACLE_CACHE = {}
+
+
+def _oracle(cfg, sd_np, clip, key=None):
+    """the pinned CPU oracle on a whole clip; `key` caches the result for tests that share (cfg, weights, clip) seeds"""
+    if key is not None and key in _ORACLE_CACHE:
+        return _ORACLE_CACHE[key]
     t = {k: torch.from_numpy(v) for k, v in clip.items()}
     with torch.no_grad():
-        return cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, t['lq'], t['QPs'], t['slices'], t['mvs'],
-                                         t['base_QPs'], t['partitions'])
+        out = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd_np), cfg, t['lq'], t['QPs'], t['slices'], t['mvs'],
+                                        t['base_QPs'], t['partitions'])
+    if key is not None:
+        _ORACLE_CACHE[key] = out
+    return out
 
 
 def test_lr180_clip_fp32_vs_oracle():
@@ -518,7 +527,7 @@ def test_lr180_fp16_small_frame_kernel_vs_oracle(vsr):
     m.fp16_enabled = True
     assert m.get_option(_native.OPT_SMALL_F16) == 1
     out = run(m, clip).cpu()
-    ref = _oracle(cfg, sd_np, clip)
+    ref = _oracle(cfg, sd_np, clip, key=f'lr180_405_4050_{vsr}')
     gt = torch.from_numpy(clip['gt'])
     if vsr:
         gt = gt.repeat_interleave(4, -1).repeat_interleave(4, -2)
@@ -532,6 +541,41 @@ def test_lr180_fp16_small_frame_kernel_vs_oracle(vsr):
     assert torch.equal(run(m, clip).cpu(), out)
 
 
+@pytest.mark.parametrize('vsr', [False, True], ids=['enhance', 'x4'])
+def test_lr180_split_fp16_vs_oracle(vsr):
+    """configs[4]'s workload in split fp16 (PNP_PREC_F16X3) against the PINNED ORACLE at the exact-fp32 path's tolerance: the 64->64
+    convs on conv3x3_f16x3_kernel (450 tiles: 57 persistent blocks per XCD, one tile each), the x4 heads on the fp32 kernels."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, vsr=vsr)
+    sd_np = gu.syn.make_state_dict(cfg, seed=405)
+    clip = gu.syn.make_clip(seed=4050, n=1, t=2 if vsr else 3, h=180, w=320, slices='IBBBP', qp_mode='ipb', crf=25, block=4)
+    m = build(cfg, sd_np)
+    m.precision = 'f16x3'
+    out = run(m, clip).cpu()
+    ref = _oracle(cfg, sd_np, clip, key=f'lr180_405_4050_{vsr}')
+    d = float((out - ref).abs().max())
+    print(f'180x320 split fp16 (vsr={vsr}) vs oracle: max-abs {d:.3e}')
+    assert out.shape == ref.shape and d < TOL
+    m.precision = 'fp32'
+    o32 = run(m, clip).cpu()
+    assert not torch.equal(o32, out) and float((o32 - ref).abs().max()) < TOL
+
+
+def test_720p_clip_split_fp16_directly_vs_oracle():
+    """The 720p clip of the test below in split fp16: 7200 tiles on 512 persistent blocks, against the pinned oracle itself."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
+    sd_np = gu.syn.make_state_dict(cfg, seed=404, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=4040, n=1, t=2, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, par_classes=3)
+    m = build(cfg, sd_np)
+    m.precision = 'f16x3'
+    out = run(m, clip).cpu()
+    ref = _oracle(cfg, sd_np, clip, key='p720_404_4040')
+    d = float((out - ref).abs().max())
+    print('720p T=2 split fp16 max|hip - oracle| =', d)
+    assert d < TOL
+    gt = torch.from_numpy(clip['gt'])
+    assert abs(cpu_ref.clip_psnr(out, gt) - cpu_ref.clip_psnr(ref, gt)) < 1e-3
+
+
 def test_720p_clip_directly_vs_oracle():
     """The headline path itself (persistent strip kernel, 8x16 tiles, 720p) against the pinned oracle on a whole 2-frame
     clip -- not through a crop (about 40 s of CPU)."""
@@ -539,7 +583,7 @@ def test_720p_clip_directly_vs_oracle():
     sd_np = gu.syn.make_state_dict(cfg, seed=404, par_gain=10.0)
     clip = gu.syn.make_clip(seed=4040, n=1, t=2, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, par_classes=3)
     out = run(build(cfg, sd_np), clip).cpu()
-    ref = _oracle(cfg, sd_np, clip)
+    ref = _oracle(cfg, sd_np, clip, key='p720_404_4040')
     d = float((out - ref).abs().max())
     print('720p T=2 max|hip - oracle| =', d)
     assert d < TOL

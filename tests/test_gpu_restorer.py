@@ -336,3 +336,34 @@ def test_bench_gpus_8_launches_eight_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', '128', '--frames', '0'],
                          capture_output=True, text=True, timeout=600, env=env)
     assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_prefetcher_uint8_upload_is_bit_identical_to_the_float_pipeline(tmp_path):
+    """ClipPrefetcher takes the frames of an on-disk clip to the GPU as uint8 and applies RescaleToZeroOne + FramesToTensor
+    (/255, HWC -> CHW) there: every tensor must equal what the dataset's own float pipeline (the reference's) produces, bit
+    for bit, and the parallel file decode must keep the frame order."""
+    from pnp_vcve_amd import synthetic as syn
+    from pnp_vcve_amd.apis import ClipPrefetcher
+    from pnp_vcve_amd.datasets import build_dataset
+    lq, gt, qp = syn.write_clip_tree(str(tmp_path / 'data'), clips=['000', '011', '015'], t=5, h=72, w=104, seed=3)
+    ds = build_dataset(dict(type='SRREDSMultipleGTCompressDataset', lq_folder=lq, gt_folder=gt, num_input_frames=100,
+                            pipeline=[dict(type='LoadImageFromFileList_ipb', qp_slice_file=qp)], scale=1, val_partition='REDS4',
+                            test_mode=True))
+    assert len(ds) == 3
+    order = [2, 0, 1]
+    for i, data in zip(order, ClipPrefetcher(ds, order, 'cuda')):
+        ref = ds[i]
+        torch.cuda.synchronize()
+        assert 'lq_u8' not in data and data['lq'].dtype == torch.float32 and data['lq'].is_contiguous()
+        for k in ('lq', 'gt', 'slices', 'QPs', 'base_QPs'):
+            assert data[k].shape == (1,) + tuple(ref[k].shape), k
+            assert torch.equal(data[k][0].cpu(), ref[k]), (i, k)
+        # the raw MV records were painted into dense maps on the device: the same maps as through the float path
+        from pnp_vcve_amd.apis import _to_device
+        from pnp_vcve_amd.datasets import collate
+        via_float = _to_device(collate([ref]), torch.device('cuda'))
+        assert 'mv_records' not in data and torch.equal(data['mvs'], via_float['mvs'])
+        assert torch.equal(data['partitions'], via_float['partitions']) and torch.equal(data['lq'], via_float['lq'])
+        assert data['meta'][0]['key'] == ref['meta']['key']
+    # frames differ from clip to clip and from frame to frame (the equality above is not vacuous)
+    assert not torch.equal(ds[0]['lq'][0], ds[0]['lq'][1]) and not torch.equal(ds[0]['lq'], ds[1]['lq'])
