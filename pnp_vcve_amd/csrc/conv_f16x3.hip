@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     constexpr int NSET = 4;                                  // register sets of weight chunks (chunk c travels in set c % 4)
     constexpr int WPT = 2;
     constexpr int EIT = 8;
-    constexpr int RQC = 16;                                  // the chunk at whose top the residual rows and the next halo are requested
+    constexpr int RQR = 13, RQH = 15;                    // chunks at whose top the residual rows / the next halo are requested
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned long long dbg_t0 = 0, dbg_p = 0, dbg_k = 0, dbg_e = 0;
@@ -219,10 +219,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         for (int c = 0; c < NC; ++c) {
             if (PAR && c >= 18 && c >= ncr) break;
             if (c + 4 < NC && (!PAR || c + 4 < ncr)) request_chunk(c + 4);
-            if (c == RQC) {
-                // After the last 3x3 chunk request: memory returns in order, so a halo request (HBM) ahead of a weight chunk
-                // (L2) would hold the chunk back.  Residual rows / partial sums of THIS tile first (the epilogue needs them),
-                // then the halo of the NEXT tile, which rides in registers through the rest of the loop and the epilogue.
+            // After the last 3x3 chunk request (chunk 17, at the top of chunk 13): memory returns in order, so a tile-data request
+            // (HBM, ~2.5 us) ahead of a weight chunk (L2) would hold the chunk back.  Residual rows / partial sums of THIS tile first
+            // (the epilogue needs them), then -- once two more register sets have gone to the ring -- the halo of the NEXT tile,
+            // which rides in registers through the rest of the loop and the epilogue.
+            if (c == RQR) {
                 if (!PAR) {
                     const unsigned rbase = ((unsigned)((ty0 + 2 * wave) * W + tx0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
 #pragma unroll
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                         res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
                     }
                 }
-                if (!PAR) request_tile(has_next ? next : tile, has_next);
             }
+            if (c == RQH && !PAR) request_tile(has_next ? next : tile, has_next);
             float pj = 1.f;
             if (PAR && c >= 18) {
                 if (c == 18) fold(true);                   // (conv + bias) * gamma BEFORE the 1x1 partition branches
