@@ -367,6 +367,9 @@ int64_t pnp_addr32_bytes_per_lr_pixel(int vsr, int deform) {
     return b;
 }
 
+// op-level entry points: the conv kernels address an NHWC64 fp32 map with 32-bit byte offsets
+bool op_map_fits(int h, int w) { return h >= 1 && w >= 1 && (int64_t)h * w * 256 < ((int64_t)1 << 32); }
+
 Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     Workspace W;
     int64_t off = 0;
@@ -1134,6 +1137,7 @@ int pnp_conv3x3_f32_ex(int nsrc, const float* const* srcs, const int* src_channe
                        const float* residual, int act, float* out, int h, int w, int variant, const int* par_flags,
                        void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4) return PNP_ERR_BAD_ARG;
+    if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;      // 32-bit byte offsets into a map
     if (variant != PNP_CONV_AUTO && variant != PNP_CONV_TILE && variant != PNP_CONV_TILE_BIG) return PNP_ERR_BAD_ARG;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1236,6 +1240,7 @@ int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs, const int* src_channe
                        const float* bias, const float* gamma, const void* packed_w1x1_f16, const float* par,
                        const float* residual, int act, float* out, int h, int w, void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4) return PNP_ERR_BAD_ARG;
+    if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;      // 32-bit byte offsets into a map
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nsrc = nsrc;
@@ -1279,6 +1284,7 @@ int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs, const int* src_chan
                          const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
                          void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4 || !srcs || !src_channels || !packed_w_x3 || !out) return PNP_ERR_BAD_ARG;
+    if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;      // 32-bit byte offsets into a map
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nsrc = nsrc;
@@ -1315,6 +1321,7 @@ int pnp_conv3x3_f16_maps(int nsrc, const void* const* srcs, const int* src_chann
                          const float* par, const int* par_flags, const float* residual, int act, void* out, int out_f16,
                          void* out16, int h, int w, int chain, void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4) return PNP_ERR_BAD_ARG;
+    if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;      // 32-bit byte offsets into a map
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.nsrc = nsrc;

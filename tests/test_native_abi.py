@@ -146,3 +146,18 @@ def test_dcn_is_built_without_slp_vectorisation():
     from pnp_vcve_amd import build_native
     assert '-fno-slp-vectorize' in build_native.EXTRA_FLAGS.get('dcn.hip', [])
     assert all(src in build_native.SOURCES for src in build_native.EXTRA_FLAGS)
+
+
+def test_op_level_convs_refuse_maps_beyond_32_bit_offsets_before_touching_memory(lib):
+    """pnp_conv3x3_f32 / _f16 / _f16x3: an NHWC64 fp32 map of 4096 x 4096 pixels is exactly 4 GiB -> PNP_ERR_UNSUPPORTED (1002) on the
+    host, before any pointer is dereferenced on the device (runs without a GPU; the pointers are fakes)."""
+    import ctypes
+    fake = 0x1000
+    srcs = (ctypes.c_void_p * 1)(fake)
+    chans = (ctypes.c_int * 1)(64)
+    w = (ctypes.c_void_p * 1)(fake)
+    for hw, rc_exp in (((4096, 4096), 1002), ((0, 64), 1002)):
+        assert lib.pnp_conv3x3_f32(1, srcs, chans, w, None, None, None, None, None, 0, fake, hw[0], hw[1], None) == rc_exp
+        assert lib.pnp_conv3x3_f16(1, srcs, chans, w, None, None, None, None, None, 0, fake, hw[0], hw[1], None) == rc_exp
+        assert lib.pnp_conv3x3_f16x3(1, srcs, chans, w, w, None, None, None, None, None, None, 0, fake, hw[0], hw[1], None) == rc_exp
+    assert lib.pnp_conv3x3_f16x3(0, srcs, chans, w, w, None, None, None, None, None, None, 0, fake, 64, 64, None) == 1001
