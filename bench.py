@@ -641,6 +641,8 @@ def secondary_workloads(dev, T, no_cpu_baseline=False):
              workload='lr180', precision='fp16', vsr=False, clips=3, steps=5, warmup=2, crfs=[15, 25, 35]),
         dict(name='7x3x180x320 -> 720x1280 fp16 MFMA convs, x4 heads, mixed crf15/25/35 batch of 3 (configs[4] as described)',
              workload='lr180', precision='fp16', vsr=True, clips=3, steps=5, warmup=2, crfs=[15, 25, 35]),
+        dict(name='7x3x128x128 split-fp16 convs, 1 clip (north_star shape; opt-in PNP_PREC_F16X3, fp32-level results)', workload='128',
+             precision='f16x3', vsr=False, clips=1, steps=20, warmup=3),
     ]
     cpu128 = None if no_cpu_baseline else cpu_baseline_128(T)
     for sp in specs:

@@ -177,11 +177,11 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert 0 < r['frac_dense_par'] <= r['algorithmic_frac'] * 1.02
     assert 'U{0,1,2}' in d['config']['workload']
     sec = d['secondary']
-    assert len(sec) == 8
-    e2e = sec[7]                                   # the whole tools/test.py loop on an on-disk tree
+    assert len(sec) == 9
+    e2e = sec[8]                                   # the whole tools/test.py loop on an on-disk tree
     assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
     assert e2e['seconds_total'] >= e2e['seconds_generator_forward'] > 0
-    for e in sec[:7]:
+    for e in sec[:8]:
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
             assert e['roofline']['frac'] > 0 and e['launches_per_frame'] > 0
@@ -193,6 +193,7 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert x3['dtype'].startswith('split f16') and x3['roofline']['bound'] == 'mfma' and x3['value'] > 1.8 * d['value']
     assert x3['roofline']['achieved'] <= 3 * x3['roofline']['algorithmic_TFLOPs'] * 1.001
     assert abs(x3['psnr'] - d['psnr_per_rank'][0]) < 1e-3      # same clip, same weights: the fp32 headline's PSNR
+    assert sec[7]['dtype'].startswith('split f16') and sec[7]['value'] > sec[0]['value'] and abs(sec[7]['psnr'] - sec[0]['psnr']) < 1e-3
     assert all('cpu_baseline' not in e for e in sec)          # --no-cpu-baseline covers the secondary entries too
 
 
