@@ -193,7 +193,7 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert x3['dtype'].startswith('split f16') and x3['roofline']['bound'] == 'mfma' and x3['value'] > 1.8 * d['value']
     assert x3['roofline']['achieved'] <= 3 * x3['roofline']['algorithmic_TFLOPs'] * 1.001
     assert abs(x3['psnr'] - d['psnr_per_rank'][0]) < 1e-3      # same clip, same weights: the fp32 headline's PSNR
-    assert sec[7]['dtype'].startswith('split f16') and sec[7]['value'] > sec[0]['value'] and abs(sec[7]['psnr'] - sec[0]['psnr']) < 1e-3
+    assert sec[7]['dtype'].startswith('split f16') and sec[7]['roofline']['bound'] == 'mfma' and abs(sec[7]['psnr'] - sec[0]['psnr']) < 1e-3
     assert all('cpu_baseline' not in e for e in sec)          # --no-cpu-baseline covers the secondary entries too
 
 
