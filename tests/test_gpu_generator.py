@@ -657,3 +657,27 @@ def test_sparse_val_follows_the_training_flag():
     m.eval()
     with pytest.raises(NotImplementedError):
         run(m, two)
+
+
+def test_1080p_vs_oracle_and_2160p_across_precisions():
+    """Frames larger than any BASELINE config: 1920x1080 (16,200 tiles) against the pinned oracle in exact fp32 and split fp16, and
+    3840x2160 (64,800 tiles; a 64-channel map is 2.1 GB, the 32-bit offset guard's last size class) consistent across the three
+    precisions.  T = 2, 2 blocks per branch (the oracle run is ~25 s of CPU)."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    sd_np = gu.syn.make_state_dict(cfg, seed=407, par_gain=10.0)
+    for (h, w) in ((1080, 1920), (2160, 3840)):
+        clip = gu.syn.make_clip(seed=4070, n=1, t=2, h=h, w=w, slices='IBBBP', block=8, par_classes=3)
+        outs = {}
+        for prec in ('fp32', 'fp16', 'f16x3'):
+            m = build(cfg, sd_np)
+            m.precision = prec
+            outs[prec] = run(m, clip).cpu()
+            assert torch.isfinite(outs[prec]).all(), (h, w, prec)
+            del m
+        d16 = float((outs['fp16'] - outs['fp32']).abs().max())
+        d3 = float((outs['f16x3'] - outs['fp32']).abs().max())
+        print(f'{w}x{h}: max|fp16 - fp32| {d16:.2e}, max|f16x3 - fp32| {d3:.2e}')
+        assert 1e-7 < d16 < 2e-2 and d3 < TOL
+        if h == 1080:
+            ref = _oracle(cfg, sd_np, clip)
+            assert float((outs['fp32'] - ref).abs().max()) < TOL and float((outs['f16x3'] - ref).abs().max()) < TOL
