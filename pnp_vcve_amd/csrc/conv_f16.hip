@@ -505,7 +505,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                     const h4 uh = to_h4(u), vh = to_h4(v);
                     const h8 pk = __builtin_shufflevector(uh, vh, 0, 1, 2, 3, 4, 5, 6, 7);
                     const int gx = tx0 + ep8 + 8 * (i & 1);
-                    const unsigned o = (unsigned)(ty0 + 2 * wave + (i >> 1)) * o_sy + (unsigned)gx * o_sx + (unsigned)ec8 * 16u;
+                    const unsigned o = (unsigned)(ty0 + 2 * wave + (i >> 1)) * o_sy + (unsigned)gx * o_sx + o_c0 + (unsigned)ec8 * 16u;
                     buf_store4(r_out, gx < W ? o : OOB, __builtin_bit_cast(f32x4, pk));
                 }
             } else {

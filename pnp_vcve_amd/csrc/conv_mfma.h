@@ -70,7 +70,9 @@ static inline bool conv_f16_eligible(const ConvArgs& a, int cfg, int grid_y) {
     if (nwide > 1 && (a.residual || a.gamma || grid_y != 1 || a.out_mode != 0)) return false;
     if (has_par && (a.nsrc != 1 || !a.wpar_h || !a.par || grid_y != 1)) return false;
     // fp16 maps (a source read through its fp16 mirror, an fp16 output, an fp16 mirror of the fp32 output)
-    if ((a.src_f16 || a.out_f16 || a.out16) && (grid_y != 1 || a.out_mode != 0)) return false;
+    // ... in the NHWC64 modes: plain (0) and, for a source / output map (no mirror), the pixel-shuffle conv (1, four sub-pixel images)
+    if ((a.src_f16 || a.out_f16) && !(a.out_mode == 0 && grid_y == 1) && !(a.out_mode == 1 && a.nsrc == 1 && !a.out16)) return false;
+    if (a.out16 && (grid_y != 1 || a.out_mode != 0)) return false;
     if (a.out_f16 && (a.residual || a.out16 || a.nsrc != 1)) return false;
     if (a.src_f16 && a.nsrc != 1) {          // several sources: the one-launch kernel, which reads ALL wide sources as fp16
         for (int s = 0; s < a.nsrc; ++s)

@@ -640,8 +640,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.act = q.act_;
         a.out_mode = q.mode_;
         a.out_cstride = 448;
-        a.out_f16 = q.io16_ == 1;
-        a.src_f16 = q.io16_ == 2;
+        a.out_f16 = q.io16_ & 1;          // io16: bit 0 the output is an fp16 map, bit 1 source 0 is one
+        a.src_f16 = (q.io16_ & 2) ? 1 : 0;
         if (mirrors) {
             for (int s = 0; s < q.nsrc; ++s)
                 if (q.src16_[s]) {
@@ -897,14 +897,16 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                                   .mode(2).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));
                 if (rc) return rc;
             } else {        // :135-142: two PixelShufflePack(2) convs (4 sub-pixel weight images each), conv_hr, conv_last + x4 bilinear lr
+                // every map of the head is read by exactly one conv, as an MFMA A operand: fp16 maps all the way on the fp16 path
+                // (the 720p map between the second pixel shuffle and conv_hr alone is 236 MB written + read per frame in fp32)
                 rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->up_img[0]).bias(packed + g->up_bias[0], 64)
-                              .act(2).mode(1, 4, IMG_WIDE).to(W.u1));
+                              .act(2).mode(1, 4, IMG_WIDE).to(W.u1).f16_map(o16));
                 if (!rc)
                     rc = conv(ConvCall(2 * h, 2 * w, conv_pick_cfg(2 * h, 2 * w)).source(W.u1, 64, packed + g->up_img[1])
-                                  .bias(packed + g->up_bias[1], 64).act(2).mode(1, 4, IMG_WIDE).to(W.u2));
+                                  .bias(packed + g->up_bias[1], 64).act(2).mode(1, 4, IMG_WIDE).to(W.u2).f16_map(o16 | s16));
                 if (!rc)
                     rc = conv(ConvCall(4 * h, 4 * w, conv_pick_cfg(4 * h, 4 * w)).source(W.u2, 64, packed + g->hr_img)
-                                  .bias(flat + g->hr_bias).act(2).to(W.u3).f16_map(o16));
+                                  .bias(flat + g->hr_bias).act(2).to(W.u3).f16_map(o16 | s16));
                 if (!rc)
                     rc = conv(ConvCall(4 * h, 4 * w, CONV_CFG_RGB).source(W.u3, 64, packed + g->last_img)
                                   .bias(packed + g->last_bias).mode(3).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));

@@ -224,7 +224,7 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
         RD("the low-quality frame", a.lr, (size_t)(2 * a.lr_plane + (a.out_mode == 2 ? hw : hw / 16)) * 4);
         WR("the output frame", a.out, hw * 3 * 4);
     } else if (a.out_mode == 1) {
-        WR("the pixel-shuffled map", a.out, hw * 4 * 256);
+        WR("the pixel-shuffled map", a.out, hw * 4 * ((f16 && a.out_f16) ? 128 : 256));
     } else if (a.out_mode == 4) {
         WR("the offset/mask map", a.out, hw * (size_t)a.out_cstride * 4);
     } else {

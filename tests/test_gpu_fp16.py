@@ -203,7 +203,7 @@ def test_f16_intermediate_maps_are_bit_identical_to_fp32_storage():
     """The BAE-block intermediate is only ever an MFMA A operand: writing it rounded (fp16 map) instead of rounding it
     in its reader must not change a single bit of the clip."""
     from pnp_vcve_amd import _native
-    for name in ('gen_parfloat_72x88', 'gen_channel_last_64x64', 'gen_two_layer_64x64'):
+    for name in ('gen_parfloat_72x88', 'gen_channel_last_64x64', 'gen_two_layer_64x64', 'gen_vsr_64x64'):
         case = [c for c in gu.GEN_CASES if c['name'] == name][0]
         a, _ = _run(case, True, options=[(_native.OPT_F16_MAPS, 0)])
         b, _ = _run(case, True)

@@ -539,6 +539,11 @@ def test_lr180_fp16_small_frame_kernel_vs_oracle(vsr):
     # the small-frame kernel really was the one that ran: the persistent fp16 kernel gives the same bits
     m.set_option(_native.OPT_SMALL_F16, 0)
     assert torch.equal(run(m, clip).cpu(), out)
+    # fp16 maps between the launches (block intermediates, and through the whole x4 head: pixel shuffle -> pixel shuffle -> conv_hr
+    # -> conv_last) against fp32 storage of the same maps: every one of them is only ever read as an MFMA A operand -> same bits
+    m.set_option(_native.OPT_SMALL_F16, 1)
+    m.set_option(_native.OPT_F16_MAPS, 0)
+    assert torch.equal(run(m, clip).cpu(), out)
 
 
 @pytest.mark.parametrize('vsr', [False, True], ids=['enhance', 'x4'])
