@@ -14,8 +14,14 @@ def _to_device(data, device):
         if k + '_u8' in out:       # frames uploaded as uint8 (dataset.get_uint8): RescaleToZeroOne + FramesToTensor on the device.
             # The 256 possible values come from the host's own fp32 division (a device-side `x / 255.0` multiplies by a rounded
             # reciprocal and is not bit-equal): a table lookup reproduces numpy's bits by construction
-            lut = (torch.arange(256, dtype=torch.float32) / 255.0).to(out[k + '_u8'].device)
-            out[k] = lut[out.pop(k + '_u8').permute(0, 1, 4, 2, 3).contiguous().long()]
+            u8 = out.pop(k + '_u8')                                    # (n, T, H, W, 3)
+            lut = (torch.arange(256, dtype=torch.float32) / 255.0).to(u8.device)
+            n, t, h, w, c = u8.shape
+            f = torch.empty((n, t, c, h, w), dtype=torch.float32, device=u8.device)
+            for i in range(n):
+                for j in range(t):                                   # frame by frame: the int64 index of a 100-frame 720p clip is 2.2 GB
+                    f[i, j] = lut[u8[i, j].permute(2, 0, 1).long()]
+            out[k] = f
     if 'mv_records' in out:
         from .ops import rasterise_side_info
         rec, rf = out.pop('mv_records'), out.pop('rec_frame')
