@@ -39,6 +39,8 @@ struct X3Args {
     const float *bias, *gamma, *residual;
     float* out;
     int res_pre;                 // residual is added BEFORE the activation (partial sum of a source chain)
+    unsigned o_sy, o_sx, o_c0;   // output addressing: byte offset of pixel (gy, gx) = gy * o_sy + gx * o_sx + o_c0 (pixel shuffle: 2x map)
+    unsigned out_bytes;
     int H, W, act;
     unsigned long long* dbg;     // timeline: 8 u64 per block or nullptr
 };
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, map_bytes);
     const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : (const void*)a.src, a.residual ? map_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : (const void*)a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
-    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, map_bytes);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, a.out_bytes);
+    const unsigned o_sy = (unsigned)__builtin_amdgcn_readfirstlane((int)a.o_sy), o_sx = (unsigned)__builtin_amdgcn_readfirstlane((int)a.o_sx);
     const __amdgpu_buffer_rsrc_t r_flags = make_rsrc((PAR && a.par_flags) ? (const void*)a.par_flags : (const void*)a.src,
                                                      (PAR && a.par_flags) ? (unsigned)ntiles * 4u : 0);
     // weight chunks through descriptors too: voffset = 16 t for every load, the chunk in the SCALAR offset -- no per-chunk
@@ -296,14 +299,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
 #pragma unroll
         for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
         asm volatile("" ::: "memory");
-        const unsigned obase = ((unsigned)(ty0 + 2 * wave) * (unsigned)W + (unsigned)(tx0 + ep)) * 256u + (unsigned)ec * 16u;
+        const unsigned obase = (unsigned)(ty0 + 2 * wave) * o_sy + (unsigned)(tx0 + ep) * o_sx + a.o_c0 + (unsigned)ec * 16u;
 #pragma unroll
         for (int i = 0; i < EIT; ++i) {
             f32x4 v = rows[i] + k_pre * res4[i];
             v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
             v += k_post * res4[i];
             const bool ok = tx0 + ep + 4 * (i & 3) < W;
-            buf_store4(r_out, ok ? obase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB, v);
+            buf_store4(r_out, ok ? obase + (unsigned)(i >> 2) * o_sy + (unsigned)(i & 3) * 4u * o_sx : OOB, v);
         }
         if (DBG) {
             dbg_p += dbg_b - dbg_a;
@@ -373,7 +376,36 @@ int launch_f16x3_image(const float* src, void* dst, int nchunks, hipStream_t str
 
 // A conv over several sources runs as a chain that accumulates through `out` (fp32 partial sums, added before the activation
 // of the last link): the RGB frame first, on the exact fp32 kernel, then one split launch per 64-channel source.
+// A pixel-shuffle conv (out_mode 1, upsample.py:49-50) is four launches, one per sub-pixel weight image, each scattering its 64
+// channels to pixel (2y + dy, 2x + dx) of the 2H x 2W map.
 int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
+    if (a.out_mode == 1) {
+        for (int y = 0; y < 4; ++y) {
+            X3Args x;
+            x.src = a.src[0];
+            x.w = reinterpret_cast<const _Float16*>(a.wsrc_h[0]) + 2 * (long)y * a.w_ystride;     // split image: 2 halfs per float
+            x.wpar = nullptr;
+            x.par = nullptr;
+            x.par_plane = 0;
+            x.par_flags = nullptr;
+            x.bias = a.bias ? a.bias + y * a.bias_ystride : nullptr;
+            x.gamma = nullptr;
+            x.residual = nullptr;
+            x.res_pre = 0;
+            x.out = a.out;
+            x.H = a.H;
+            x.W = a.W;
+            x.act = a.act;
+            x.dbg = nullptr;
+            x.o_sy = (unsigned)a.W * 1024u;
+            x.o_sx = 512u;
+            x.o_c0 = (unsigned)(y >> 1) * (unsigned)a.W * 512u + (unsigned)(y & 1) * 256u;
+            x.out_bytes = (unsigned)a.H * (unsigned)a.W * 1024u;
+            const int rc = launch_x3<false, false>(x, stream);
+            if (rc) return rc;
+        }
+        return PNP_OK;
+    }
     int lr_idx = -1, wide[4], nwide = 0;
     for (int s = 0; s < a.nsrc; ++s) {
         if (a.src_c[s] == 4) lr_idx = s;
@@ -411,6 +443,10 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         x.W = a.W;
         x.act = last ? a.act : 0;
         x.dbg = a.dbg;
+        x.o_sy = (unsigned)a.W * 256u;
+        x.o_sx = 256u;
+        x.o_c0 = 0;
+        x.out_bytes = (unsigned)a.H * (unsigned)a.W * 256u;
         const int rc = x.wpar ? (x.dbg ? launch_x3<true, true>(x, stream) : launch_x3<true, false>(x, stream))
                               : (x.dbg ? launch_x3<false, true>(x, stream) : launch_x3<false, false>(x, stream));
         if (rc) return rc;

@@ -205,7 +205,7 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
         const size_t img = a.src_c[s] == 64 ? (rgb_head ? 9 * 2048 : 9 * 4096) : 4096;
         for (int y = 0; y < gy; ++y) {
             if (f16) RD("an fp16 weight image", (const uint16_t*)a.wsrc_h[s] + (size_t)y * a.w_ystride, img * 2);
-            else if (x3 && a.src_c[s] == 64) RD("a split fp16 weight image", a.wsrc_h[s], img * 4);
+            else if (x3 && a.src_c[s] == 64) RD("a split fp16 weight image", (const char*)a.wsrc_h[s] + (size_t)y * a.w_ystride * 4, img * 4);
             else RD("a weight image", a.wsrc[s] + (size_t)y * a.w_ystride, img * 4);
         }
     }
