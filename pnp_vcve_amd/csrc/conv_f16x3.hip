@@ -379,8 +379,12 @@ int launch_f16x3_image(const float* src, void* dst, int nchunks, hipStream_t str
 // A pixel-shuffle conv (out_mode 1, upsample.py:49-50) is four launches, one per sub-pixel weight image, each scattering its 64
 // channels to pixel (2y + dy, 2x + dx) of the 2H x 2W map.
 int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
-    if (a.out_mode == 1) {
-        for (int y = 0; y < 4; ++y) {
+    if (a.out_mode == 1 || a.out_mode == 4) {
+        // out_mode 4 (the DCN aligner's conv_offset[2], iconvsr_mv.py:30-36): grid_y blocks of 64 output channels into a map of
+        // out_cstride channels per pixel
+        const int ny = a.out_mode == 1 ? 4 : a.out_cstride / 64;
+        const unsigned pix = (unsigned)a.out_cstride * 4u;
+        for (int y = 0; y < ny; ++y) {
             X3Args x;
             x.src = a.src[0];
             x.w = reinterpret_cast<const _Float16*>(a.wsrc_h[0]) + 2 * (long)y * a.w_ystride;     // split image: 2 halfs per float
@@ -397,10 +401,17 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
             x.W = a.W;
             x.act = a.act;
             x.dbg = nullptr;
-            x.o_sy = (unsigned)a.W * 1024u;
-            x.o_sx = 512u;
-            x.o_c0 = (unsigned)(y >> 1) * (unsigned)a.W * 512u + (unsigned)(y & 1) * 256u;
-            x.out_bytes = (unsigned)a.H * (unsigned)a.W * 1024u;
+            if (a.out_mode == 1) {
+                x.o_sy = (unsigned)a.W * 1024u;
+                x.o_sx = 512u;
+                x.o_c0 = (unsigned)(y >> 1) * (unsigned)a.W * 512u + (unsigned)(y & 1) * 256u;
+                x.out_bytes = (unsigned)a.H * (unsigned)a.W * 1024u;
+            } else {
+                x.o_sy = (unsigned)a.W * pix;
+                x.o_sx = pix;
+                x.o_c0 = 256u * (unsigned)y;
+                x.out_bytes = (unsigned)a.H * (unsigned)a.W * pix;
+            }
             const int rc = launch_x3<false, false>(x, stream);
             if (rc) return rc;
         }

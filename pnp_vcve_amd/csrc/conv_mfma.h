@@ -85,12 +85,15 @@ int launch_conv3x3_f16(const ConvArgs& a, int grid_y, hipStream_t stream);
 
 // split-fp16 variant (conv_f16x3.hip): fp32 maps in and out, three fp16 MFMAs per product.  Takes the NHWC64 convs of 64-channel
 // sources (+ optionally the RGB frame, which runs on the exact fp32 kernel as the first link of the source chain) and the pixel-
-// shuffle convs; the RGB heads and the DCN offset convs stay on the fp32 kernels.
+// shuffle and DCN offset convs (one launch per 64-channel output block); the RGB heads stay on the fp32 kernels.
 int launch_f16x3_image(const float* src, void* dst, int nchunks, hipStream_t stream);      // nchunks * 16 KiB
 static inline bool conv_f16x3_eligible(const ConvArgs& a, int cfg, int grid_y) {
     if (cfg != CONV_CFG_RGB && a.out_mode == 1 && grid_y == 4)       // pixel-shuffle conv: one 64-channel source, four sub-pixel images
         return a.nsrc == 1 && a.src_c[0] == 64 && a.wsrc_h[0] && !a.wpar && !a.wpar_h && !a.residual && !a.gamma && !a.src_f16 &&
                !a.out_f16 && !a.out16 && (long)a.H * a.W * 1024 < ((long)1 << 32);
+    if (cfg != CONV_CFG_RGB && a.out_mode == 4 && grid_y * 64 == a.out_cstride)     // DCN offset conv: grid_y blocks of 64 channels
+        return a.nsrc == 1 && a.src_c[0] == 64 && a.wsrc_h[0] && !a.wpar && !a.wpar_h && !a.residual && !a.gamma && !a.src_f16 &&
+               !a.out_f16 && !a.out16 && (long)a.H * a.W * a.out_cstride * 4 < ((long)1 << 32);
     if (cfg == CONV_CFG_RGB || a.out_mode != 0 || grid_y != 1) return false;
     int nwide = 0;
     for (int s = 0; s < a.nsrc; ++s)
