@@ -10,13 +10,16 @@
 // changes no data layout, only how a conv multiplies.  Opt-in (PNP_PREC_F16X3); the default and the headline stay exact fp32.
 //
 // Kernel: persistent 4-wave blocks, two per CU, each walking 8x16 tiles: two fp16 A tiles (hi, lo) converted from the fp32 halo
-// -- which is requested one tile ahead and rides in registers through the K loop --, weight chunks streamed from L2 through a
-// 3-slot ring.  The weight image
-// interleaves the two halves of the split so that every 8 KiB chunk is self-contained: chunk (tap, k-half) = 2 k-steps x
-// [hi N0, hi N1, lo N0, lo N1] units, i.e. per k-step 6 fragment reads (A hi, A lo, 4 x B) for 6 MFMAs -- 1 KiB of LDS reads
-// per MFMA, the ratio the matrix pipe sustains at full rate (profiles/r03_ub_lds.txt).  Chunks are requested four ahead into
-// register sets (L2 latency), written into the ring two ahead.  80.9 KiB of LDS -> two blocks per CU.  A partition branch
-// scales its A fragments by par_j(pixel) in fp32 and splits the product again (VALU work beside the MFMAs).
+// -- which is requested one tile ahead and rides in registers through the end of the K loop --, weight chunks streamed from L2
+// through a 3-slot ring.  The weight image interleaves the two halves of the split so that every 8 KiB chunk is self-contained:
+// chunk (tap, k-half) = 2 k-steps x [hi N0, hi N1, lo N0, lo N1] units, i.e. per k-step 6 fragment reads (A hi, A lo, 4 x B) for
+// 6 MFMAs -- one read per MFMA, at which two waves sharing a SIMD keep the matrix pipe full (33 cycles per MFMA and SIMD;
+// a wave on its own: 48, profiles/r03_ub_mfma_issue.txt).  Chunks are requested four ahead into register sets (L2 latency) and
+// written into the ring two ahead, in the middle of a chunk, so that the per-chunk barrier waits for that write only (counted
+// lgkmcnt) while the next k-step's fragments, fetched before the barrier, stay in flight.  80.9 KiB of LDS -> two blocks per CU.
+// A partition branch scales its A fragments by par_j(pixel) in fp32 and splits the product again (VALU work beside the MFMAs).
+// Pixel-shuffle (out_mode 1) and channel-block (out_mode 4) convs are one launch per 64-channel output block with an affine
+// output mapping (o_sy, o_sx, o_c0).  DESIGN.md 3.6 has the timeline and what bounds it.
 #include "conv_mfma.h"
 #include "f16_util.h"
 
@@ -39,7 +42,7 @@ struct X3Args {
     const float *bias, *gamma, *residual;
     float* out;
     int res_pre;                 // residual is added BEFORE the activation (partial sum of a source chain)
-    unsigned o_sy, o_sx, o_c0;   // output addressing: byte offset of pixel (gy, gx) = gy * o_sy + gx * o_sx + o_c0 (pixel shuffle: 2x map)
+    unsigned o_sy, o_sx, o_c0;   // output addressing: byte offset of pixel (gy, gx) = gy * o_sy + gx * o_sx + o_c0
     unsigned out_bytes;
     int H, W, act;
     unsigned long long* dbg;     // timeline: 8 u64 per block or nullptr
