@@ -313,6 +313,23 @@ def test_dist_test_driver_one_rank_over_rccl():
     assert get(one.stdout, 'PSNR') == get(rc.stdout, 'PSNR') and get(one.stdout, 'SSIM') == get(rc.stdout, 'SSIM')
 
 
+def test_tools_test_precision_switch():
+    """tools/test.py --precision f16x3 (split fp16) scores like the default fp32 run to the printed digits' last place or so; --precision
+    fp16 is the --fp16 switch."""
+    import re
+    common = ['--seed', '0', '--cfg-options', 'data.test.num_clips=2', 'data.test.num_input_frames=3',
+              'data.test.height=64', 'data.test.width=64']
+    cfgp = os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128_IPB.py')
+    res = {}
+    for flags in ((), ('--precision', 'f16x3'), ('--precision', 'fp16'), ('--fp16',)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), cfgp, 'none'] + common + list(flags),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        res[flags] = float(re.search(r'Eval-PSNR: ([0-9.]+)', out.stdout).group(1))
+    assert abs(res[()] - res[('--precision', 'f16x3')]) < 1e-4
+    assert res[('--precision', 'fp16')] == res[('--fp16',)] and abs(res[()] - res[('--fp16',)]) < 5e-2
+
+
 def test_bench_gpus_8_launches_eight_ranks():
     """`python bench.py --gpus 8` -- the driver's scaling run -- on the one GPU of this box: eight rank processes from the
     launcher (all on cuda:0; gloo for the tiny collectives because RCCL wants one GPU per rank), eight per-rank entries,

@@ -35,6 +35,9 @@ def parse_args():
     p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
     p.add_argument('--fp16', action='store_true',
                    help='fp16 MFMA operands for the 64-channel convs (same as `fp16 = dict()` in the config); default fp32')
+    p.add_argument('--precision', choices=['fp32', 'fp16', 'f16x3'], default=None,
+                   help="arithmetic of the 64-channel convs: fp32 (exact, default), fp16 (= --fp16), f16x3 (split fp16: fp32-level "
+                        "results from three fp16 MFMAs per product, ~2.2x the fp32 rate); also `precision = '...'` in the config")
     p.add_argument('--local_rank', type=int, default=0)
     a = p.parse_args()
     if 'LOCAL_RANK' not in os.environ:
@@ -68,6 +71,9 @@ def main():
     if cfg.get('fp16', None) is not None or args.fp16:      # mmcv idiom: `fp16 = dict(...)` in the config
         from pnp_vcve_amd.restorer import wrap_fp16_model
         wrap_fp16_model(model)
+    precision = args.precision or cfg.get('precision', None)
+    if precision is not None:
+        model.precision = precision
     if args.save_path is not None:      # PNG encode off the critical path (pnp_vcve_amd/io_async.py)
         from pnp_vcve_amd.io_async import FrameWriter
         model.frame_writer = FrameWriter(max_workers=4)
