@@ -545,7 +545,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pipeline_e2e(dev, T, clips=6, workers=16):
+def pipeline_e2e(dev, T, clips=6, workers=16, precision='fp32'):
     """The whole evaluation loop of tools/test.py on an on-disk tree in the reference's REDS layout (restorers/basicvsr.py:155-231,
     apis/test.py:100-119): PNG + MV-record decode on a loader thread and H2D on a side stream one clip ahead (ClipPrefetcher),
     MV / partition maps painted on the GPU (pnp_rasterise_side_info_f32), the fp32 generator, PSNR + SSIM on the device, enhanced
@@ -574,6 +574,7 @@ def pipeline_e2e(dev, T, clips=6, workers=16):
         sd_np = syn.make_state_dict(cfg, seed=2025)
         model.generator.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
         model = model.to(dev).eval()
+        model.precision = precision
         out_dir = os.path.join(root, 'out')
         nrec = 0
         with FrameWriter(max_workers=workers) as writer:
@@ -603,7 +604,7 @@ def pipeline_e2e(dev, T, clips=6, workers=16):
         total = time.perf_counter() - t0
         model.frame_writer = None
         pngs = sum(len(f) for _, _, f in os.walk(out_dir))
-        return {'name': f'end-to-end tools/test.py loop on an on-disk REDS-layout tree: {n} clips x {T}x3x{h}x{w} fp32 (PNG + MV records from '
+        return {'name': f'end-to-end tools/test.py loop on an on-disk REDS-layout tree: {n} clips x {T}x3x{h}x{w} {precision} (PNG + MV records from '
                         f'disk -> GPU rasteriser -> generator -> PSNR + SSIM on the device -> async PNG write-back)',
                 'metric': f'enhanced frames/sec ({w}x{h}, {T}-frame window), whole pipeline', 'value': n * T / total, 'unit': 'frames/s',
                 'frames_per_s_before_the_final_png_drain': n * T / t_loop,
@@ -612,7 +613,7 @@ def pipeline_e2e(dev, T, clips=6, workers=16):
                 'seconds_main_thread_waiting_for_loader_h2d_per_clip': stall[:-1],
                 'seconds_png_drain_after_last_clip': drain,
                 'seconds_metrics_and_uint8_d2h_and_submit': t_loop - fwd - sum(stall),
-                'png_workers': workers, 'pngs_written': pngs, 'psnr': float(sum(psnr) / max(len(psnr), 1)),
+                'dtype': DTYPE_TEXT[precision], 'png_workers': workers, 'pngs_written': pngs, 'psnr': float(sum(psnr) / max(len(psnr), 1)),
                 'seconds_writing_the_synthetic_tree_untimed': t_tree,
                 'note': 'clip 0 is an untimed warm-up; the loader thread works one clip ahead, so its decode + H2D are visible only where '
                         'they exceed the previous clip\'s GPU time'}
