@@ -51,12 +51,18 @@ struct X3Args {
 // Halo geometry: 10 rows x 18 pixels x 16 float4.  Requests 0..9: row k, pixels 0..15 (thread t: pixel t >> 4, float4 t & 15);
 // requests 10, 11: the two right-hand pixel columns (item j = t + 256 (k - 10): row j >> 5, pixel 16 + ((j >> 4) & 1)) -- so the
 // global offset and the LDS address of request k are one per-thread base plus k times a constant (no per-request registers).
-template <bool PAR, bool DBG>
+// S4: 4x16-pixel tiles for frames with at most 256 8x16 tiles (half the CUs would otherwise idle): the four
+// waves are 2 M tiles (pixel rows 2 wm, 2 wm + 1) x 2 N halves, a wave owns 32 pixels x 32 channels (one accumulator pair, four
+// fragment reads for three MFMAs per k-step); halo 6 rows = requests 0..5 + one side request (t < 192).
+template <bool PAR, bool DBG, bool S4>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     constexpr int NC = 18 + (PAR ? 6 : 0);                   // chunks: two k-halves per tap, then two per partition branch
     constexpr int NSET = 4;                                  // register sets of weight chunks (chunk c travels in set c % 4)
     constexpr int WPT = 2;
-    constexpr int EIT = 8;
+    constexpr int THX = S4 ? 4 : TH, ROWS = THX + 2, ABY = ROWS * RSB;      // tile rows, halo rows, bytes of one fp16 A tile
+    constexpr int NTW = S4 ? 1 : 2;                          // 32-channel N tiles per wave
+    constexpr int NREQ = S4 ? ROWS + 1 : X3_AIT;             // 16-byte halo requests per thread
+    constexpr int CW = NTW * 8, PPI = 64 / CW, EIT = 32 / PPI;   // epilogue: float4 per pixel in the wave's N range, pixels per instruction
     constexpr int RQR = 13, RQH = 15;                    // chunks at whose top the residual rows / the next halo are requested
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -68,9 +74,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         dbg_r0 = __builtin_amdgcn_s_memrealtime();
     }
     const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    const int wrow = S4 ? wave >> 1 : wave, wn = S4 ? wave & 1 : 0;      // the wave's pixel-row pair and N half
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
-    const int ntiles = tiles_x * ((H + TH - 1) / TH);
+    const int ntiles = tiles_x * ((H + THX - 1) / THX);
     // Persistent blocks, two per CU.  XCD x (blockIdx & 7) owns the contiguous band of tiles [ntiles*x/8, ntiles*(x+1)/8); its
     // blocks walk the band interleaved (block i takes tiles i, i + per, ...), so at any moment an XCD works on one window of
     // consecutive tiles whose shared halo rows meet in its L2.
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     const int band_hi = (int)((long)ntiles * (xcd + 1) / 8);
     int tile = (int)((long)ntiles * xcd / 8) + (blockIdx.x >> 3);
     if (tile >= band_hi) return;
-    char* const sR = smem + 2 * A_BYTES;
+    char* const sR = smem + 2 * ABY;
 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
     const unsigned row_bytes = (unsigned)W * 256u;
@@ -88,21 +95,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, a.out_bytes);
     const unsigned o_sy = (unsigned)__builtin_amdgcn_readfirstlane((int)a.o_sy), o_sx = (unsigned)__builtin_amdgcn_readfirstlane((int)a.o_sx);
     const __amdgpu_buffer_rsrc_t r_flags = make_rsrc((PAR && a.par_flags) ? (const void*)a.par_flags : (const void*)a.src,
-                                                     (PAR && a.par_flags) ? (unsigned)ntiles * 4u : 0);
+                                                     (PAR && a.par_flags) ? (unsigned)(tiles_x * ((H + TH - 1) / TH)) * 4u : 0);   // per 8x16 tile
     // weight chunks through descriptors too: voffset = 16 t for every load, the chunk in the SCALAR offset -- no per-chunk
     // 64-bit address pairs for the compiler to hoist out of the tile loop and spill
     const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.w, 18u * X3_CHUNK);
     const __amdgpu_buffer_rsrc_t r_wp = make_rsrc(PAR ? (const void*)a.wpar : (const void*)a.w, 6u * X3_CHUNK);
-    const int ec = lane & 15, ep = lane >> 4, n0 = lane & 31;
+    const int ec = lane % CW, ep = lane / CW, n0 = lane & 31;
     const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     const float k_pre = a.res_pre ? 1.f : 0.f, k_post = 1.f - k_pre;
-    float bco[2], gco[2];
+    float bco[NTW], gco[NTW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        bco[j] = a.bias ? a.bias[j * 32 + n0] : 0.f;
-        gco[j] = a.gamma ? a.gamma[j * 32 + n0] : 1.f;
+    for (int j = 0; j < NTW; ++j) {
+        bco[j] = a.bias ? a.bias[(wn * NTW + j) * 32 + n0] : 0.f;
+        gco[j] = a.gamma ? a.gamma[(wn * NTW + j) * 32 + n0] : 1.f;
     }
-    const int a_off = (2 * wave + my) * RSB + mx * PSB + 16 * h;
+    const int a_off = (2 * wrow + my) * RSB + mx * PSB + 16 * h;
     // per-thread halo bases (see above)
     const int hp = t >> 4, hcs = t & 15;
     const int h2r = t >> 5, h2x = 16 + ((t >> 4) & 1);
@@ -111,27 +118,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     char* const l_main = smem + hp * PSB + hcs * 8;                                         // + k * RSB
     // request 11 covers rows 8, 9 only (t < 64): the other threads park their (zero) value in the pad bytes of row 9
     char* const l_side = smem + h2r * RSB + h2x * PSB + hcs * 8;
-    char* const l_side11 = t < 64 ? l_side + 8 * RSB : smem + 9 * RSB + PW * PSB + hcs * 8;
+    char* const l_park = smem + (ROWS - 1) * RSB + PW * PSB + hcs * 8;
+    char* const l_side11 = t < 64 ? l_side + 8 * RSB : l_park;
+    char* const l_side6 = t < 192 ? l_side : l_park;          // S4: the one side request covers rows 0..5
 
     // ---- requests that travel ahead of their tile: the fp32 halo (12 x 16 B per thread) and its partition values / flags
-    f32x4 areg[X3_AIT];
+    f32x4 areg[NREQ];
     float pvn[3] = {0.f, 0.f, 0.f};
     int pfn = 0;
     auto request_tile = [&](int tl, bool live) {             // !live: every offset out of range (loads return 0, no branch)
-        const int ty0 = (tl / tiles_x) * TH, tx0 = (tl % tiles_x) * TW;
+        const int ty0 = (tl / tiles_x) * THX, tx0 = (tl % tiles_x) * TW;
         const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * 256u;
         const bool ok_main = live & ((unsigned)(tx0 - 1 + hp) < (unsigned)W);    // rows outside the image leave the descriptor by themselves
         const bool ok_side = live & ((unsigned)(tx0 - 1 + h2x) < (unsigned)W);
 #pragma unroll
-        for (int k = 0; k < 10; ++k) areg[k] = buf_load4(r_src, ok_main ? hbase + g_main + (unsigned)k * row_bytes : OOB);
-        areg[10] = buf_load4(r_src, ok_side ? hbase + g_side : OOB);
-        areg[11] = buf_load4(r_src, (ok_side & (t < 64)) ? hbase + g_side + 8u * row_bytes : OOB);
+        for (int k = 0; k < ROWS; ++k) areg[k] = buf_load4(r_src, ok_main ? hbase + g_main + (unsigned)k * row_bytes : OOB);
+        if (S4) {
+            areg[ROWS] = buf_load4(r_src, (ok_side & (t < 192)) ? hbase + g_side : OOB);
+        } else {
+            areg[NREQ - 2] = buf_load4(r_src, ok_side ? hbase + g_side : OOB);
+            areg[NREQ - 1] = buf_load4(r_src, (ok_side & (t < 64)) ? hbase + g_side + 8u * row_bytes : OOB);
+        }
         if (PAR) {
-            const int gy = ty0 + 2 * wave + my, gx = tx0 + mx;
+            const int gy = ty0 + 2 * wrow + my, gx = tx0 + mx;
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj)
                 pvn[jj] = buf_load1(r_par, (live & (gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
-            pfn = __builtin_bit_cast(int, buf_load1(r_flags, live ? (unsigned)tl * 4u : OOB));
+            const int fidx = S4 ? ((tl / tiles_x) >> 1) * tiles_x + tl % tiles_x : tl;       // the 8x16 tile this one lies in
+            pfn = __builtin_bit_cast(int, buf_load1(r_flags, live ? (unsigned)fidx * 4u : OOB));
         }
     };
     int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
@@ -154,15 +168,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     for (;;) {
         unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0;
         if (DBG) dbg_a = __builtin_amdgcn_s_memtime();
-        const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+        const int ty0 = (tile / tiles_x) * THX, tx0 = (tile % tiles_x) * TW;
         // ---- fp32 halo -> the two fp16 A tiles: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048); chunks 0, 1 -> ring
 #pragma unroll
-        for (int k = 0; k < X3_AIT; ++k) {
+        for (int k = 0; k < NREQ; ++k) {
             const h4 hi = to_h4(areg[k]);
             const f32x4 rem = (areg[k] - __builtin_convertvector(hi, f32x4)) * X3_SCALE;
-            char* d = k < 10 ? l_main + k * RSB : (k == 10 ? l_side : l_side11);
+            char* d = k < ROWS ? l_main + k * RSB : (S4 ? l_side6 : (k == ROWS ? l_side : l_side11));
             *reinterpret_cast<h4*>(d) = hi;
-            *reinterpret_cast<h4*>(d + A_BYTES) = to_h4(rem);
+            *reinterpret_cast<h4*>(d + ABY) = to_h4(rem);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -187,9 +201,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         if (DBG) dbg_b = __builtin_amdgcn_s_memtime();
 
         // ---- K loop: chunk c from ring slot c % 3: two k-steps of hi*hi -> acc_hi, lo*hi + hi*lo -> acc_lo
-        f32x16 acc_hi[2], acc_lo[2];
+        f32x16 acc_hi[NTW], acc_lo[NTW];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc_hi[j][r] = 0.f;
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             }
         auto fold = [&](bool with_bias) {          // acc_hi <- ((acc_hi + acc_lo / 2048) [+ bias]) [* gamma]; acc_lo <- 0
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NTW; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc_hi[j][r] + acc_lo[j][r] * X3_INV;
@@ -208,16 +222,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         f32x4 res4[EIT];
 #pragma unroll
         for (int i = 0; i < EIT; ++i) res4[i] = (f32x4)(0.f);
-        struct Frag { h8 ah, al, b[4]; };                    // one k-step: A hi, A lo, B hi N0 / hi N1 / lo N0 / lo N1
+        struct Frag { h8 ah, al, b[2 * NTW]; };              // one k-step: A hi, A lo, B hi (N tiles of the wave), B lo (same)
         auto load_frag = [&](int c, int s2) {               // c, s2 compile-time after unrolling
             const int tap = c >> 1, kh = c & 1, dy = c < 18 ? tap / 3 : 1, dx = c < 18 ? tap % 3 : 1;
             const int o = a_off + dy * RSB + dx * PSB + 32 * (2 * kh + s2);
             const char* b_lane = sR + (c % X3_RING) * X3_CHUNK + lane * 16;
             Frag f;
             f.ah = *reinterpret_cast<const h8*>(smem + o);
-            f.al = *reinterpret_cast<const h8*>(smem + A_BYTES + o);
+            f.al = *reinterpret_cast<const h8*>(smem + ABY + o);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) f.b[u] = *reinterpret_cast<const h8*>(b_lane + (s2 * 4 + u) * UNIT);
+            for (int u = 0; u < 2 * NTW; ++u)     // chunk units per k-step: [hi N0, hi N1, lo N0, lo N1]
+                f.b[u] = *reinterpret_cast<const h8*>(b_lane + (s2 * 4 + (S4 ? 2 * u + wn : u)) * UNIT);
             return f;
         };
         Frag fr = load_frag(0, 0);
@@ -231,11 +246,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             // which rides in registers through the rest of the loop and the epilogue.
             if (c == RQR) {
                 if (!PAR) {
-                    const unsigned rbase = ((unsigned)((ty0 + 2 * wave) * W + tx0 + ep) * 64u + (unsigned)ec * 4u) * 4u;
 #pragma unroll
-                    for (int i = 0; i < EIT; ++i) {
-                        const bool ok = tx0 + ep + 4 * (i & 3) < W;
-                        res4[i] = buf_load4(r_res, ok ? rbase + (unsigned)(i >> 2) * row_bytes + (unsigned)(i & 3) * 1024u : OOB);
+                    for (int i = 0; i < EIT; ++i) {       // the wave's pixel p = ep + PPI i: row p >> 4, column p & 15
+                        const int p = ep + PPI * i, gx = tx0 + (p & 15);
+                        const unsigned ro = ((unsigned)(ty0 + 2 * wrow + (p >> 4)) * (unsigned)W + (unsigned)gx) * 256u +
+                                            (unsigned)wn * 128u + (unsigned)ec * 16u;
+                        res4[i] = buf_load4(r_res, gx < W ? ro : OOB);
                     }
                 }
             }
@@ -263,12 +279,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                     ah = __builtin_convertvector(__builtin_elementwise_min(__builtin_elementwise_max(v, (f32x8)(-65504.f)), (f32x8)(65504.f)), h8);
                     al = __builtin_convertvector((v - __builtin_convertvector(ah, f32x8)) * X3_SCALE, h8);
                 }
-                acc_hi[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[0], acc_hi[0], 0, 0, 0);
-                acc_hi[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[1], acc_hi[1], 0, 0, 0);
-                acc_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fr.b[0], acc_lo[0], 0, 0, 0);
-                acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fr.b[1], acc_lo[1], 0, 0, 0);
-                acc_lo[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[2], acc_lo[0], 0, 0, 0);
-                acc_lo[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[3], acc_lo[1], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc_hi[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[j], acc_hi[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fr.b[j], acc_lo[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[NTW + j], acc_lo[j], 0, 0, 0);
                 if (s2 == 0 && c + 2 < NC && (!PAR || c + 2 < ncr)) {
                     // ring write of chunk c + 2 (into the slot of chunk c - 1, which every wave left before the previous barrier)
                     // in the MIDDLE of the chunk: the barrier below then waits for it, not for the fragment reads behind it
@@ -279,10 +295,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (s2 == 0 || c + 1 < NC) fr = nf;
             }
-            // LDS operations complete in order: the 6 fragment reads of the next chunk's first k-step were issued after the ring
-            // write, so "at most 6 outstanding" means the write has landed -- and the reads stay in flight across the barrier
-            if (c + 1 < NC) asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory");
-            else lds_barrier();
+            // LDS operations complete in order: the 6 (S4: 4) fragment reads of the next chunk's first k-step were issued after the
+            // ring write, so "at most that many outstanding" means the write has landed -- and the reads stay in flight across the barrier
+            if (c + 1 >= NC) lds_barrier();
+            else if (S4) asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory");
         }
         if (DBG) dbg_c = __builtin_amdgcn_s_memtime();
         // the branch chunks' VALU work (scaling and re-splitting A fragments) needs the registers: the next halo only now
@@ -291,25 +308,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         fold(!PAR || ncr == 18);         // PAR with branches: bias / gamma went in before them; otherwise here
 
         // ---- epilogue: transpose through the dead A tiles, [+ partial sum], activation, [+ residual], whole pixel rows to HBM
-        float* sT = reinterpret_cast<float*>(smem + wave * 8192);
+        static_assert(4 * 4096 * NTW <= 2 * ABY, "the transposition slices fit the dead A tiles");
+        float* sT = reinterpret_cast<float*>(smem + wave * (4096 * NTW));        // [32 pixels][32 NTW channels] fp32 per wave
         const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + n0] = acc_hi[j][r];
+            for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (32 * NTW) + j * 32 + n0] = acc_hi[j][r];
         asm volatile("" ::: "memory");
         f32x4 rows[EIT];
 #pragma unroll
-        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + 4 * i) * 16 + ec];
+        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + PPI * i) * CW + ec];
         asm volatile("" ::: "memory");
-        const unsigned obase = (unsigned)(ty0 + 2 * wave) * o_sy + (unsigned)(tx0 + ep) * o_sx + a.o_c0 + (unsigned)ec * 16u;
 #pragma unroll
         for (int i = 0; i < EIT; ++i) {
             f32x4 v = rows[i] + k_pre * res4[i];
             v = __builtin_elementwise_max(v, (f32x4)(0.f)) + neg_slope * __builtin_elementwise_min(v, (f32x4)(0.f));
             v += k_post * res4[i];
-            const bool ok = tx0 + ep + 4 * (i & 3) < W;
-            buf_store4(r_out, ok ? obase + (unsigned)(i >> 2) * o_sy + (unsigned)(i & 3) * 4u * o_sx : OOB, v);
+            const int p = ep + PPI * i, gx = tx0 + (p & 15);
+            const unsigned o = (unsigned)(ty0 + 2 * wrow + (p >> 4)) * o_sy + (unsigned)gx * o_sx + a.o_c0 + (unsigned)wn * 128u + (unsigned)ec * 16u;
+            buf_store4(r_out, gx < W ? o : OOB, v);
         }
         if (DBG) {
             dbg_p += dbg_b - dbg_a;
@@ -352,19 +370,29 @@ __global__ __launch_bounds__(256) void f16x3_image_kernel(const float* __restric
     d[2 * 512] = lo;
 }
 
-template <bool PAR, bool DBG>
-int launch_x3(const X3Args& xa, hipStream_t stream) {
-    auto kern = conv3x3_f16x3_kernel<PAR, DBG>;
+template <bool PAR, bool DBG, bool S4>
+int launch_x3_t(const X3Args& xa, hipStream_t stream) {
+    auto kern = conv3x3_f16x3_kernel<PAR, DBG, S4>;
+    constexpr int lds = S4 ? 2 * (4 + 2) * RSB + X3_RING * X3_CHUNK : X3_LDS;
     static PnpPerDevice once;
     const hipError_t attr_err = once.run([&](int, int&) {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     if (attr_err != hipSuccess) return (int)attr_err;
-    const int tiles = ((xa.W + TW - 1) / TW) * ((xa.H + TH - 1) / TH);
+    const int th = S4 ? 4 : TH;
+    const int tiles = ((xa.W + TW - 1) / TW) * ((xa.H + th - 1) / th);
     int per_xcd = (tiles + 7) / 8;                // blocks per XCD: two per CU at most (32 CUs), one tile each on small frames
     if (per_xcd > 64) per_xcd = 64;
-    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(256), X3_LDS, stream, xa);
+    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(256), lds, stream, xa);
     return (int)hipGetLastError();
+}
+
+// frames with at most one 8x16 tile per CU run on 4x16 tiles -- twice the blocks, half the work each.  Measured: 128x128 (128
+// tiles) 2240 -> 2888 frames/s; 180x320 (460 tiles, three clips) loses 9 % on them and stays on 8x16.
+template <bool PAR, bool DBG>
+int launch_x3(const X3Args& xa, hipStream_t stream) {
+    const int tiles8 = ((xa.W + TW - 1) / TW) * ((xa.H + TH - 1) / TH);
+    return tiles8 <= 256 ? launch_x3_t<PAR, DBG, true>(xa, stream) : launch_x3_t<PAR, DBG, false>(xa, stream);
 }
 
 }  // namespace
