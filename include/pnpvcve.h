@@ -68,7 +68,8 @@ int64_t pnp_generator_packed_floats(const pnp_generator* g);
  * hi + lo/2048 (two fp16 numbers, 22 significand bits) and each product is three fp16 MFMAs with fp32
  * accumulation; results agree with PNP_PREC_F32 to ~1e-6 relative per conv (inside north_star's 1e-3 gate,
  * which PNP_PREC_F16 is not) at about a third of the fp16 matrix rate.  Feature maps stay fp32; the RGB
- * frame, the RGB head (conv_last) and the deformable alignment stay on the exact fp32 kernels.
+ * frame, the RGB head (conv_last) and the deformable alignment stay on the exact fp32 kernels.  Range: the high
+ * parts are fp16, so activations and weights beyond +-65504 saturate (the exact fp32 path has no such limit).
  * Set it BEFORE sizing/packing: it changes pnp_generator_packed_floats and pnp_generator_workspace_bytes. */
 #define PNP_PREC_F32 0
 #define PNP_PREC_F16 1
