@@ -382,15 +382,13 @@ def test_f16_partition_branch_skipping_is_value_identical(hw):
 
 
 @pytest.mark.parametrize('hw', [(40, 56), (180, 320), (256, 512)], ids=lambda s: '%dx%d' % s)
-@pytest.mark.parametrize('nwide', [1, 2, 3])
-@pytest.mark.parametrize('with_lr', [False, True], ids=['wide', 'rgb+wide'])
+@pytest.mark.parametrize('nwide,with_lr', [(1, True), (2, False), (2, True), (3, False), (3, True)],     # (1, False) is the ordinary
+                         ids=['rgb+1', '2', 'rgb+2', '3', 'rgb+3'])                                     # single-source kernel
 def test_f16_input_conv_in_one_launch_equals_the_launch_chain(hw, nwide, with_lr):
     """conv3x3_f16_multi_kernel (all wide sources read through fp16 mirrors, one launch) against the chain of single-source
     launches through fp32 partial sums: same MFMA chains per source, folded in the chain's order -- bit-identical, and so is
     the fp16 mirror of the result."""
     from pnp_vcve_amd import ops
-    if nwide == 1 and not with_lr:
-        pytest.skip('a single 64-channel source is the ordinary single-source kernel')
     h, w = hw
     cin = (3 if with_lr else 0) + 64 * nwide
     lr = gu.syn.uniform(53, 'lr', (1, 3, h, w), 0, 1)
