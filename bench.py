@@ -13,9 +13,11 @@ tools/dist_test.sh:11-22).  Clips are sharded one per rank (weak scaling, replic
 tensors), a barrier + synchronize on both sides of the timed region, MAX over ranks, and one RCCL all-gather of
 (PSNR, frames/s) per rank (mmedit/apis/test.py:211-233).  Rank 0 prints ONE JSON line.
 
-At N = 1 with the default workload the line also carries `secondary`: the other BASELINE.json workloads
-(7x3x128x128 fp32, 1 and 8 clips; 180x320 fp16 with and without the x4 heads), measured in the same process after the
-headline with their own timed region, roofline and kernel-event mode.
+stdout carries exactly ONE strict-JSON line of at most 4 KB (the driver keeps the last 8 KB of stdout; round 3's 21 KB line was
+cut in half and never parsed).  At N = 1 with the default workload the other BASELINE.json workloads (7x3x128x128 fp32, 1 and
+8 clips; 180x320 fp16 with and without the x4 heads; the opt-in precisions at 720p; the end-to-end loop) are measured in the same
+process after the headline, each with its own timed region, roofline and kernel-event mode; they go to `bench_secondary.json`
+beside this file (and to stderr), and the line carries only `north_star_128`, a compact summary of the 7x3x128x128 entries.
 """
 import argparse
 import json
@@ -119,6 +121,52 @@ def _launch_weighted_traffic(pmc, prefix):
     if not ks:
         return None
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
+
+
+MAX_LINE_BYTES = 4096
+SECONDARY_FILE = os.path.join(ROOT, 'bench_secondary.json')
+
+
+def strict(obj, digits=6):
+    """JSON-safe copy: non-finite floats -> None (json.dumps(allow_nan=False) would raise), floats to `digits` significant digits."""
+    import math
+    if isinstance(obj, float):
+        if not math.isfinite(obj):
+            return None
+        if obj.is_integer() and abs(obj) < 2.0 ** 53:
+            return int(obj)                       # byte / launch counts stay exact
+        return float(f'{obj:.{digits}g}') if digits else obj
+    if isinstance(obj, dict):
+        return {k: strict(v, digits) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [strict(v, digits) for v in obj]
+    return obj
+
+
+# what the single stdout line keeps of a roofline object (the full objects, with their prose, go to bench_secondary.json)
+ROOFLINE_KEEP = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_us', 'frac_wall',
+                 'algorithmic_frac', 'frac_dense_par', 'hbm_frac', 'algorithmic_bytes_per_launch', 'traffic_source')
+
+
+def bounded_line(res):
+    """the ONE stdout line: strict JSON, <= MAX_LINE_BYTES.  Rooflines are cut to ROOFLINE_KEEP with the kernel named by its
+    symbol only; if the line is still too long, optional blocks are dropped in a fixed order (never value / roofline / cpu_baseline)."""
+    line_obj = dict(res)
+    for k in ('roofline', 'roofline_mv_warp', 'roofline_dcn'):
+        if k in line_obj:
+            r = line_obj[k]
+            c = {q: r[q] for q in ROOFLINE_KEEP if q in r}
+            c['kernel'] = r['kernel'].split(' (')[0]
+            line_obj[k] = c
+    line_obj = strict(line_obj)
+    for drop in (None, 'frames_per_s_per_rank', 'psnr_per_rank', 'launches_per_frame', 'kernel_events', 'north_star_128', 'dist',
+                 'parity', 'roofline_dcn', 'roofline_mv_warp'):
+        if drop is not None:
+            line_obj.pop(drop, None)
+        line = json.dumps(line_obj, allow_nan=False, separators=(',', ':'))
+        if len(line.encode()) <= MAX_LINE_BYTES:
+            return line
+    raise RuntimeError(f'bench line is {len(line)} bytes (> {MAX_LINE_BYTES}) even without its optional blocks')
 
 
 def make_inputs(seed, t, h, w, dev, n=1, crfs=None):
@@ -236,9 +284,16 @@ def build_model(cfg, sd_np, dev, precision, graphs=False):
     return m
 
 
-def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, dense_prof=None):
+def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, dense_prof=None, ms_per_step=None, clips=1):
     """roofline objects from the per-launch HIP-event records of pnp_generator_profile (device ms, launches,
-    algorithmic work per kind)."""
+    algorithmic work per kind).
+
+    Every roofline carries `frac_wall`: the path's algorithmic work per step in the roofline's unit (all conv FLOPs, or the
+    block convs' algorithmic bytes) over the step's WALL time -- comparable across entries.  With one clip per step launches run
+    back to back on one stream and `achieved` / `frac` are per-launch figures (work / sum of HIP-event launch durations).  With
+    several clips per step the clips run on side streams and their launches OVERLAP: the sum of launch durations exceeds the wall
+    time and a per-launch figure undersells the chip, so there `achieved` / `frac` ARE the wall-clock figures and the per-launch
+    ones are kept as `per_launch_achieved` / `per_launch_frac`."""
     import torch
     from pnp_vcve_amd.ops import par_tile_flags
     res = {}
@@ -333,6 +388,21 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
                     '(DESIGN.md 3.4 item 5, profiles/r03_ub_mfma_issue.txt): a wave issues in order and each 1-KiB fragment read costs '
                     'it 16 cycles of issue, so one wave per SIMD at 1.5 reads per MFMA runs 60 cycles per MFMA (two waves: 44.7 per '
                     'SIMD); the matrix phase at that rate is balanced against the memory phase of the partner group'}
+    r = res['roofline']
+    if ms_per_step:
+        if r['bound'] == 'mfma':
+            mult = 3.0 if precision == 'f16x3' else 1.0     # split fp16 executes three fp16 MFMAs per product
+            wall = mult * conv_fl / steps / (ms_per_step * 1e-3) / 1e12
+        else:
+            wall = bytes_frame * T * a['lq'].shape[0] / (ms_per_step * 1e-3) / 1e9
+        r['achieved_wall'] = wall
+        r['frac_wall'] = wall / r['peak']
+        if clips > 1:
+            r['per_launch_achieved'], r['per_launch_frac'] = r['achieved'], r['frac']
+            r['achieved'], r['frac'] = wall, wall / r['peak']
+            r['definition'] = ('clips run concurrently on side streams, launches overlap: achieved / frac = algorithmic work per step '
+                               '(all convs' + (' x 3 MFMAs per product' if precision == 'f16x3' else '') + ') / wall time per step; '
+                               'per_launch_* = work / sum of HIP-event launch durations (undersells overlapping launches)')
     if wp['launches']:
         gbs = wp['work'] / (wp['ms'] * 1e-3) / 1e9
         res['roofline_mv_warp'] = {'kernel': 'mv_warp_nhwc_kernel (MV-guided bilinear alignment)', 'bound': 'hbm',
@@ -352,6 +422,31 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
                                'algorithmic_bytes_per_launch': dc['work'] / dc['launches'],
                                'algorithmic_bytes_per_pixel': 2240}
     return res
+
+
+def timed_steps(step, steps, dist=None, cdev=None):
+    """The timed region of the contract: barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier; returns (last
+    output, this rank's seconds, MAX over ranks).  The collectives run over whatever backend the process group has (RCCL on the
+    GPU boxes; gloo in the CPU test of the 8-rank path, where there is no device to synchronize)."""
+    import torch
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max = elapsed
+    if dist is not None:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed_max = float(et.item())
+    return out, elapsed, elapsed_max
 
 
 def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, warmup, T, rank=0, world=1,
@@ -375,21 +470,7 @@ def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, 
     events_inside = kernel_events and workload == '720p'
     if events_inside:
         m.profile(True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed_max = elapsed
-    if dist is not None:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed_max = float(et.item())
+    out, elapsed, elapsed_max = timed_steps(step, steps, dist, cdev)
     if kernel_events and not events_inside:
         m.profile(True)
         for _ in range(steps):
@@ -424,7 +505,8 @@ def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, 
         tag = ptag if workload == '720p' and not vsr and cfg.get('deform', 'vos') == 'vos' \
             else f'{workload}_' + ptag + ('vsr_' if vsr else '') + ('' if cfg.get('deform', 'vos') == 'vos' else cfg['deform'] + '_')
         pmc, pmc_src = committed_pmc_traffic(tag)
-        res.update(rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, dense_prof))
+        res.update(rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, dense_prof,
+                             ms_per_step=res['ms_per_step'], clips=clips))
     return res, m, a
 
 
@@ -434,12 +516,14 @@ def workload_text(clips, T, h, w, workload, cfg, precision):
             f'8x8 block (one-hot/255, none on the I frame), quarter-pel block MVs, IBBBP cadence')
 
 
-def main():
-    args = parse_args()
+def main(argv=None, measure_fn=None):
+    """`measure_fn` replaces measure() in the CPU test of the rank path (tests/test_host_logic.py: 8 gloo ranks, no GPU); the
+    script itself always runs the real one and refuses to start without a GPU."""
+    args = parse_args(argv)
     global F16_MIRRORS
     F16_MIRRORS = args.f16_mirrors
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
 
     import numpy as np   # noqa: F401
     import torch
@@ -456,7 +540,11 @@ def main():
     # is created and every collective below runs over it even at WORLD_SIZE=1, so the RCCL path (init with device_id,
     # barrier, all_reduce(MAX), all_gather on device tensors, destroy) is the same code at N = 1 and N = 8.
     grouped = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
-    torch.cuda.set_device(dev)
+    if measure_fn is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError('bench.py needs an MI355X: no GPU is visible (there is no CPU path to measure)')
+        measure_fn = measure
+        torch.cuda.set_device(dev)
     if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -476,7 +564,7 @@ def main():
     T = args.frames
     headline = args.workload == '720p' and args.precision == 'fp32' and not args.vsr and args.deform == 'vos'
 
-    r, m, a = measure(dev, sd_np, cfg, workload=args.workload, precision=args.precision, vsr=args.vsr, clips=args.clips,
+    r, m, a = measure_fn(dev, sd_np, cfg, workload=args.workload, precision=args.precision, vsr=args.vsr, clips=args.clips,
                       graphs=args.graphs, steps=args.steps, warmup=args.warmup, T=T, rank=rank, world=world,
                       kernel_events=not args.no_kernel_events, dense_par=headline and world == 1,
                       dist=dist if grouped else None, cdev=cdev)
@@ -537,12 +625,55 @@ def main():
                              'gate': 1e-3}
         del m, a
         torch.cuda.empty_cache()
+        full = None
         if world == 1 and headline and not args.no_secondary and not args.no_kernel_events:
-            res['secondary'] = secondary_workloads(dev, T, args.no_cpu_baseline)
-        print(json.dumps(res), flush=True)
+            # the other BASELINE workloads: measured after the headline, written beside this file and to stderr -- never on stdout
+            try:
+                sec = secondary_workloads(dev, T, args.no_cpu_baseline)
+                res['north_star_128'] = north_star_128(sec)
+                res['secondary_file'] = os.path.basename(SECONDARY_FILE)
+                full = dict(res, secondary=sec)
+            except Exception as e:                      # the headline line must still be printed
+                print(f'bench.py: secondary workloads failed: {e!r}', file=sys.stderr, flush=True)
+                res['north_star_128'] = None
+        if full is not None:
+            text = json.dumps(strict(full, digits=0), allow_nan=False, indent=1)
+            try:
+                with open(SECONDARY_FILE, 'w') as fh:
+                    fh.write(text + '\n')
+            except OSError as e:
+                print(f'bench.py: cannot write {SECONDARY_FILE}: {e}', file=sys.stderr)
+            print(text, file=sys.stderr, flush=True)
+        print(bounded_line(res), flush=True)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def north_star_128(sec):
+    """compact summary of the 7x3x128x128 entries of `secondary` for the stdout line (north_star: "throughput on synthetic
+    7x3x128x128 clips ... alongside the reference CPU path timed on the host cores (core count stated)")."""
+    by = {(e.get('workload'), e.get('precision'), e.get('clips_per_step'), e.get('hip_graphs')): e for e in sec if 'workload' in e}
+    one, eight, graph = by.get(('128', 'fp32', 1, False)), by.get(('128', 'fp32', 8, False)), by.get(('128', 'fp32', 8, True))
+    x3 = by.get(('128', 'f16x3', 1, False))
+    out = {'unit': 'frames/s', 'dtype': 'f32'}
+    if one:
+        out['clips_1'] = one['value']
+        out['frac_per_launch'] = one['roofline']['frac']
+        out['frac_wall'] = one['roofline'].get('frac_wall')
+        cb = one.get('cpu_baseline')
+        if cb:
+            out['cpu'] = cb['value']
+            out['cpu_cores'] = cb['cores']
+            out['speedup_vs_cpu'] = one['value'] / cb['value']
+    if eight:
+        out['clips_8'] = eight['value']
+        out['frac_wall_clips_8'] = eight['roofline'].get('frac_wall')
+    if graph:
+        out['clips_8_hipgraph'] = graph['value']
+    if x3:
+        out['clips_1_f16x3'] = x3['value']
+    return out
 
 
 def pipeline_e2e(dev, T, clips=6, workers=16, precision='fp32'):
@@ -579,12 +710,15 @@ def pipeline_e2e(dev, T, clips=6, workers=16, precision='fp32'):
         nrec = 0
         with FrameWriter(max_workers=workers) as writer:
             model.frame_writer = writer
-            it = iter(ClipPrefetcher(ds, range(len(ds)), dev))
-            data = next(it)                                   # clip 0 is the warm-up (first-use allocations, kernel attributes)
+            data = next(iter(ClipPrefetcher(ds, [0], dev)))   # clip 0 is the warm-up (first-use allocations, kernel attributes)
             with torch.no_grad():
                 model(test_mode=True, save_image=True, save_path=out_dir, **data)
             torch.cuda.synchronize()
+            writer.drain()                                    # the warm-up clip's PNG encodes must not overlap the timed loop
+            # the timed clips' loader starts INSIDE the timed window: the first clip's decode + H2D is fully exposed, as it is
+            # for the first clip of a real run
             t0 = time.perf_counter()
+            it = iter(ClipPrefetcher(ds, range(1, len(ds)), dev))
             stall, fwd, psnr, n = [], 0.0, [], 0
             while True:
                 a = time.perf_counter()
@@ -615,8 +749,9 @@ def pipeline_e2e(dev, T, clips=6, workers=16, precision='fp32'):
                 'seconds_metrics_and_uint8_d2h_and_submit': t_loop - fwd - sum(stall),
                 'dtype': DTYPE_TEXT[precision], 'png_workers': workers, 'pngs_written': pngs, 'psnr': float(sum(psnr) / max(len(psnr), 1)),
                 'seconds_writing_the_synthetic_tree_untimed': t_tree,
-                'note': 'clip 0 is an untimed warm-up; the loader thread works one clip ahead, so its decode + H2D are visible only where '
-                        'they exceed the previous clip\'s GPU time'}
+                'note': 'clip 0 is an untimed warm-up on its own loader; the timed clips\' loader is created inside the timed window (the first '
+                        'clip\'s decode + H2D is fully exposed); after that it works one clip ahead, so decode + H2D are visible only '
+                        'where they exceed the previous clip\'s GPU time'}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -654,7 +789,8 @@ def secondary_workloads(dev, T, no_cpu_baseline=False):
         r, m, a = measure(dev, sd_np, cfg, workload=sp['workload'], precision=sp['precision'], vsr=sp['vsr'],
                           clips=sp['clips'], graphs=sp.get('graphs', False), steps=sp['steps'], warmup=sp['warmup'], T=T,
                           crfs=sp.get('crfs'), kernel_events=sp.get('kernel_events', True))
-        e = {'name': sp['name'], 'metric': f'enhanced frames/sec ({w}x{h}, {T}-frame window)', 'value': r['value'],
+        e = {'name': sp['name'], 'workload': sp['workload'], 'precision': sp['precision'],
+             'metric': f'enhanced frames/sec ({w}x{h}, {T}-frame window)', 'value': r['value'],
              'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': sp['steps'], 'warmup': sp['warmup'],
              'dtype': DTYPE_TEXT[sp['precision']],
              'clips_per_step': sp['clips'], 'vsr_x4_heads': sp['vsr'], 'hip_graphs': sp.get('graphs', False),

@@ -277,7 +277,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                     typedef float f32x8 __attribute__((ext_vector_type(8)));
                     const f32x8 v = (__builtin_convertvector(ah, f32x8) + __builtin_convertvector(al, f32x8) * X3_INV) * pj;
                     ah = __builtin_convertvector(__builtin_elementwise_min(__builtin_elementwise_max(v, (f32x8)(-65504.f)), (f32x8)(65504.f)), h8);
-                    al = __builtin_convertvector((v - __builtin_convertvector(ah, f32x8)) * X3_SCALE, h8);
+                    // the low part saturates like the high one (to_h4 / f16x3_image_kernel): when |par * x| leaves fp16's range the
+                    // remainder would otherwise convert to inf and the MFMA to NaN
+                    const f32x8 rm = (v - __builtin_convertvector(ah, f32x8)) * X3_SCALE;
+                    al = __builtin_convertvector(__builtin_elementwise_min(__builtin_elementwise_max(rm, (f32x8)(-65504.f)), (f32x8)(65504.f)), h8);
                 }
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) acc_hi[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[j], acc_hi[j], 0, 0, 0);
@@ -463,6 +466,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         r.wsrc[0] = a.wsrc[lr_idx];
         r.act = 0;
         r.residual = nullptr;
+        r.dbg = nullptr;          // the fp32 tile kernel's trace is 16 u64 per TILE; pnp_conv3x3_f16x3_ex's buffer holds 8 per split block
         const int rc = launch_conv3x3(r, cfg, 1, stream);
         if (rc) return rc;
         have_partial = true;

@@ -105,11 +105,21 @@ class CompressedClipFolderDataset(_EvalMixin, torch.utils.data.Dataset):
     decode_workers = 8
 
     def _pool(self):
+        """the decode pool of THIS process: a forked DataLoader worker inherits the parent's executor object without its threads
+        (futures submitted to it would never complete), so the pool is keyed on the pid and re-created after a fork"""
+        import os
         pool = getattr(self, '_decode_pool', None)
-        if pool is None:
+        if pool is None or pool[0] != os.getpid():
             from concurrent.futures import ThreadPoolExecutor
-            pool = self._decode_pool = ThreadPoolExecutor(max_workers=self.decode_workers, thread_name_prefix='pnp-decode')
-        return pool
+            pool = self._decode_pool = (os.getpid(), ThreadPoolExecutor(max_workers=self.decode_workers,
+                                                                        thread_name_prefix='pnp-decode'))
+        return pool[1]
+
+    def __getstate__(self):
+        """picklable for spawn-started DataLoader workers: the executor stays behind"""
+        state = dict(self.__dict__)
+        state.pop('_decode_pool', None)
+        return state
 
     def _read_clip(self, idx):
         """host side of one clip: uint8 HWC frames, side info and raw MV records (files decoded in parallel)"""

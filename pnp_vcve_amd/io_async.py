@@ -54,8 +54,8 @@ class FrameWriter:
             self._futures.append(fut)
         return fut
 
-    def close(self):
-        """Wait for every queued frame; raise the first failure."""
+    def drain(self):
+        """Wait for every frame queued so far (the pool stays usable); raise the first failure."""
         with self._lock:
             futs, self._futures = self._futures, []
         err = None
@@ -64,9 +64,15 @@ class FrameWriter:
                 f.result()
             except BaseException as e:      # noqa: BLE001 -- surfaced to the caller below
                 err = err or e
-        self._pool.shutdown(wait=True)
         if err is not None:
             raise err
+
+    def close(self):
+        """Wait for every queued frame; raise the first failure."""
+        try:
+            self.drain()
+        finally:
+            self._pool.shutdown(wait=True)
 
     def __enter__(self):
         return self

@@ -148,11 +148,13 @@ def state_dict_schema(cfg=None):
     return sch
 
 
-def make_state_dict(cfg=None, seed=0, par_gain=1.0):
+def make_state_dict(cfg=None, seed=0, par_gain=1.0, caa_gain=1.0):
     """Seeded "trained-like" weights: magnitudes follow the reference's
     initialisers but biases are non-zero and the 1x1
     partition branches are scaled by `par_gain` so that every term of the
-    block is numerically visible in a parity check."""
+    block is numerically visible in a parity check.  `caa_gain` scales the
+    weights of the expert-routing predictor (Base_Predictor), i.e. how strongly
+    the expert mixture follows the base QP; 1.0 leaves every earlier fixture as it was."""
     sch = state_dict_schema(cfg)
     sd = {}
     for name, shape in sch.items():
@@ -174,6 +176,8 @@ def make_state_dict(cfg=None, seed=0, par_gain=1.0):
         else:                                     # torch default: U(-1/sqrt(fan_in), +)
             b = 1.0 / np.sqrt(fan_in)
             sd[name] = uniform(seed, name, shape, -b, b)
+            if caa_gain != 1.0 and name.startswith('BasePredictor.') and name.endswith('.weight'):
+                sd[name] = (sd[name] * np.float32(caa_gain)).astype(np.float32)
     return sd
 
 

@@ -61,6 +61,10 @@ GEN_CASES = [
          clip=dict(seed=120, n=1, t=3, h=64, w=64, slices='allP', qp_mode='qp', crf=25)),
     dict(name='gen_t9_two_keys_64x64', cfg=dict(num_blocks=2), wseed=30, par_gain=10.0,
          clip=dict(seed=121, n=1, t=9, h=64, w=64, slices=[73, 66, 66, 80, 66, 66, 66, 80, 66], qp_mode='qp', crf=25)),
+    # r04: the x4 heads with every ingredient visible at >= 1e-3 (gen_vsr_*'s par->0 / base*2 moved the output by less
+    # than the old 1e-4 gate): partition branches x100, expert routing x30 -> par->0 2.2e-3, base*2 1.2e-3, allkey 3.3e-3, mvs->0 5e-3
+    dict(name='gen_vsr_gain_64x64', cfg=dict(vsr=True), wseed=33, par_gain=100.0, caa_gain=30.0,
+         clip=dict(seed=122, n=1, t=3, h=64, w=64, slices=[73, 66, 80], qp_mode='qp', crf=25)),
     # sparse_val=True (eval-time sparse evaluation of the 1x1 branches): maps with NON-binary values and overlapping
     # planes, so that "nonzero -> 1/255, later plane wins" is visible (a one-hot/255 map would equal the dense path)
     dict(name='gen_sparse_val_64x64', cfg=dict(sparse_val=True), wseed=25, par_gain=10.0, par_kind='overlap',
@@ -85,7 +89,7 @@ def gen_case_inputs(case):
     """-> (cfg, state-dict (numpy), clip dict (numpy))."""
     cfg = dict(syn.DEFAULT_GENERATOR_CFG)
     cfg.update(case['cfg'])
-    sd = syn.make_state_dict(cfg, seed=case['wseed'], par_gain=case.get('par_gain', 1.0))
+    sd = syn.make_state_dict(cfg, seed=case['wseed'], par_gain=case.get('par_gain', 1.0), caa_gain=case.get('caa_gain', 1.0))
     clip = syn.make_clip(**case['clip'])
     if case.get('par_kind') == 'overlap':
         clip['partitions'] = overlap_par(case['clip']['seed'], clip['partitions'].shape)

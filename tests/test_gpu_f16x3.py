@@ -16,7 +16,7 @@ from oracle import cpu_ref
 pytestmark = pytest.mark.gpu
 
 TOL_CONV = 2e-5       # tests/test_gpu_ops.py's tolerance for the exact-fp32 MFMA conv
-TOL_PATH = 1e-4       # tests/test_gpu_generator.py's tolerance for the exact-fp32 path (north_star: 1e-3)
+TOL_PATH = 5e-6       # tests/test_gpu_generator.py's tolerance for the exact-fp32 path (north_star: 1e-3; observed 1.2-1.8e-7)
 
 
 def dev():

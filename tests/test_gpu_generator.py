@@ -9,7 +9,11 @@ from oracle import cpu_ref
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4      # north_star gate is 1e-3 on enhanced frames; the fp32 MFMA path is held to 1e-4
+# north_star's gate is 1e-3 on enhanced frames.  The exact-fp32 path and the split-fp16 path deliver 1.2-1.8e-7 on every golden
+# case; they are held to 5e-6, i.e. at least 8x below the smallest effect any ingredient has on any golden case in which it acts
+# (tests/golden/manifest.json 'sensitivity': min 4.1e-5 = base*2 on gen_vsr_nocat_e4_64x64), so a build that ignored an input in
+# one configuration cannot pass that configuration's golden.
+TOL = 5e-6
 
 
 def dev():
@@ -576,33 +580,30 @@ def test_lr180_split_fp16_vs_oracle(vsr):
     assert not torch.equal(o32, out) and float((o32 - ref).abs().max()) < TOL
 
 
-def test_720p_clip_split_fp16_directly_vs_oracle():
-    """The 720p clip of the test below in split fp16: 7200 tiles on 512 persistent blocks, against the pinned oracle itself."""
+def _headline_clip():
+    """BASELINE configs[2] itself: 7 x 3 x 720 x 1280, IBBBP cadence (I B B B P B B) -- every source pattern of the input conv occurs
+    on the persistent-kernel size: sequence ends (zero neighbour), neighbour == key frame (one warped source, summed weights),
+    neighbour != key frame (4-source conv with the unwarped neighbour; iconvsr_ipb_par.py:86-90,121-125)."""
     cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
     sd_np = gu.syn.make_state_dict(cfg, seed=404, par_gain=10.0)
-    clip = gu.syn.make_clip(seed=4040, n=1, t=2, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, par_classes=3)
+    clip = gu.syn.make_clip(seed=4040, n=1, t=7, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, par_classes=3)
+    return cfg, sd_np, clip
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_720p_headline_clip_t7_vs_oracle(precision):
+    """The headline workload -- the whole 7-frame 720p clip, not a 2-frame sample and not a crop -- against the pinned oracle
+    (iconvsr_ipb_par.py:71-147), exact fp32 and split fp16, at the golden tolerance.  About 2 minutes of CPU on the box's host
+    cores, once: both precisions share the oracle's result."""
+    cfg, sd_np, clip = _headline_clip()
     m = build(cfg, sd_np)
-    m.precision = 'f16x3'
+    m.precision = precision
     out = run(m, clip).cpu()
-    ref = _oracle(cfg, sd_np, clip, key='p720_404_4040')
+    ref = _oracle(cfg, sd_np, clip, key='p720_t7_404_4040')
     d = float((out - ref).abs().max())
-    print('720p T=2 split fp16 max|hip - oracle| =', d)
-    assert d < TOL
-    gt = torch.from_numpy(clip['gt'])
-    assert abs(cpu_ref.clip_psnr(out, gt) - cpu_ref.clip_psnr(ref, gt)) < 1e-3
-
-
-def test_720p_clip_directly_vs_oracle():
-    """The headline path itself (persistent strip kernel, 8x16 tiles, 720p) against the pinned oracle on a whole 2-frame
-    clip -- not through a crop (about 40 s of CPU)."""
-    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)
-    sd_np = gu.syn.make_state_dict(cfg, seed=404, par_gain=10.0)
-    clip = gu.syn.make_clip(seed=4040, n=1, t=2, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, par_classes=3)
-    out = run(build(cfg, sd_np), clip).cpu()
-    ref = _oracle(cfg, sd_np, clip, key='p720_404_4040')
-    d = float((out - ref).abs().max())
-    print('720p T=2 max|hip - oracle| =', d)
-    assert d < TOL
+    per_frame = [float((out[0, i] - ref[0, i]).abs().max()) for i in range(7)]
+    print(f'720p T=7 {precision} max|hip - oracle| = {d:.3e}; per frame', ' '.join(f'{v:.1e}' for v in per_frame))
+    assert out.shape == (1, 7, 3, 720, 1280) and d < TOL
     gt = torch.from_numpy(clip['gt'])
     assert abs(cpu_ref.clip_psnr(out, gt) - cpu_ref.clip_psnr(ref, gt)) < 1e-3
 

@@ -5,6 +5,7 @@ import sys
 
 import numpy as np
 import pytest
+from bench_util import bench_line
 import torch
 
 from oracle import cpu_ref
@@ -124,16 +125,13 @@ def test_bench_emits_the_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', '128', '--frames', '3',
                           '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity'):
+    d = bench_line(out.stdout)
+    for k in ('roofline', 'cpu_baseline', 'parity'):
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['dtype'] == 'f32' and d['vs_baseline'] is None
-    assert d['value'] > 0 and abs(d['value'] - 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    assert d['value'] > 0 and abs(d['value'] - 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-4 * d['value']
     r = d['roofline']
-    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-5
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0
     assert d['parity']['max_abs_diff_vs_cpu'] < d['parity']['gate']
@@ -150,33 +148,45 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', '128', '--frames', '3',
                           '--steps', '2', '--warmup', '1'], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = bench_line(out.stdout)
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'clip-sharded replicas x2'
     assert len(d['frames_per_s_per_rank']) == 2 and len(d['psnr_per_rank']) == 2
     assert d['psnr_per_rank'][0] != d['psnr_per_rank'][1]            # rank r ran clip r of the synthetic set
     assert 'roofline' in d and 'cpu_baseline' not in d              # the CPU baseline is an N = 1 leg
     # whole-job rate = all ranks' frames over the slowest rank's time
-    assert abs(d['value'] - 2 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    assert abs(d['value'] - 2 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-4 * d['value']
 
 
-def test_bench_headline_line_carries_the_secondary_workloads():
-    """the default (720p fp32) line also measures the other BASELINE workloads in `secondary` and the dense-partition
-    figure next to the roofline (kept short: 1 step, no CPU baseline)."""
+def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_file():
+    """the default (720p fp32) run: stdout is ONE strict-JSON line under 4 KB with roofline / cpu-free blocks (round 3's 21 KB line
+    was truncated by the driver and never parsed); the other BASELINE workloads are measured too but land in bench_secondary.json
+    beside bench.py (kept short: 1 step, no CPU baseline)."""
     import json
+    side = os.path.join(ROOT, 'bench_secondary.json')
+    if os.path.exists(side):
+        os.remove(side)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    d = bench_line(out.stdout)
     assert d['metric'].startswith('enhanced frames/sec (1280x720') and d['dtype'] == 'f32'
     r = d['roofline']
     # frac prices EXECUTED FLOPs; algorithmic_frac (the dense reference count) can only be larger; on a dense partition map
     # nothing is skipped, so the dense-map figure is an executed figure too
-    assert 0 < r['frac'] <= r['algorithmic_frac'] and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert 0 < r['frac_dense_par'] <= r['algorithmic_frac'] * 1.02
+    assert r['bound'] == 'mfma' and r['kernel'].startswith('conv3x3_persist_kernel')
+    assert 0 < r['frac'] <= r['algorithmic_frac'] and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-5
+    assert 0 < r['frac_dense_par'] <= r['algorithmic_frac'] * 1.02 and 0 < r['frac_wall'] <= r['algorithmic_frac'] * 1.02
+    assert d['roofline_mv_warp']['bound'] == 'hbm' and d['roofline_mv_warp']['frac'] > 0
     assert 'U{0,1,2}' in d['config']['workload']
-    sec = d['secondary']
+    ns = d['north_star_128']
+    assert ns['clips_1'] > 0 and ns['clips_8'] > 0 and ns['clips_8_hipgraph'] > 0 and 0 < ns['frac_per_launch'] < 1
+    assert 'cpu' not in ns                                      # --no-cpu-baseline covers the 128x128 CPU leg too
+    assert d['secondary_file'] == 'bench_secondary.json'
+    with open(side) as fh:
+        full = json.load(fh, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert full['value'] == d['value'] or abs(full['value'] - d['value']) < 1e-4 * d['value']
+    assert 'definition' in full['roofline'] and 'device_ms_per_step' in full['roofline']      # the prose lives here, not on stdout
+    sec = full['secondary']
     assert len(sec) == 9
     e2e = sec[8]                                   # the whole tools/test.py loop on an on-disk tree
     assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
@@ -184,7 +194,17 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     for e in sec[:8]:
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
-            assert e['roofline']['frac'] > 0 and e['launches_per_frame'] > 0
+            rf = e['roofline']
+            assert rf['frac'] > 0 and rf['frac_wall'] > 0 and e['launches_per_frame'] > 0
+            dom = max(rf['device_ms_per_step'].values())
+            if e['clips_per_step'] == 1:
+                # one clip = one stream: launches run back to back, so device time of any kind fits inside the step
+                assert dom <= e['ms_per_step'] * 1.02, e['name']
+                assert 'per_launch_frac' not in rf
+            else:
+                # concurrent clips: achieved / frac ARE the wall-clock figures, reproducible from the entry's own numbers
+                assert abs(rf['frac'] - rf['frac_wall']) < 1e-12 and rf['per_launch_frac'] > 0
+                assert abs(rf['achieved'] - rf['achieved_wall']) < 1e-9
     assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm' and sec[5]['roofline']['bound'] == 'hbm'
     assert sec[2]['hip_graphs'] is True and sec[6]['vsr_x4_heads'] is True
     assert sec[3]['value'] > 3 * d['value']       # fp16 operands at the headline shape: > 3x the fp32 rate
@@ -195,6 +215,7 @@ def test_bench_headline_line_carries_the_secondary_workloads():
     assert abs(x3['psnr'] - d['psnr_per_rank'][0]) < 1e-3      # same clip, same weights: the fp32 headline's PSNR
     assert sec[7]['dtype'].startswith('split f16') and sec[7]['roofline']['bound'] == 'mfma' and abs(sec[7]['psnr'] - sec[0]['psnr']) < 1e-3
     assert all('cpu_baseline' not in e for e in sec)          # --no-cpu-baseline covers the secondary entries too
+    assert abs(ns['clips_1'] - sec[0]['value']) < 1e-4 * ns['clips_1'] and abs(ns['clips_8'] - sec[1]['value']) < 1e-4 * ns['clips_8']
 
 
 def test_evaluate_refuses_a_batch_instead_of_scoring_sample_zero():
@@ -220,7 +241,7 @@ def test_bench_deform_basic_reports_the_dcn_roofline(precision):
                           '--warmup', '1', '--deform', 'basic', '--precision', precision, '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    d = bench_line(out.stdout)
     r = d['roofline_dcn']
     assert d['config']['deform'] == 'basic' and r['bound'] == 'hbm' and r['launches'] == 2 * 4       # 4 alignments per 3-frame clip
     assert abs(r['algorithmic_bytes_per_launch'] - 2240 * 128 * 128) < 1 and r['frac'] > 0
@@ -251,18 +272,18 @@ def test_bench_rank_path_runs_over_rccl_at_world_size_1():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', '128', '--frames', '3', '--steps', '2',
                           '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=_rank_env())
     assert out.returncode == 0, out.stdout + out.stderr
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    d = bench_line(out.stdout)
     assert d['n_gpus'] == 1 and d['dist']['process_group'] is True and d['dist']['backend'] == 'nccl'
     assert d['dist']['rccl_version'] and d['dist']['collectives'] == ['barrier', 'all_reduce(MAX)', 'all_gather', 'barrier']
     assert len(d['frames_per_s_per_rank']) == 1 and d['frames_per_s_per_rank'][0] > 0
-    assert abs(d['value'] - 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    assert abs(d['value'] - 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-4 * d['value']
     # without the environment the same command creates no process group
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', '128', '--frames', '3', '--steps', '1',
                           '--warmup', '1', '--no-cpu-baseline', '--no-kernel-events'], capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    d = bench_line(out.stdout)
     assert d['dist'] == {'process_group': False, 'backend': None, 'rccl_version': None, 'collectives': []}
 
 
@@ -342,13 +363,11 @@ def test_bench_gpus_8_launches_eight_ranks():
                           '--steps', '2', '--warmup', '1', '--no-kernel-events'], capture_output=True, text=True, timeout=1500,
                          env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = bench_line(out.stdout)
     assert d['n_gpus'] == 8 and d['config']['parallelism'] == 'clip-sharded replicas x8' and d['scaling'] == 'weak'
     assert len(d['frames_per_s_per_rank']) == 8 and len(set(d['psnr_per_rank'])) == 8      # rank r ran clip r
     assert d['dist']['process_group'] is True and d['dist']['backend'] == 'gloo'
-    assert abs(d['value'] - 8 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    assert abs(d['value'] - 8 * 2 * 3 / (d['ms_per_step'] * 2e-3)) < 1e-4 * d['value']
     assert 'cpu_baseline' not in d and 'secondary' not in d
     # rc propagation: an argument the ranks reject makes every rank exit non-zero -> the launcher does too
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', '128', '--frames', '0'],

@@ -50,6 +50,15 @@ def main():
     cfg = Config.fromfile(args.config)
     if args.cfg_options:
         cfg.merge_from_dict(parse_cfg_options(args.cfg_options))
+    # One arithmetic per run.  `--fp16` / `fp16 = dict(...)` in the config (the mmcv idiom) IS precision 'fp16'; a command line
+    # switch overrides the config; two switches that disagree are an error instead of the last one silently winning.
+    cli = {p for p in (args.precision, 'fp16' if args.fp16 else None) if p is not None}
+    if len(cli) > 1:
+        raise SystemExit(f'tools/test.py: --fp16 contradicts --precision {args.precision}')
+    conf = {p for p in (cfg.get('precision', None), 'fp16' if cfg.get('fp16', None) is not None else None) if p is not None}
+    if not cli and len(conf) > 1:
+        raise SystemExit(f"tools/test.py: the config sets fp16 = dict(...) and precision = {cfg.get('precision')!r}")
+    precision = next(iter(cli or conf), None)
     if args.launcher != 'none':
         init_dist(args.launcher, **cfg.dist_params)
     rank, world = get_dist_info()
@@ -68,11 +77,10 @@ def main():
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     model = model.to(dev)          # no DDP wrap: inference replicas share nothing
-    if cfg.get('fp16', None) is not None or args.fp16:      # mmcv idiom: `fp16 = dict(...)` in the config
+    if precision == 'fp16':
         from pnp_vcve_amd.restorer import wrap_fp16_model
         wrap_fp16_model(model)
-    precision = args.precision or cfg.get('precision', None)
-    if precision is not None:
+    elif precision is not None:
         model.precision = precision
     if args.save_path is not None:      # PNG encode off the critical path (pnp_vcve_amd/io_async.py)
         from pnp_vcve_amd.io_async import FrameWriter
