@@ -471,11 +471,15 @@ def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, 
     if events_inside:
         m.profile(True)
     out, elapsed, elapsed_max = timed_steps(step, steps, dist, cdev)
+    ms_events_pass = None
     if kernel_events and not events_inside:
         m.profile(True)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
+        ms_events_pass = 1e3 * (time.perf_counter() - te) / steps      # the wall time the per-launch durations below add up inside
     prof = m.profile_read() if kernel_events else None
     m.profile(False)
     dense_prof = None
@@ -499,6 +503,7 @@ def measure(dev, sd_np, cfg, *, workload, precision, vsr, clips, graphs, steps, 
            'elapsed_rank': elapsed, 'psnr_rank': psnr, 'frames_per_s_rank': frames_rank / elapsed,
            'kernel_events': ('none' if not kernel_events else 'inside the timed region' if events_inside
                              else 'separate pass of the same steps after the timed region'),
+           'ms_per_step_events_pass': ms_events_pass,
            'launches_per_frame': (sum(v['launches'] for v in prof.values()) / (steps * T * clips)) if prof else None}
     if prof is not None:
         ptag = {'fp32': '', 'fp16': 'fp16_', 'f16x3': 'f16x3_'}[precision]
@@ -794,7 +799,7 @@ def secondary_workloads(dev, T, no_cpu_baseline=False):
              'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': sp['steps'], 'warmup': sp['warmup'],
              'dtype': DTYPE_TEXT[sp['precision']],
              'clips_per_step': sp['clips'], 'vsr_x4_heads': sp['vsr'], 'hip_graphs': sp.get('graphs', False),
-             'kernel_events': r['kernel_events'],
+             'kernel_events': r['kernel_events'], 'ms_per_step_events_pass': r['ms_per_step_events_pass'],
              'launches_per_frame': r['launches_per_frame'], 'psnr': r['psnr_rank']}
         for k in ('roofline', 'roofline_mv_warp'):
             if k in r:

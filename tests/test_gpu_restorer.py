@@ -198,8 +198,9 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
             assert rf['frac'] > 0 and rf['frac_wall'] > 0 and e['launches_per_frame'] > 0
             dom = max(rf['device_ms_per_step'].values())
             if e['clips_per_step'] == 1:
-                # one clip = one stream: launches run back to back, so device time of any kind fits inside the step
-                assert dom <= e['ms_per_step'] * 1.02, e['name']
+                # one clip = one stream: launches run back to back, so the device time of any kind fits inside the wall time of
+                # the pass the events were taken in (below 720p a separate pass: two events per few-us launch slow it down)
+                assert dom <= (e['ms_per_step_events_pass'] or e['ms_per_step']) * 1.02, e['name']
                 assert 'per_launch_frac' not in rf
             else:
                 # concurrent clips: achieved / frac ARE the wall-clock figures, reproducible from the entry's own numbers
