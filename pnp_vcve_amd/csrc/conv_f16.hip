@@ -41,6 +41,21 @@
 #include <mutex>
 #include <type_traits>
 
+// The fragment reads a k-step issues (for a k-step DEPTH ahead) are DEALT into its MFMA gaps instead of trailing the MFMAs as a
+// burst: a wave issues in order, a 1-KiB ds_read_b128 holds its issue slot for ~16 cycles, and in the matrix phase of these kernels
+// there is ONE wave per SIMD -- with the burst it ran 60 cycles per MFMA at 1.5 reads per MFMA (what r03 took for a structural
+// limit), with the reads inside the gaps 33.5 (tools/ubench/ub_mfma_issue.hip, profiles/r04_ub_mfma_issue.txt).
+#define F16_DEAL_READS(NT_)                                                         \
+    if ((NT_) == 2) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+    } else {                                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                          \
+    }
+
 namespace {
 
 constexpr int B_BYTES = 9 * 4 * 2 * UNIT;         // 73728
@@ -422,6 +437,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                     if (NT == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[NT - 1], 0, 0, 0);
                     if (k + DEPTH < NS) fetch(k + DEPTH);
                     else if (PAR && br0 >= 0) fetch_par(br0, k + DEPTH - NS);
+                    F16_DEAL_READS(NT)
                     if (k == MID) __builtin_amdgcn_s_barrier();         // the phase's middle barrier (no LDS hand-off here)
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -440,6 +456,7 @@ __global__ __launch_bounds__(512) void conv3x3_f16_kernel(const F16Args a) {
                             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[0], 0, 0, 0);
                             acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[NT - 1], 0, 0, 0);
                             if (nxt >= 0) fetch_par(nxt, q);
+                            F16_DEAL_READS(2)
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -783,6 +800,7 @@ __global__ __launch_bounds__(256 * G, G == 1 ? 3 : 4) void conv3x3_f16_small_ker
 #pragma unroll
                 for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (tt + NT_ * i) * 16) = wreg[c & 1][i];
             }
+            F16_DEAL_READS(2)
             __builtin_amdgcn_sched_barrier(0);
         }
         // the ring write above is older than the 6 fragment reads of k-steps 2 and 3: wait for it, not for them

@@ -57,7 +57,12 @@ struct X3Args {
 template <bool PAR, bool DBG, bool S4>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     constexpr int NC = 18 + (PAR ? 6 : 0);                   // chunks: two k-halves per tap, then two per partition branch
-    constexpr int NSET = 4;                                  // register sets of weight chunks (chunk c travels in set c % 4)
+    // register sets of weight chunks (chunk c travels in set c % NSET, requested NSET chunks ahead, written to the ring two ahead).
+    constexpr int NSET = 4;
+    // DEAL: the next k-step's fragment reads go one into each MFMA gap of this k-step instead of as a burst in front of it (see
+    // the K loop).  Not for the branch variant: its VALU work leaves no registers for the longer live ranges (8-13 spills and a
+    // longer epilogue, measured: front half 31.7 k -> 35.5 k cycles per tile), so it keeps the burst.
+    constexpr bool DEAL = !PAR;
     constexpr int WPT = 2;
     constexpr int THX = S4 ? 4 : TH, ROWS = THX + 2, ABY = ROWS * RSB;      // tile rows, halo rows, bytes of one fp16 A tile
     constexpr int NTW = S4 ? 1 : 2;                          // 32-channel N tiles per wave
@@ -158,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             wreg[c % NSET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c < 18 ? r_w : r_wp, t * 16, so, 0));
         }
     };
-    auto request_first_chunks = [&]() {                     // chunks 0..3 of a tile: the same images for every tile
+    auto request_first_chunks = [&]() {                     // chunks 0..NSET-1 of a tile: the same images for every tile
 #pragma unroll
-        for (int c = 0; c < 4; ++c) request_chunk(c);
+        for (int c = 0; c < NSET; ++c) request_chunk(c);
     };
     request_tile(tile, true);
     request_first_chunks();
@@ -172,11 +177,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         // ---- fp32 halo -> the two fp16 A tiles: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048); chunks 0, 1 -> ring
 #pragma unroll
         for (int k = 0; k < NREQ; ++k) {
-            const h4 hi = to_h4(areg[k]);
-            const f32x4 rem = (areg[k] - __builtin_convertvector(hi, f32x4)) * X3_SCALE;
+            // x saturates at +-65504 as a WHOLE: the remainder is taken from the clamped value, so it is at most half an fp16 ulp
+            // (<= 16) and its scaled form (<= 32768) needs no clamp of its own; in-range values are untouched
+            const f32x4 xc = clamp_h(areg[k]);
+            const h4 hi = __builtin_convertvector(xc, h4);
             char* d = k < ROWS ? l_main + k * RSB : (S4 ? l_side6 : (k == ROWS ? l_side : l_side11));
             *reinterpret_cast<h4*>(d) = hi;
-            *reinterpret_cast<h4*>(d + ABY) = to_h4(rem);
+            *reinterpret_cast<h4*>(d + ABY) = __builtin_convertvector((xc - __builtin_convertvector(hi, f32x4)) * X3_SCALE, h4);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -229,9 +236,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             const char* b_lane = sR + (c % X3_RING) * X3_CHUNK + lane * 16;
             Frag f;
             f.ah = *reinterpret_cast<const h8*>(smem + o);
-            f.al = *reinterpret_cast<const h8*>(smem + ABY + o);
+            if (!DEAL) f.al = *reinterpret_cast<const h8*>(smem + ABY + o);
 #pragma unroll
-            for (int u = 0; u < 2 * NTW; ++u)     // chunk units per k-step: [hi N0, hi N1, lo N0, lo N1]
+            for (int u = 0; u < NTW; ++u)         // chunk units per k-step: [hi N0, hi N1, lo N0, lo N1]
+                f.b[u] = *reinterpret_cast<const h8*>(b_lane + (s2 * 4 + (S4 ? 2 * u + wn : u)) * UNIT);
+            if (DEAL) f.al = *reinterpret_cast<const h8*>(smem + ABY + o);     // dealt reads: in the order of first use
+#pragma unroll
+            for (int u = NTW; u < 2 * NTW; ++u)
                 f.b[u] = *reinterpret_cast<const h8*>(b_lane + (s2 * 4 + (S4 ? 2 * u + wn : u)) * UNIT);
             return f;
         };
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (PAR && c >= 18 && c >= ncr) break;
-            if (c + 4 < NC && (!PAR || c + 4 < ncr)) request_chunk(c + 4);
+            if (c + NSET < NC && (!PAR || c + NSET < ncr)) request_chunk(c + NSET);
             // After the last 3x3 chunk request (chunk 17, at the top of chunk 13): memory returns in order, so a tile-data request
             // (HBM, ~2.5 us) ahead of a weight chunk (L2) would hold the chunk back.  Residual rows / partial sums of THIS tile first
             // (the epilogue needs them), then -- once two more register sets have gone to the ring -- the halo of the NEXT tile,
@@ -269,18 +280,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                 Frag nf;
                 if (s2 == 0) nf = load_frag(c, 1);
                 else if (c + 1 < NC) nf = load_frag(c + 1, 0);
-                __builtin_amdgcn_sched_barrier(0);          // the reads stay AHEAD of the MFMAs (the scheduler would sink them to their use)
+                if (!DEAL) __builtin_amdgcn_sched_barrier(0);          // burst form: the reads stay AHEAD of the MFMAs
                 h8 ah = fr.ah, al = fr.al;
                 if (PAR && c >= 18) {
                     // par_j(pixel) * x as a split number again: (hi + lo / 2048) is exact in fp32 (22 bits), one fp32 rounding
                     // for the product, then the same split as the halo
                     typedef float f32x8 __attribute__((ext_vector_type(8)));
-                    const f32x8 v = (__builtin_convertvector(ah, f32x8) + __builtin_convertvector(al, f32x8) * X3_INV) * pj;
-                    ah = __builtin_convertvector(__builtin_elementwise_min(__builtin_elementwise_max(v, (f32x8)(-65504.f)), (f32x8)(65504.f)), h8);
-                    // the low part saturates like the high one (to_h4 / f16x3_image_kernel): when |par * x| leaves fp16's range the
-                    // remainder would otherwise convert to inf and the MFMA to NaN
-                    const f32x8 rm = (v - __builtin_convertvector(ah, f32x8)) * X3_SCALE;
-                    al = __builtin_convertvector(__builtin_elementwise_min(__builtin_elementwise_max(rm, (f32x8)(-65504.f)), (f32x8)(65504.f)), h8);
+                    f32x8 v = (__builtin_convertvector(ah, f32x8) + __builtin_convertvector(al, f32x8) * X3_INV) * pj;
+                    // saturates as a whole like the halo split (the remainder of the CLAMPED product fits fp16 by construction)
+                    v = __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x8)(-65504.f)), (f32x8)(65504.f));
+                    ah = __builtin_convertvector(v, h8);
+                    al = __builtin_convertvector((v - __builtin_convertvector(ah, f32x8)) * X3_SCALE, h8);
                 }
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) acc_hi[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[j], acc_hi[j], 0, 0, 0);
@@ -295,6 +305,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
 #pragma unroll
                     for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[(c + 2) % NSET][i];
                 }
+                // The NEXT k-step's fragment reads are DEALT into this k-step's MFMA gaps, one per gap, together with whatever the
+                // chunk requests from memory (weights four chunks ahead, the residual rows, the next halo) and the ring write.  A
+                // wave issues in order: a burst of six 1-KiB reads in front of six MFMAs holds the wave's issue slot for ~96 cycles
+                // in which only a partner wave can feed the matrix pipe (a lone wave then runs 48-60 cycles per MFMA: what r03 took
+                // for a structural limit); one read per gap hides inside the MFMA's own 32 cycles -- 33.0-33.5 cycles per MFMA for
+                // a lone wave at up to 1.5 reads per MFMA, 32.6 per SIMD for two (tools/ubench/ub_mfma_issue.hip,
+                // profiles/r04_ub_mfma_issue.txt).  Reads are issued in the order of their first use (load_frag).
+#define X3_GAP(NREAD, NVMEM, NWRITE)                                                          \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                \
+                __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  /* fragment read(s) */        \
+                __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);  /* memory requests */         \
+                if (NWRITE) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   /* ring write */
+                if (!DEAL) {
+                } else if (S4) {            // 3 MFMAs, 4 reads
+                    X3_GAP(2, 4, 0) X3_GAP(1, 4, 1) X3_GAP(1, 4, 1)
+                } else {                    // 6 MFMAs, 6 reads
+                    X3_GAP(1, 2, 0) X3_GAP(1, 2, 0) X3_GAP(1, 2, 0) X3_GAP(1, 2, 0) X3_GAP(1, 2, 1) X3_GAP(1, 2, 1)
+                }
+#undef X3_GAP
                 __builtin_amdgcn_sched_barrier(0);
                 if (s2 == 0 || c + 1 < NC) fr = nf;
             }
@@ -366,8 +395,9 @@ __global__ __launch_bounds__(256) void f16x3_image_kernel(const float* __restric
     const int n = lane & 31, hh = lane >> 5;
     const int k = 16 * s + 8 * hh + j;
     const float v = src[chunk * per_chunk + (((k >> 3) * 2 + nt) * 64 + ((k >> 2) & 1) * 32 + n) * 4 + (k & 3)];
-    const _Float16 hi = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-    const _Float16 lo = (_Float16)fminf(fmaxf((v - (float)hi) * X3_SCALE, -65504.f), 65504.f);
+    const float vc = fminf(fmaxf(v, -65504.f), 65504.f);         // saturates as a whole (see the halo split)
+    const _Float16 hi = (_Float16)vc;
+    const _Float16 lo = (_Float16)((vc - (float)hi) * X3_SCALE);
     _Float16* d = dst + chunk * (2 * per_chunk) + (s >> 1) * per_chunk + ((s & 1) * 4 + nt) * 512 + lane * 8 + j;
     d[0] = hi;
     d[2 * 512] = lo;

@@ -37,6 +37,9 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
 }
 
+__device__ __forceinline__ f32x4 clamp_h(f32x4 v) {       // to fp16's finite range
+    return __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x4)(-65504.f)), (f32x4)(65504.f));
+}
 __device__ __forceinline__ h4 to_h4(f32x4 v) {
     // saturate instead of overflowing to inf (a single out-of-range activation would poison the frame)
     v = __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x4)(-65504.f)), (f32x4)(65504.f));

@@ -276,3 +276,35 @@ def test_f16x3_full_width_720p_tracks_fp32():
     d = float((outs['fp32'] - outs['f16x3']).abs().max())
     print(f'720p: f16x3 vs fp32 max|d| {d:.3e}')
     assert 0 < d < TOL_PATH
+
+
+def test_f16x3_operands_saturate_instead_of_overflowing():
+    """include/pnpvcve.h: a value beyond fp16's range saturates at +-65504 AS A WHOLE (hi = 65504, lo = 0) instead of turning into
+    inf / NaN -- in the halo split, in the weight image and in the partition branch's re-split of par_j * x (the
+    remainder of the re-split was converted without a clamp and overflowed to inf -> NaN through the MFMA)."""
+    from pnp_vcve_amd import ops
+    h, w = 32, 48
+    x, wt, b, gam, w1, par = _front_half_inputs(38, h, w, 1.0)
+    x = x.copy()
+    x[0, 3, 9, 11] = 1e6                      # the activation itself is out of range
+    x[0, 5, 20, 30] = 3e4                     # in range, but par_j * x below is not
+    par = par * np.float32(8.0)
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    pg = G(par)
+    out = ops.conv3x3_f16x3([xs], [ops.pack_conv3x3(G(wt))], bias=G(b), gamma=G(gam),
+                            packed_w1x1=ops.pack_conv1x1([G(v) for v in w1]), par=pg, par_flags=ops.par_tile_flags(pg), act=0)
+    assert torch.isfinite(out).all()
+    # the same arithmetic in fp64 on the values the kernel is specified to see: x and par_j * x clamped to +-65504
+    xc = np.clip(x, -65504.0, 65504.0)
+    ref = F.conv2d(D(xc), D(wt), D(b), padding=1) * D(gam).view(1, 64, 1, 1)
+    for j in range(3):
+        pxc = torch.clamp(D(par[j]).view(1, 1, h, w) * D(xc), -65504.0, 65504.0)
+        ref = ref + F.conv2d(pxc, D(w1[j]))
+    got = ops.nhwc_to_nchw(out.unsqueeze(0)).cpu().double()
+    assert float((got - ref).abs().max()) < 1e-6 * float(ref.abs().max())
+    # an out-of-range weight saturates the same way
+    wbig = wt.copy()
+    wbig[7, 3, 1, 1] = -2e5
+    o2 = ops.conv3x3_f16x3([ops.nchw_to_nhwc(G(np.clip(x, -1, 1)))[0]], [ops.pack_conv3x3(G(wbig))], bias=G(b))
+    r2 = F.conv2d(D(np.clip(x, -1, 1)), D(np.clip(wbig, -65504.0, 65504.0)), D(b), padding=1)
+    assert torch.isfinite(o2).all() and float((ops.nhwc_to_nchw(o2.unsqueeze(0)).cpu().double() - r2).abs().max()) < 1e-6 * float(r2.abs().max())
