@@ -27,8 +27,7 @@ namespace {
 
 constexpr int X3_RING = 3;
 constexpr int X3_CHUNK = 8 * UNIT;                            // 4 k-steps x 2 N tiles
-constexpr int X3_LDS = 2 * A_BYTES + X3_RING * X3_CHUNK;      // 80,896
-static_assert(2 * X3_LDS <= 160 * 1024, "two blocks per CU");
+static_assert(2 * ((TH + 2) * PW * 288 + 256 + X3_RING * X3_CHUNK) <= 160 * 1024, "two blocks per CU");
 constexpr int X3_AIT = (NPIX * 16 + 255) / 256;               // 12 16-byte halo loads per thread (fp32 source)
 constexpr float X3_SCALE = 2048.f, X3_INV = 1.f / 2048.f;
 
@@ -51,24 +50,33 @@ struct X3Args {
 // Halo geometry: 10 rows x 18 pixels x 16 float4.  Requests 0..9: row k, pixels 0..15 (thread t: pixel t >> 4, float4 t & 15);
 // requests 10, 11: the two right-hand pixel columns (item j = t + 256 (k - 10): row j >> 5, pixel 16 + ((j >> 4) & 1)) -- so the
 // global offset and the LDS address of request k are one per-thread base plus k times a constant (no per-request registers).
-// S4: 4x16-pixel tiles for frames with at most 256 8x16 tiles (half the CUs would otherwise idle): the four
-// waves are 2 M tiles (pixel rows 2 wm, 2 wm + 1) x 2 N halves, a wave owns 32 pixels x 32 channels (one accumulator pair, four
-// fragment reads for three MFMAs per k-step); halo 6 rows = requests 0..5 + one side request (t < 192).
+// S4: 4x16-pixel tiles for frames with at most 256 8x16 tiles (half the CUs would otherwise idle): the four waves are 2 pixel-row
+// pairs x 2 N halves, a wave owns 32 pixels x 32 channels; halo 6 rows = requests 0..5 + one side request (t < 192).
+//
+// MFMA shape (r04): v_mfma_f32_16x16x32_f16.  The kernel is POWER-limited -- in r04's A/B 10 % fewer cycles per tile came back as
+// a 5 % lower clock -- and the clock the chip holds under this load depends on the shape: the same LDS-fed split loop sustains
+// 1.67 PFLOP/s at 1.70 GHz on 16x16x32 against 1.43 PFLOP/s at 1.50 GHz on 32x32x16 (tools/ubench/ub_shape16.hip,
+// profiles/r04_ub_shape16.txt: +17 %).  A wave's 32 pixels are two M tiles (its two pixel rows: MFMA row = pixel column), its
+// channels 16-wide N tiles; a chunk (tap, k-half) is ONE 32-deep k-step: 4 A fragments (2 rows x hi / lo) and per N tile a
+// (hi, lo) pair of B fragments for 6 MFMAs of 16 cycles -- the same 1 KiB of fragment reads per 32 matrix cycles as before.
+// LDS image of the halo: pixel = [64 ch hi | 64 ch lo | 32 B pad] = 288 B.  A lane group of a ds_read_b128 holds 8 pixels of
+// k-group g and the 8 other pixels of k-group g ^ 1 (16 B apart): with a pixel stride of 18 (any even number of) 16-B slots
+// the first set lands on the even slots and the second on the odd ones for every tap -- conflict-free; the 144-B stride of the
+// 32x32x16 image (one plane per pixel) cannot do that for any lane -> pixel mapping.
+constexpr int XPSB = 288, XRSB = PW * XPSB;                  // pixel / row stride of the split A tile
+constexpr int XPARK = 256;                                   // where idle lanes of the side requests put their (unused) halves
+
 template <bool PAR, bool DBG, bool S4>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     constexpr int NC = 18 + (PAR ? 6 : 0);                   // chunks: two k-halves per tap, then two per partition branch
     // register sets of weight chunks (chunk c travels in set c % NSET, requested NSET chunks ahead, written to the ring two ahead).
-    constexpr int NSET = 4;
-    // DEAL: the next k-step's fragment reads go one into each MFMA gap of this k-step instead of as a burst in front of it (see
-    // the K loop).  Not for the branch variant: its VALU work leaves no registers for the longer live ranges (8-13 spills and a
-    // longer epilogue, measured: front half 31.7 k -> 35.5 k cycles per tile), so it keeps the burst.
-    constexpr bool DEAL = !PAR;
+    constexpr int NSET = 4;                                  // (3 starves the ring: K loop 13.6 k -> 18.8 k cycles per tile)
     constexpr int WPT = 2;
-    constexpr int THX = S4 ? 4 : TH, ROWS = THX + 2, ABY = ROWS * RSB;      // tile rows, halo rows, bytes of one fp16 A tile
-    constexpr int NTW = S4 ? 1 : 2;                          // 32-channel N tiles per wave
+    constexpr int THX = S4 ? 4 : TH, ROWS = THX + 2, ABY = ROWS * XRSB + XPARK;     // tile rows, halo rows, bytes of the A tile
+    constexpr int NTW = S4 ? 2 : 4;                          // 16-channel N tiles per wave
     constexpr int NREQ = S4 ? ROWS + 1 : X3_AIT;             // 16-byte halo requests per thread
-    constexpr int CW = NTW * 8, PPI = 64 / CW, EIT = 32 / PPI;   // epilogue: float4 per pixel in the wave's N range, pixels per instruction
-    constexpr int RQR = 13, RQH = 15;                    // chunks at whose top the residual rows / the next halo are requested
+    constexpr int CW = NTW * 4, PPI = 64 / CW, EIT = 32 / PPI;   // epilogue: float4 per pixel in the wave's N range, pixels per instruction
+    constexpr int RQR = 13;                              // chunk at whose top the residual rows are requested
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned long long dbg_t0 = 0, dbg_p = 0, dbg_k = 0, dbg_e = 0;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         dbg_t0 = __builtin_amdgcn_s_memtime();
         dbg_r0 = __builtin_amdgcn_s_memrealtime();
     }
-    const int m = lane & 31, h = lane >> 5, my = m >> 4, mx = m & 15;
+    const int lm = lane & 15, lg = lane >> 4;                // MFMA row / column (pixel column, output channel) and k-group of the lane
     const int wrow = S4 ? wave >> 1 : wave, wn = S4 ? wave & 1 : 0;      // the wave's pixel-row pair and N half
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     const int band_hi = (int)((long)ntiles * (xcd + 1) / 8);
     int tile = (int)((long)ntiles * xcd / 8) + (blockIdx.x >> 3);
     if (tile >= band_hi) return;
-    char* const sR = smem + 2 * ABY;
+    char* const sR = smem + ABY;
 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
     const unsigned row_bytes = (unsigned)W * 256u;
@@ -105,39 +113,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     // 64-bit address pairs for the compiler to hoist out of the tile loop and spill
     const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.w, 18u * X3_CHUNK);
     const __amdgpu_buffer_rsrc_t r_wp = make_rsrc(PAR ? (const void*)a.wpar : (const void*)a.w, 6u * X3_CHUNK);
-    const int ec = lane % CW, ep = lane / CW, n0 = lane & 31;
+    const int ec = lane % CW, ep = lane / CW;
     const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     const float k_pre = a.res_pre ? 1.f : 0.f, k_post = 1.f - k_pre;
     float bco[NTW], gco[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        bco[j] = a.bias ? a.bias[(wn * NTW + j) * 32 + n0] : 0.f;
-        gco[j] = a.gamma ? a.gamma[(wn * NTW + j) * 32 + n0] : 1.f;
+    for (int j = 0; j < NTW; ++j) {                          // the lane's output channel in N tile j of the wave
+        bco[j] = a.bias ? a.bias[wn * 32 + j * 16 + lm] : 0.f;
+        gco[j] = a.gamma ? a.gamma[wn * 32 + j * 16 + lm] : 1.f;
     }
-    const int a_off = (2 * wrow + my) * RSB + mx * PSB + 16 * h;
+    const int a_off = 2 * wrow * XRSB + lm * XPSB + 16 * lg;         // + row r, tap (dy, dx), plane (128), k-half (64)
     // per-thread halo bases (see above)
     const int hp = t >> 4, hcs = t & 15;
     const int h2r = t >> 5, h2x = 16 + ((t >> 4) & 1);
     const unsigned g_main = (unsigned)hp * 256u + (unsigned)hcs * 16u;                       // + (row k) * row_bytes
     const unsigned g_side = (unsigned)h2r * row_bytes + (unsigned)h2x * 256u + (unsigned)hcs * 16u;   // + 8 rows for request 11
-    char* const l_main = smem + hp * PSB + hcs * 8;                                         // + k * RSB
-    // request 11 covers rows 8, 9 only (t < 64): the other threads park their (zero) value in the pad bytes of row 9
-    char* const l_side = smem + h2r * RSB + h2x * PSB + hcs * 8;
-    char* const l_park = smem + (ROWS - 1) * RSB + PW * PSB + hcs * 8;
-    char* const l_side11 = t < 64 ? l_side + 8 * RSB : l_park;
+    char* const l_main = smem + hp * XPSB + hcs * 8;                                        // + k * XRSB
+    // request 11 covers rows 8, 9 only (t < 64): the other threads park their (zero) value behind the tile
+    char* const l_side = smem + h2r * XRSB + h2x * XPSB + hcs * 8;
+    char* const l_park = smem + ROWS * XRSB + hcs * 8;
+    char* const l_side11 = t < 64 ? l_side + 8 * XRSB : l_park;
     char* const l_side6 = t < 192 ? l_side : l_park;          // S4: the one side request covers rows 0..5
 
     // ---- requests that travel ahead of their tile: the fp32 halo (12 x 16 B per thread) and its partition values / flags
     f32x4 areg[NREQ];
-    float pvn[3] = {0.f, 0.f, 0.f};
+    float pvn[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};  // partition planes at the lane's two pixels (rows 2 wrow, 2 wrow + 1; column lm)
     int pfn = 0;
-    auto request_tile = [&](int tl, bool live) {             // !live: every offset out of range (loads return 0, no branch)
+    // part 0..2: halo rows [0,4), [4,6), [6,8) (S4: [0,2), [2,3), [3,4)); part 3: the remaining rows, the side columns and the
+    // partition values / flags.  The parts are issued where registers are free (see the K loop).
+    auto request_tile_part = [&](int tl, bool live, int part) {     // !live: every offset out of range (loads return 0, no branch)
         const int ty0 = (tl / tiles_x) * THX, tx0 = (tl % tiles_x) * TW;
         const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * 256u;
         const bool ok_main = live & ((unsigned)(tx0 - 1 + hp) < (unsigned)W);    // rows outside the image leave the descriptor by themselves
         const bool ok_side = live & ((unsigned)(tx0 - 1 + h2x) < (unsigned)W);
+        constexpr int K1 = S4 ? 2 : 4, K2 = S4 ? 3 : 6, K3 = S4 ? 4 : 8;
+        const int k0 = part == 0 ? 0 : (part == 1 ? K1 : (part == 2 ? K2 : K3));
+        const int k1 = part == 0 ? K1 : (part == 1 ? K2 : (part == 2 ? K3 : ROWS));
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) areg[k] = buf_load4(r_src, ok_main ? hbase + g_main + (unsigned)k * row_bytes : OOB);
+        for (int k = 0; k < ROWS; ++k)
+            if (k >= k0 && k < k1) areg[k] = buf_load4(r_src, ok_main ? hbase + g_main + (unsigned)k * row_bytes : OOB);
+        if (part != 3) return;
         if (S4) {
             areg[ROWS] = buf_load4(r_src, (ok_side & (t < 192)) ? hbase + g_side : OOB);
         } else {
@@ -145,13 +160,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             areg[NREQ - 1] = buf_load4(r_src, (ok_side & (t < 64)) ? hbase + g_side + 8u * row_bytes : OOB);
         }
         if (PAR) {
-            const int gy = ty0 + 2 * wrow + my, gx = tx0 + mx;
+            const int gx = tx0 + lm;
 #pragma unroll
-            for (int jj = 0; jj < 3; ++jj)
-                pvn[jj] = buf_load1(r_par, (live & (gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+            for (int r = 0; r < 2; ++r) {
+                const int gy = ty0 + 2 * wrow + r;
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj)
+                    pvn[jj][r] = buf_load1(r_par, (live & (gy < H) & (gx < W)) ? (unsigned)(jj * a.par_plane + (long)gy * W + gx) * 4u : OOB);
+            }
             const int fidx = S4 ? ((tl / tiles_x) >> 1) * tiles_x + tl % tiles_x : tl;       // the 8x16 tile this one lies in
             pfn = __builtin_bit_cast(int, buf_load1(r_flags, live ? (unsigned)fidx * 4u : OOB));
         }
+    };
+    auto request_tile = [&](int tl, bool live) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) request_tile_part(tl, live, part);
     };
     int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
     auto bsel = [&](int j) { return j == 0 ? bs0 : (j == 1 ? bs1 : bs2); };
@@ -174,22 +197,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0;
         if (DBG) dbg_a = __builtin_amdgcn_s_memtime();
         const int ty0 = (tile / tiles_x) * THX, tx0 = (tile % tiles_x) * TW;
-        // ---- fp32 halo -> the two fp16 A tiles: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048); chunks 0, 1 -> ring
+        // ---- fp32 halo -> the split A tile: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048); chunks 0, 1 -> ring
 #pragma unroll
         for (int k = 0; k < NREQ; ++k) {
             // x saturates at +-65504 as a WHOLE: the remainder is taken from the clamped value, so it is at most half an fp16 ulp
             // (<= 16) and its scaled form (<= 32768) needs no clamp of its own; in-range values are untouched
             const f32x4 xc = clamp_h(areg[k]);
             const h4 hi = __builtin_convertvector(xc, h4);
-            char* d = k < ROWS ? l_main + k * RSB : (S4 ? l_side6 : (k == ROWS ? l_side : l_side11));
+            char* d = k < ROWS ? l_main + k * XRSB : (S4 ? l_side6 : (k == ROWS ? l_side : l_side11));
             *reinterpret_cast<h4*>(d) = hi;
-            *reinterpret_cast<h4*>(d + ABY) = __builtin_convertvector((xc - __builtin_convertvector(hi, f32x4)) * X3_SCALE, h4);
+            *reinterpret_cast<h4*>(d + 128) = __builtin_convertvector((xc - __builtin_convertvector(hi, f32x4)) * X3_SCALE, h4);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * X3_CHUNK + (t + 256 * i) * 16) = wreg[c][i];
-        float pv[3] = {pvn[0], pvn[1], pvn[2]};
+        float pv[3][2];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) pv[jj][0] = pvn[jj][0], pv[jj][1] = pvn[jj][1];
         if (PAR) {
             ncr = NC;
             bs0 = 0, bs1 = 1, bs2 = 2;
@@ -207,54 +232,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         const bool has_next = next < band_hi;
         if (DBG) dbg_b = __builtin_amdgcn_s_memtime();
 
-        // ---- K loop: chunk c from ring slot c % 3: two k-steps of hi*hi -> acc_hi, lo*hi + hi*lo -> acc_lo
-        f32x16 acc_hi[NTW], acc_lo[NTW];
+        // ---- K loop: chunk c (one 32-deep k-step) from ring slot c % 3: hi*hi -> acc_hi, lo*hi + hi*lo -> acc_lo
+        f32x4 acc_hi[2][NTW], acc_lo[2][NTW];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc_hi[j][r] = 0.f;
-                acc_lo[j][r] = 0.f;
+            for (int j = 0; j < NTW; ++j) {
+                acc_hi[r][j] = (f32x4)(0.f);
+                acc_lo[r][j] = (f32x4)(0.f);
             }
         auto fold = [&](bool with_bias) {          // acc_hi <- ((acc_hi + acc_lo / 2048) [+ bias]) [* gamma]; acc_lo <- 0
 #pragma unroll
-            for (int j = 0; j < NTW; ++j)
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc_hi[j][r] + acc_lo[j][r] * X3_INV;
-                    acc_hi[j][r] = with_bias ? (v + bco[j]) * gco[j] : v;
-                    acc_lo[j][r] = 0.f;
+                for (int j = 0; j < NTW; ++j) {
+                    const f32x4 v = acc_hi[r][j] + acc_lo[r][j] * X3_INV;
+                    acc_hi[r][j] = with_bias ? (v + bco[j]) * gco[j] : v;
+                    acc_lo[r][j] = (f32x4)(0.f);
                 }
         };
         f32x4 res4[EIT];
 #pragma unroll
         for (int i = 0; i < EIT; ++i) res4[i] = (f32x4)(0.f);
-        struct Frag { h8 ah, al, b[2 * NTW]; };              // one k-step: A hi, A lo, B hi (N tiles of the wave), B lo (same)
-        auto load_frag = [&](int c, int s2) {               // c, s2 compile-time after unrolling
+        // fragments: A of a chunk = [hi row 0, hi row 1, lo row 0, lo row 1]; B of (chunk, N tile j) = (hi, lo); chunk units in the
+        // ring slot: [hi N0..N3, lo N0..N3]
+        auto load_a = [&](int c, int u) {                   // c, u compile-time after unrolling
             const int tap = c >> 1, kh = c & 1, dy = c < 18 ? tap / 3 : 1, dx = c < 18 ? tap % 3 : 1;
-            const int o = a_off + dy * RSB + dx * PSB + 32 * (2 * kh + s2);
-            const char* b_lane = sR + (c % X3_RING) * X3_CHUNK + lane * 16;
-            Frag f;
-            f.ah = *reinterpret_cast<const h8*>(smem + o);
-            if (!DEAL) f.al = *reinterpret_cast<const h8*>(smem + ABY + o);
-#pragma unroll
-            for (int u = 0; u < NTW; ++u)         // chunk units per k-step: [hi N0, hi N1, lo N0, lo N1]
-                f.b[u] = *reinterpret_cast<const h8*>(b_lane + (s2 * 4 + (S4 ? 2 * u + wn : u)) * UNIT);
-            if (DEAL) f.al = *reinterpret_cast<const h8*>(smem + ABY + o);     // dealt reads: in the order of first use
-#pragma unroll
-            for (int u = NTW; u < 2 * NTW; ++u)
-                f.b[u] = *reinterpret_cast<const h8*>(b_lane + (s2 * 4 + (S4 ? 2 * u + wn : u)) * UNIT);
-            return f;
+            return *reinterpret_cast<const h8*>(smem + a_off + ((u & 1) + dy) * XRSB + dx * XPSB + (u >> 1) * 128 + kh * 64);
         };
-        Frag fr = load_frag(0, 0);
+        auto load_b = [&](int c, int j, int plane) {
+            return *reinterpret_cast<const h8*>(sR + (c % X3_RING) * X3_CHUNK + (plane * 4 + (S4 ? 2 * wn + j : j)) * UNIT + lane * 16);
+        };
+        h8 fa[4], fan[4], fb[2], fbn[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fa[u] = load_a(0, u), fan[u] = fa[u];
+        fb[0] = load_b(0, 0, 0);
+        fb[1] = load_b(0, 0, 1);
+        fbn[0] = fb[0], fbn[1] = fb[1];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (PAR && c >= 18 && c >= ncr) break;
             if (c + NSET < NC && (!PAR || c + NSET < ncr)) request_chunk(c + NSET);
             // After the last 3x3 chunk request (chunk 17, at the top of chunk 13): memory returns in order, so a tile-data request
             // (HBM, ~2.5 us) ahead of a weight chunk (L2) would hold the chunk back.  Residual rows / partial sums of THIS tile first
-            // (the epilogue needs them), then -- once two more register sets have gone to the ring -- the halo of the NEXT tile,
-            // which rides in registers through the rest of the loop and the epilogue.
+            // (the epilogue needs them); the halo of the NEXT tile is requested behind the loop.
             if (c == RQR) {
                 if (!PAR) {
 #pragma unroll
@@ -266,87 +287,97 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                     }
                 }
             }
-            if (c == RQH && !PAR) request_tile(has_next ? next : tile, has_next);
-            float pj = 1.f;
+            // the next tile's halo: requested where registers are free -- the weight sets of chunks 14..17 are dead once written to
+            // the ring (two chunks ahead), so rows [0,4) can leave at chunk 14, [4,6) at 15, [6,8) at 16; the rest follows behind the
+            // loop.  (All of it behind the loop: the epilogue's stores queue behind 20 loads in the CU's memory pipe, +2 k cycles.)
+            if (!PAR && c >= 14 && c <= 16) request_tile_part(has_next ? next : tile, has_next, c - 14);
+            h8 xa[4] = {fa[0], fa[1], fa[2], fa[3]};
             if (PAR && c >= 18) {
                 if (c == 18) fold(true);                   // (conv + bias) * gamma BEFORE the 1x1 partition branches
                 const int bi = bsel((c - 18) >> 1);
-                pj = bi == 0 ? pv[0] : (bi == 1 ? pv[1] : pv[2]);
-            }
+                // par_j(pixel) * x as a split number again: (hi + lo / 2048) is exact in fp32 (22 bits), one fp32 rounding for the
+                // product, then the same split as the halo (saturating as a whole)
+                typedef float f32x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                // fragments of the NEXT k-step before this one's MFMAs -- across the chunk boundary too: chunk c + 1 has been
-                // in the ring since the barrier that ended chunk c - 1, the A tiles do not change
-                Frag nf;
-                if (s2 == 0) nf = load_frag(c, 1);
-                else if (c + 1 < NC) nf = load_frag(c + 1, 0);
-                if (!DEAL) __builtin_amdgcn_sched_barrier(0);          // burst form: the reads stay AHEAD of the MFMAs
-                h8 ah = fr.ah, al = fr.al;
-                if (PAR && c >= 18) {
-                    // par_j(pixel) * x as a split number again: (hi + lo / 2048) is exact in fp32 (22 bits), one fp32 rounding
-                    // for the product, then the same split as the halo
-                    typedef float f32x8 __attribute__((ext_vector_type(8)));
-                    f32x8 v = (__builtin_convertvector(ah, f32x8) + __builtin_convertvector(al, f32x8) * X3_INV) * pj;
-                    // saturates as a whole like the halo split (the remainder of the CLAMPED product fits fp16 by construction)
+                for (int r = 0; r < 2; ++r) {
+                    const float pj = bi == 0 ? pv[0][r] : (bi == 1 ? pv[1][r] : pv[2][r]);
+                    f32x8 v = (__builtin_convertvector(fa[r], f32x8) + __builtin_convertvector(fa[2 + r], f32x8) * X3_INV) * pj;
                     v = __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x8)(-65504.f)), (f32x8)(65504.f));
-                    ah = __builtin_convertvector(v, h8);
-                    al = __builtin_convertvector((v - __builtin_convertvector(ah, f32x8)) * X3_SCALE, h8);
+                    xa[r] = __builtin_convertvector(v, h8);
+                    xa[2 + r] = __builtin_convertvector((v - __builtin_convertvector(xa[r], f32x8)) * X3_SCALE, h8);
+                }
+            }
+            const bool more = c + 1 < NC;                   // (a branch tile that stops early reads a stale ring slot: unused)
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) {
+                // quarter q: N tile q of the chunk -- 6 MFMAs; meanwhile the (hi, lo) B pair of the next quarter and 1 (S4: 2) of the
+                // next chunk's 4 A fragments are fetched, DEALT into the MFMA gaps: a wave issues in order, a burst of 1-KiB reads in
+                // front of the MFMAs holds its issue slot while only a partner wave can feed the matrix pipe (a lone wave then runs
+                // 48-60 cycles per 32-cycle MFMA), one read per gap hides inside it (tools/ubench/ub_mfma_issue.hip).
+                const int cn = q + 1 < NTW ? c : c + 1, qn = q + 1 < NTW ? q + 1 : 0;
+                if (q + 1 < NTW || more) {
+                    fbn[0] = load_b(cn, qn, 0);
+                    fbn[1] = load_b(cn, qn, 1);
+                }
+                if (more) {
+#pragma unroll
+                    for (int u = q * (4 / NTW); u < (q + 1) * (4 / NTW); ++u) fan[u] = load_a(c + 1, u);
                 }
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) acc_hi[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[j], acc_hi[j], 0, 0, 0);
+                for (int r = 0; r < 2; ++r) acc_hi[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[r], fb[0], acc_hi[r][q], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fr.b[j], acc_lo[j], 0, 0, 0);
+                for (int r = 0; r < 2; ++r) acc_lo[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[2 + r], fb[0], acc_lo[r][q], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) acc_lo[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fr.b[NTW + j], acc_lo[j], 0, 0, 0);
-                if (s2 == 0 && c + 2 < NC && (!PAR || c + 2 < ncr)) {
+                for (int r = 0; r < 2; ++r) acc_lo[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[r], fb[1], acc_lo[r][q], 0, 0, 0);
+                if (q == (S4 ? 0 : 1) && c + 2 < NC && (!PAR || c + 2 < ncr)) {
                     // ring write of chunk c + 2 (into the slot of chunk c - 1, which every wave left before the previous barrier)
                     // in the MIDDLE of the chunk: the barrier below then waits for it, not for the fragment reads behind it
                     char* d = sR + ((c + 2) % X3_RING) * X3_CHUNK;
 #pragma unroll
                     for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(d + (t + 256 * i) * 16) = wreg[(c + 2) % NSET][i];
                 }
-                // The NEXT k-step's fragment reads are DEALT into this k-step's MFMA gaps, one per gap, together with whatever the
-                // chunk requests from memory (weights four chunks ahead, the residual rows, the next halo) and the ring write.  A
-                // wave issues in order: a burst of six 1-KiB reads in front of six MFMAs holds the wave's issue slot for ~96 cycles
-                // in which only a partner wave can feed the matrix pipe (a lone wave then runs 48-60 cycles per MFMA: what r03 took
-                // for a structural limit); one read per gap hides inside the MFMA's own 32 cycles -- 33.0-33.5 cycles per MFMA for
-                // a lone wave at up to 1.5 reads per MFMA, 32.6 per SIMD for two (tools/ubench/ub_mfma_issue.hip,
-                // profiles/r04_ub_mfma_issue.txt).  Reads are issued in the order of their first use (load_frag).
-#define X3_GAP(NREAD, NVMEM, NWRITE)                                                          \
+#define X3_GAP(NREAD, NVMEM, NWRITE)                                                              \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                \
-                __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  /* fragment read(s) */        \
-                __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);  /* memory requests */         \
+                if (NREAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* a fragment read */ \
+                if (NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);  /* memory requests */ \
                 if (NWRITE) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   /* ring write */
-                if (!DEAL) {
-                } else if (S4) {            // 3 MFMAs, 4 reads
-                    X3_GAP(2, 4, 0) X3_GAP(1, 4, 1) X3_GAP(1, 4, 1)
-                } else {                    // 6 MFMAs, 6 reads
-                    X3_GAP(1, 2, 0) X3_GAP(1, 2, 0) X3_GAP(1, 2, 0) X3_GAP(1, 2, 0) X3_GAP(1, 2, 1) X3_GAP(1, 2, 1)
+                if (S4) {                   // 4 reads
+                    X3_GAP(1, 4, 0) X3_GAP(1, 4, 0) X3_GAP(1, 4, 0) X3_GAP(1, 4, 0) X3_GAP(0, 0, 1) X3_GAP(0, 0, 1)
+                } else {                    // 3 reads
+                    X3_GAP(1, 3, 0) X3_GAP(0, 3, 0) X3_GAP(1, 3, 0) X3_GAP(0, 3, 1) X3_GAP(1, 0, 0) X3_GAP(0, 0, 1)
                 }
 #undef X3_GAP
                 __builtin_amdgcn_sched_barrier(0);
-                if (s2 == 0 || c + 1 < NC) fr = nf;
+                fb[0] = fbn[0], fb[1] = fbn[1];
             }
-            // LDS operations complete in order: the 6 (S4: 4) fragment reads of the next chunk's first k-step were issued after the
-            // ring write, so "at most that many outstanding" means the write has landed -- and the reads stay in flight across the barrier
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fa[u] = fan[u];
+            // LDS operations complete in order: the fragment reads of the quarters behind the ring write (non-S4: quarters 2, 3 = 6
+            // reads; S4: quarter 1 = 4) were issued after it, so "at most that many outstanding" means the write has landed -- and
+            // those reads stay in flight across the barrier
             if (c + 1 >= NC) lds_barrier();
             else if (S4) asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory");
         }
         if (DBG) dbg_c = __builtin_amdgcn_s_memtime();
-        // the branch chunks' VALU work (scaling and re-splitting A fragments) needs the registers: the next halo only now
+        // the next halo only now: inside the loop its 48 registers do not fit beside the fragments of the 16x16x32 pipeline (23 spills),
+        // and the epilogue is long enough to cover the latency (the branch variant always requested it here: same prologue time)
         if (PAR) request_tile(has_next ? next : tile, has_next);
+        else request_tile_part(has_next ? next : tile, has_next, 3);
         request_first_chunks();          // every set is free again; the latency hides behind the epilogue
         fold(!PAR || ncr == 18);         // PAR with branches: bias / gamma went in before them; otherwise here
 
-        // ---- epilogue: transpose through the dead A tiles, [+ partial sum], activation, [+ residual], whole pixel rows to HBM
-        static_assert(4 * 4096 * NTW <= 2 * ABY, "the transposition slices fit the dead A tiles");
-        float* sT = reinterpret_cast<float*>(smem + wave * (4096 * NTW));        // [32 pixels][32 NTW channels] fp32 per wave
+        // ---- epilogue: transpose through the dead A tile, [+ partial sum], activation, [+ residual], whole pixel rows to HBM
+        // accumulator element e of lane (lm, lg), M tile r, N tile j = pixel (row r, column 4 lg + e), channel 16 j + lm of the wave
+        static_assert(4 * 2048 * NTW <= ROWS * XRSB, "the transposition slices fit the dead A tile");
+        float* sT = reinterpret_cast<float*>(smem + wave * (2048 * NTW));        // [32 pixels][16 NTW channels] fp32 per wave
         const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * (32 * NTW) + j * 32 + n0] = acc_hi[j][r];
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sT[(16 * r + 4 * lg + e) * (16 * NTW) + j * 16 + lm] = acc_hi[r][j][e];
         asm volatile("" ::: "memory");
         f32x4 rows[EIT];
 #pragma unroll
@@ -369,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         }
         if (!has_next) break;
         tile = next;
-        lds_barrier();                   // the transposition rows are read: the next tile may overwrite the A tiles
+        lds_barrier();                   // the transposition rows are read: the next tile may overwrite the A tile
     }
     if (DBG && t == 0) {
         unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
@@ -383,30 +414,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     }
 }
 
-// fp32 B image -> the split image: per 64-deep chunk of the fp32 image (a tap / a 1x1 branch) two 8 KiB chunks (k-halves) of
-// 2 k-steps x [hi N0, hi N1, lo N0, lo N1] fragment units; hi = fp16(w) (saturating), lo = fp16((w - hi) * 2048)
+// fp32 B image -> the split image: per 64-deep chunk of the fp32 image (a tap / a 1x1 branch) two 8 KiB chunks (k-halves = one
+// 32-deep k-step of v_mfma_f32_16x16x32_f16) of [hi N0..N3, lo N0..N3] fragment units; unit = 64 lanes x 8 halfs, lane (n, g) holds
+// input channels 32 kh + 8 g .. + 7 of output channel 16 j + n; hi = fp16(w) (saturating), lo = fp16((w - hi) * 2048)
 __global__ __launch_bounds__(256) void f16x3_image_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long total) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // index into the plain fp16 image (f16_image_kernel's order)
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one (input channel, output channel) of a 64-deep chunk
     if (idx >= total) return;
     constexpr int per_chunk = PNP_CHUNK_Q * 2 * 256;                   // 4096
     const long chunk = idx / per_chunk;
     const int rem = (int)(idx - chunk * per_chunk);
-    const int j = rem & 7, lane = (rem >> 3) & 63, nt = (rem >> 9) & 1, s = rem >> 10;
-    const int n = lane & 31, hh = lane >> 5;
-    const int k = 16 * s + 8 * hh + j;
-    const float v = src[chunk * per_chunk + (((k >> 3) * 2 + nt) * 64 + ((k >> 2) & 1) * 32 + n) * 4 + (k & 3)];
+    const int jj = rem & 7, lane = (rem >> 3) & 63, j = (rem >> 9) & 3, kh = rem >> 11;
+    const int n = lane & 15, g = lane >> 4;
+    const int k = 32 * kh + 8 * g + jj, co = 16 * j + n;
+    const float v = src[chunk * per_chunk + (((k >> 3) * 2 + (co >> 5)) * 64 + ((k >> 2) & 1) * 32 + (co & 31)) * 4 + (k & 3)];
     const float vc = fminf(fmaxf(v, -65504.f), 65504.f);         // saturates as a whole (see the halo split)
     const _Float16 hi = (_Float16)vc;
     const _Float16 lo = (_Float16)((vc - (float)hi) * X3_SCALE);
-    _Float16* d = dst + chunk * (2 * per_chunk) + (s >> 1) * per_chunk + ((s & 1) * 4 + nt) * 512 + lane * 8 + j;
+    _Float16* d = dst + chunk * (2 * per_chunk) + kh * per_chunk + j * 512 + lane * 8 + jj;
     d[0] = hi;
-    d[2 * 512] = lo;
+    d[4 * 512] = lo;
 }
 
 template <bool PAR, bool DBG, bool S4>
 int launch_x3_t(const X3Args& xa, hipStream_t stream) {
     auto kern = conv3x3_f16x3_kernel<PAR, DBG, S4>;
-    constexpr int lds = S4 ? 2 * (4 + 2) * RSB + X3_RING * X3_CHUNK : X3_LDS;
+    constexpr int lds = (S4 ? 4 + 2 : TH + 2) * XRSB + XPARK + X3_RING * X3_CHUNK;
     static PnpPerDevice once;
     const hipError_t attr_err = once.run([&](int, int&) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
