@@ -182,6 +182,8 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
     assert ns['clips_1'] > 0 and ns['clips_8'] > 0 and ns['clips_8_hipgraph'] > 0 and 0 < ns['frac_per_launch'] < 1
     assert 'cpu' not in ns                                      # --no-cpu-baseline covers the 128x128 CPU leg too
     assert d['secondary_file'] == 'bench_secondary.json'
+    oi = d['opt_in_720p']                                       # the opt-in arithmetics at the headline shape, compact
+    assert oi['f16x3'] > 1.8 * d['value'] and oi['fp16'] > 3 * d['value'] and oi['f16x3_bound'] == 'mfma' and oi['fp16_bound'] == 'hbm'
     with open(side) as fh:
         full = json.load(fh, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
     assert full['value'] == d['value'] or abs(full['value'] - d['value']) < 1e-4 * d['value']
@@ -246,7 +248,7 @@ def test_bench_deform_basic_reports_the_dcn_roofline(precision):
     r = d['roofline_dcn']
     assert d['config']['deform'] == 'basic' and r['bound'] == 'hbm' and r['launches'] == 2 * 4       # 4 alignments per 3-frame clip
     assert abs(r['algorithmic_bytes_per_launch'] - 2240 * 128 * 128) < 1 and r['frac'] > 0
-    assert ('fp16' in r['kernel']) == (precision == 'fp16')
+    assert r['kernel'] == ('dcn_window_kernel<true>' if precision == 'fp16' else 'dcn_window_kernel<false>')     # <true> = fp16 MFMA operands
 
 
 def _free_port():
