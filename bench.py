@@ -13,8 +13,9 @@ tools/dist_test.sh:11-22).  Clips are sharded one per rank (weak scaling, replic
 tensors), a barrier + synchronize on both sides of the timed region, MAX over ranks, and one RCCL all-gather of
 (PSNR, frames/s) per rank (mmedit/apis/test.py:211-233).  Rank 0 prints ONE JSON line.
 
-stdout carries exactly ONE strict-JSON line of at most 4 KB (the driver keeps the last 8 KB of stdout; round 3's 21 KB line was
-cut in half and never parsed).  At N = 1 with the default workload the other BASELINE.json workloads (7x3x128x128 fp32, 1 and
+stdout carries exactly ONE strict-JSON line of at most 4 KB and nothing else (the driver keeps the last 8 KB of stdout; round 3's
+21 KB line was cut in half and never parsed): file descriptor 1 is pointed at stderr for the run -- RCCL and gloo print to
+stdout too -- and the line is written to the saved descriptor at the end.  At N = 1 with the default workload the other BASELINE.json workloads (7x3x128x128 fp32, 1 and
 8 clips; 180x320 fp16 with and without the x4 heads; the opt-in precisions at 720p; the end-to-end loop) are measured in the same
 process after the headline, each with its own timed region, roofline and kernel-event mode; they go to `bench_secondary.json`
 beside this file (and to stderr), and the line carries only `north_star_128`, a compact summary of the 7x3x128x128 entries.
@@ -530,6 +531,13 @@ def main(argv=None, measure_fn=None):
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
 
+    # stdout belongs to the ONE result line.  Libraries print there too (RCCL writes a version banner to the C-level stdout, which
+    # is flushed at exit, i.e. BEHIND the line; gloo prints its connection lines): file descriptor 1 is pointed at stderr for
+    # the whole run and the line is written to the saved descriptor at the very end.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np   # noqa: F401
     import torch
     import torch.distributed as dist
@@ -650,10 +658,11 @@ def main(argv=None, measure_fn=None):
             except OSError as e:
                 print(f'bench.py: cannot write {SECONDARY_FILE}: {e}', file=sys.stderr)
             print(text, file=sys.stderr, flush=True)
-        print(bounded_line(res), flush=True)
+        os.write(line_fd, (bounded_line(res) + '\n').encode())
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
+    os.close(line_fd)
 
 
 def north_star_128(sec):

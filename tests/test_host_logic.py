@@ -430,7 +430,7 @@ def test_bench_eight_rank_path_over_gloo_prints_one_bounded_line(tmp_path):
                           '127.0.0.1', '--master-port', str(port), str(script), '--gpus', '8', '--workload', '128', '--frames', '3',
                           '--steps', '2', '--warmup', '1', '--no-kernel-events'], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    d = bench_line(out.stdout, clean=False)
+    d = bench_line(out.stdout)          # clean: bench.py points fd 1 at stderr, so even gloo's connection lines stay off stdout
     assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'clip-sharded replicas x8'
     assert d['psnr_per_rank'] == [30.0 + r for r in range(8)] and len(d['frames_per_s_per_rank']) == 8
     assert d['dist'] == {'process_group': True, 'backend': 'gloo', 'rccl_version': None,
