@@ -208,9 +208,17 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
     #: frames below this many pixels cannot fill the chip alone: samples of a batch then run concurrently
     CONCURRENT_BELOW_PIXELS = 512 * 512
     MAX_CONTEXTS = 8                       # PNP_MAX_CONTEXTS (r02, 128x128 fp32, 8 clips: 2 ctx 2130, 4 ctx 2022, 8 ctx 2213 frames/s)
+    #: a large frame fills the chip by itself, but every persistent conv launch ends with a partial round (720p: 7200 tiles on
+    #: 512 strips = 14.06 rounds, the 15th on 32 blocks) and a dispatch gap: two samples interleaved on two streams fill each
+    #: other's tails -- measured +4.9 % fp32 / +4.5 % split fp16 / +5.2 % fp16 at 720p, bit-identical (tools/tail_fill_probe.py);
+    #: more than two gain nothing and cost a workspace each
+    LARGE_FRAME_CONTEXTS = 2
+
+    def _contexts(self, n, h, w):
+        return min(n, self.LARGE_FRAME_CONTEXTS if h * w >= self.CONCURRENT_BELOW_PIXELS else self.MAX_CONTEXTS)
 
     def _get_workspace(self, n, t, h, w, device):
-        ctx = 1 if h * w >= self.CONCURRENT_BELOW_PIXELS else min(n, self.MAX_CONTEXTS)
+        ctx = self._contexts(n, h, w)
         k = (ctx, t, h, w, str(device))
         ws = self._workspace.get(k)
         if ws is None:
@@ -302,7 +310,7 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
         key = (n, t, h, w, str(dev), side.numpy().tobytes(), self._packed.data_ptr(), self._packed_floats)
         ent = self._graphs.get(key)
         if ent is None:
-            ctx = 1 if h * w >= self.CONCURRENT_BELOW_PIXELS else min(n, self.MAX_CONTEXTS)
+            ctx = self._contexts(n, h, w)
             nbytes = int(_native.lib().pnp_generator_workspace_bytes(self._handle, t, h, w)) * ctx
             ent = dict(lrs=torch.empty_like(lrs_c), mvs=torch.empty_like(mvs_c), par=torch.empty_like(par_c),
                        out=torch.empty(out_shape, device=dev, dtype=torch.float32),

@@ -346,12 +346,26 @@ def test_batch_samples_run_concurrently_and_match_one_at_a_time(fp16):
     assert float(chk) == float(ref.sum())
 
 
-def test_large_frames_keep_one_context():
-    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=1)
-    m = build(cfg, gu.syn.make_state_dict(cfg, seed=63))
-    clip = gu.syn.make_clip(seed=64, n=2, t=1, h=512, w=512, slices='IBBBP')
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3', 'fp16'])
+def test_large_frames_run_two_samples_on_two_streams_and_match_one_at_a_time(precision):
+    """A large frame fills the chip, but every persistent conv launch ends with a partial round of tiles and a dispatch gap: a
+    batch of large frames runs TWO samples at a time on two streams so that they fill each other's tails (r04: +5 % at 720p).
+    Three 720p samples (the third reuses context 0) must equal sample-by-sample calls bit for bit, and a consumer on the
+    caller's stream right behind the call sees the finished output."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    m = build(cfg, gu.syn.make_state_dict(cfg, seed=63, par_gain=10.0))
+    m.precision = precision
+    clip = gu.syn.make_clip(seed=64, n=3, t=2, h=720, w=1280, slices='IBBBP', crf=[15, 25, 35], par_classes=3)
     out = run(m, clip)
-    assert out.shape == (2, 1, 3, 512, 512) and next(iter(m._workspace))[0] == 1
+    chk = out.double().sum()
+    assert m.LARGE_FRAME_CONTEXTS == 2 and next(iter(m._workspace))[0] == 2
+    singles = []
+    for b in range(3):
+        singles.append(run(m, {k: v[b:b + 1] for k, v in clip.items()}))
+        assert next(iter(m._workspace))[0] == 1
+    ref = torch.cat(singles)
+    assert out.shape == (3, 2, 3, 720, 1280) and torch.equal(out, ref) and float(chk) == float(ref.double().sum())
+    assert not torch.equal(out[0], out[1])
 
 
 @pytest.mark.parametrize('fp16', [False, True])
