@@ -123,9 +123,13 @@ class BasicVSR(nn.Module):
         return eval_result
 
     def forward_test(self, lq, gt=None, QPs=None, slices=None, mvs=None, base_QPs=None, par_map=None, meta=None,
-                     save_image=False, save_path=None, iteration=None):
-        """basicvsr.py:155-233."""
-        if not self.psnr_only:
+                     save_image=False, save_path=None, iteration=None, precomputed_output=None):
+        """basicvsr.py:155-233.  `precomputed_output` (not in the reference): this clip's enhanced frames when the caller has
+        already run the generator -- apis.multi_gpu_test does so for two clips at a time, which the generator interleaves on two
+        streams; evaluation and saving then proceed clip by clip exactly as below."""
+        if precomputed_output is not None:
+            output = precomputed_output
+        elif not self.psnr_only:
             with torch.no_grad():
                 torch.cuda.synchronize()
                 begin = time.time()

@@ -408,3 +408,42 @@ def test_prefetcher_uint8_upload_is_bit_identical_to_the_float_pipeline(tmp_path
         assert data['meta'][0]['key'] == ref['meta']['key']
     # frames differ from clip to clip and from frame to frame (the equality above is not vacuous)
     assert not torch.equal(ds[0]['lq'][0], ds[0]['lq'][1]) and not torch.equal(ds[0]['lq'], ds[1]['lq'])
+
+
+def test_tools_test_two_clips_in_flight_scores_exactly_like_one():
+    """tools/test.py --clips-in-flight 2 (the default): pairs of clips go through the generator as one batch (two streams), the third
+    of three clips alone; PSNR / SSIM must equal the strict one-clip-per-forward run digit for digit."""
+    import re
+    common = ['--seed', '0', '--cfg-options', 'data.test.num_clips=3', 'data.test.num_input_frames=3',
+              'data.test.height=64', 'data.test.width=64']
+    cfgp = os.path.join(ROOT, 'configs', 'HR_davis_LR_128x128_IPB.py')
+    got = {}
+    for cif in ('1', '2'):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), cfgp, 'none', '--clips-in-flight', cif] + common,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        got[cif] = (re.search(r'Eval-PSNR: ([0-9.]+)', out.stdout).group(1), re.search(r'Eval-SSIM: ([0-9.]+)', out.stdout).group(1))
+    assert got['1'] == got['2'], got
+
+
+def test_multi_gpu_test_pairs_equal_shapes_only():
+    """apis.multi_gpu_test(clips_in_flight=2) on the real model: per-clip metrics equal the one-at-a-time loop exactly, in clip order,
+    for an odd number of clips; clips of different shapes fall back to one at a time."""
+    from pnp_vcve_amd import synthetic as syn
+    from pnp_vcve_amd.apis import multi_gpu_test, _pairable
+    from pnp_vcve_amd.datasets import SyntheticCompressedClipDataset
+    from pnp_vcve_amd.registry import build_model
+    gcfg = dict(syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    model = build_model(dict(type='BasicVSR', generator=dict(type='IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par', **gcfg),
+                             pixel_loss=dict(type='CharbonnierLoss')), train_cfg=None,
+                        test_cfg=dict(metrics=['PSNR', 'SSIM'], crop_border=0)).cuda().eval()
+    ds = SyntheticCompressedClipDataset(num_clips=5, num_input_frames=3, height=64, width=80)
+    one = multi_gpu_test(model, ds, device='cuda', clips_in_flight=1)
+    two = multi_gpu_test(model, ds, device='cuda', clips_in_flight=2)
+    assert len(one) == len(two) == 5
+    for a, b in zip(one, two):
+        assert a['eval_result'] == b['eval_result']
+    assert len({r['eval_result']['PSNR'] for r in one}) == 5          # five different clips: the order check is not vacuous
+    x = {k: torch.zeros(1, 3, 3, 64, 64) for k in ('lq', 'QPs', 'slices', 'mvs', 'base_QPs', 'partitions')}
+    y = dict(x, lq=torch.zeros(1, 3, 3, 64, 72))
+    assert _pairable(x, x) and not _pairable(x, y) and not _pairable(x, {k: v for k, v in x.items() if k != 'mvs'})
