@@ -20,6 +20,9 @@ from pnp_vcve_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=2.5)
+ap.add_argument('--zeros', action='store_true',
+                help='all-zero operands (same instruction stream, same cycles): if the kernel is POWER-limited the chip holds a higher '
+                     'clock and the launch takes less wall time (MI355X_MICROARCH.md, DVFS give-back item 1)')
 args = ap.parse_args()
 h, w = 720, 1280
 dev = torch.device('cuda:0')
@@ -31,6 +34,9 @@ w1 = ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev) * 0.05 for _ in ran
 par = (torch.rand(3, h, w, device=dev) / 255.0).contiguous()
 bias = torch.randn(64, device=dev) * 0.1
 gam = torch.rand(64, device=dev)
+if args.zeros:
+    for t_ in (x, res, pw, w1, bias):
+        t_.zero_()
 PEAK = 157.3
 
 
@@ -40,7 +46,8 @@ def run(kind, trace=None):
     return ops.conv3x3([x], [pw], bias=bias, gamma=gam, packed_w1x1=w1, par=par, act=1, trace=trace)     # front half, K = 768, dense par
 
 
-print(f'device: {torch.cuda.get_device_name(0)}; kernel: conv3x3_persist_kernel (720x1280, 64->64, fp32 MFMA 32x32x2), random operands')
+print(f'device: {torch.cuda.get_device_name(0)}; kernel: conv3x3_persist_kernel (720x1280, 64->64, fp32 MFMA 32x32x2), '
+      f'{"ALL-ZERO" if args.zeros else "random"} operands')
 for kind, K in (('back', 576), ('front', 768)):
     for _ in range(3):
         run(kind)
