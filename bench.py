@@ -704,7 +704,7 @@ def opt_in_720p(sec):
     return out
 
 
-def pipeline_e2e(dev, T, clips=6, workers=16, precision='fp32'):
+def pipeline_e2e(dev, T, clips=10, workers=16, precision='fp32'):
     """The whole evaluation loop of tools/test.py on an on-disk tree in the reference's REDS layout (restorers/basicvsr.py:155-231,
     apis/test.py:100-119): PNG + MV-record decode on a loader thread and H2D on a side stream one clip ahead (ClipPrefetcher),
     MV / partition maps painted on the GPU (pnp_rasterise_side_info_f32), the fp32 generator, PSNR + SSIM on the device, enhanced

@@ -22,6 +22,7 @@
 // output mapping (o_sy, o_sx, o_c0).  DESIGN.md 3.6 has the timeline and what bounds it.
 #include "conv_mfma.h"
 #include "f16_util.h"
+#include <string.h>
 
 namespace {
 
@@ -45,6 +46,13 @@ struct X3Args {
     unsigned out_bytes;
     int H, W, act;
     unsigned long long* dbg;     // timeline: 8 u64 per block or nullptr
+    // MS kernels (an input conv in ONE launch): further 64-channel sources of the same size, accumulated into the same MFMA chains
+    // source after source (src / w are source 0), and optionally the RGB frame in front of them
+    int nsrc;                    // 64-channel sources: 1..3
+    const float* src2[2];
+    const _Float16* w2[2];
+    const float* lr4;            // (H, W, 4) fp32, 4th channel zero, or nullptr
+    const _Float16* wlr;         // its split image: 2 chunks (k = 4 tap + channel)
 };
 
 // Halo geometry: 10 rows x 18 pixels x 16 float4.  Requests 0..9: row k, pixels 0..15 (thread t: pixel t >> 4, float4 t & 15);
@@ -66,13 +74,26 @@ struct X3Args {
 constexpr int XPSB = 288, XRSB = PW * XPSB;                  // pixel / row stride of the split A tile
 constexpr int XPARK = 256;                                   // where idle lanes of the side requests put their (unused) halves
 
-template <bool PAR, bool DBG, bool S4>
+// a pointer chosen at run time by wave-uniform values, made PROVABLY uniform (the descriptor built from it must live in scalar
+// registers: otherwise every buffer access becomes a waterfall loop)
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <bool PAR, bool DBG, bool S4, bool MS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
+    static_assert(!MS || (!PAR && !DBG), "the multi-source kernel is the plain conv");
     constexpr int NC = 18 + (PAR ? 6 : 0);                   // chunks: two k-halves per tap, then two per partition branch
     // register sets of weight chunks (chunk c travels in set c % NSET, requested NSET chunks ahead, written to the ring two ahead).
     constexpr int NSET = 4;                                  // (3 starves the ring: K loop 13.6 k -> 18.8 k cycles per tile)
     constexpr int WPT = 2;
-    constexpr int THX = S4 ? 4 : TH, ROWS = THX + 2, ABY = ROWS * XRSB + XPARK;     // tile rows, halo rows, bytes of the A tile
+    constexpr int THX = S4 ? 4 : TH, ROWS = THX + 2;                               // tile rows, halo rows
+    constexpr int LBY = MS ? ROWS * PW * 16 : 0;                                   // MS: the RGB halo, [4 ch hi | 4 ch lo] = 16 B per pixel
+    constexpr int ABY = ROWS * XRSB + XPARK + LBY;                                 // bytes in front of the weight ring
     constexpr int NTW = S4 ? 2 : 4;                          // 16-channel N tiles per wave
     constexpr int NREQ = S4 ? ROWS + 1 : X3_AIT;             // 16-byte halo requests per thread
     constexpr int CW = NTW * 4, PPI = 64 / CW, EIT = 32 / PPI;   // epilogue: float4 per pixel in the wave's N range, pixels per instruction
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
     const unsigned row_bytes = (unsigned)W * 256u;
-    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, map_bytes);
+    __amdgpu_buffer_rsrc_t r_src = make_rsrc(a.src, map_bytes);      // the source whose halo is requested next (MS: changes per pass)
     const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? (const void*)a.residual : (const void*)a.src, a.residual ? map_bytes : 0);
     const __amdgpu_buffer_rsrc_t r_par = make_rsrc(PAR ? (const void*)a.par : (const void*)a.src, PAR ? (unsigned)(3 * a.par_plane * 4) : 0);
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out, a.out_bytes);
@@ -111,8 +132,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                                                      (PAR && a.par_flags) ? (unsigned)(tiles_x * ((H + TH - 1) / TH)) * 4u : 0);   // per 8x16 tile
     // weight chunks through descriptors too: voffset = 16 t for every load, the chunk in the SCALAR offset -- no per-chunk
     // 64-bit address pairs for the compiler to hoist out of the tile loop and spill
-    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.w, 18u * X3_CHUNK);
+    __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.w, 18u * X3_CHUNK);       // the weights whose chunks are requested next (MS: per pass)
     const __amdgpu_buffer_rsrc_t r_wp = make_rsrc(PAR ? (const void*)a.wpar : (const void*)a.w, 6u * X3_CHUNK);
+    const bool has_lr = MS && a.lr4 != nullptr;
+    const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(has_lr ? (const void*)a.lr4 : (const void*)a.src, has_lr ? (unsigned)H * (unsigned)W * 16u : 0);
+    const __amdgpu_buffer_rsrc_t r_wlr = make_rsrc(has_lr ? (const void*)a.wlr : (const void*)a.w, 2u * X3_CHUNK);
+    char* const sL = smem + ROWS * XRSB + XPARK;
+    f32x4 lrreg = (f32x4)(0.f);                              // the thread's pixel of the next tile's RGB halo (t < ROWS * PW)
+    // RGB A fragments: k = 32 kh + 8 lg + jj = 4 tap + channel -> the lane's 8 k values are taps 8 kh + 2 lg, + 1 (4 channels each);
+    // taps beyond 8 carry zero weights and re-read tap 8 (finite values)
+    int rgb_off[2][2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int tap = 8 * kh + 2 * lg + e;
+            tap = tap > 8 ? 8 : tap;
+            rgb_off[kh][e] = ((tap / 3) * PW + tap % 3) * 16;
+        }
     const int ec = lane % CW, ep = lane / CW;
     const float neg_slope = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     const float k_pre = a.res_pre ? 1.f : 0.f, k_post = 1.f - k_pre;
@@ -141,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     int pfn = 0;
     // part 0..2: halo rows [0,4), [4,6), [6,8) (S4: [0,2), [2,3), [3,4)); part 3: the remaining rows, the side columns and the
     // partition values / flags.  The parts are issued where registers are free (see the K loop).
+    bool want_lr = false;                                    // the tile being requested starts with the RGB pass
     auto request_tile_part = [&](int tl, bool live, int part) {     // !live: every offset out of range (loads return 0, no branch)
         const int ty0 = (tl / tiles_x) * THX, tx0 = (tl % tiles_x) * TW;
         const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * 256u;
@@ -153,6 +191,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         for (int k = 0; k < ROWS; ++k)
             if (k >= k0 && k < k1) areg[k] = buf_load4(r_src, ok_main ? hbase + g_main + (unsigned)k * row_bytes : OOB);
         if (part != 3) return;
+        if (MS && want_lr) {
+            const int ry = t / PW, rx = t - ry * PW;
+            const bool ok = live & (t < ROWS * PW) & ((unsigned)(tx0 - 1 + rx) < (unsigned)W);
+            lrreg = buf_load4(r_lr, ok ? (unsigned)((ty0 - 1 + ry) * W + (tx0 - 1 + rx)) * 16u : OOB);
+        }
         if (S4) {
             areg[ROWS] = buf_load4(r_src, (ok_side & (t < 192)) ? hbase + g_side : OOB);
         } else {
@@ -186,17 +229,105 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             wreg[c % NSET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c < 18 ? r_w : r_wp, t * 16, so, 0));
         }
     };
-    auto request_first_chunks = [&]() {                     // chunks 0..NSET-1 of a tile: the same images for every tile
+    auto request_first_chunks = [&](bool rgb_first) {       // chunks 0..NSET-1 of a pass: the same images for every tile
+        if (MS && rgb_first) {                              // the RGB pass's two chunks travel in sets 2, 3; source 0's chunks 2, 3 follow
+            request_chunk(0);
+            request_chunk(1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < WPT; ++i)
+                    wreg[2 + c][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_wlr, t * 16, c * X3_CHUNK + i * 4096, 0));
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NSET; ++c) request_chunk(c);
     };
+    want_lr = has_lr;
     request_tile(tile, true);
-    request_first_chunks();
+    request_first_chunks(has_lr);
 
     for (;;) {
         unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0;
         if (DBG) dbg_a = __builtin_amdgcn_s_memtime();
         const int ty0 = (tile / tiles_x) * THX, tx0 = (tile % tiles_x) * TW;
+        const int next = tile + per;
+        const bool has_next = next < band_hi;
+        // ---- K loop: chunk c (one 32-deep k-step) from ring slot c % 3: hi*hi -> acc_hi, lo*hi + hi*lo -> acc_lo
+        f32x4 acc_hi[2][NTW], acc_lo[2][NTW];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                acc_hi[r][j] = (f32x4)(0.f);
+                acc_lo[r][j] = (f32x4)(0.f);
+            }
+        auto fold = [&](bool with_bias) {          // acc_hi <- ((acc_hi + acc_lo / 2048) [+ bias]) [* gamma]; acc_lo <- 0
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const f32x4 v = acc_hi[r][j] + acc_lo[r][j] * X3_INV;
+                    acc_hi[r][j] = with_bias ? (v + bco[j]) * gco[j] : v;
+                    acc_lo[r][j] = (f32x4)(0.f);
+                }
+        };
+        f32x4 res4[EIT];                                     // set at chunk RQR of every pass (zeros but in the last one): not live across passes
+        // ---- MS with the RGB frame: its 9 x 4 (3 + a zero) channels are K = 36 of two 32-deep chunks, contracted in front of the 64-channel
+        //      sources from a 16-byte-per-pixel halo of its own.  Short (48 MFMAs per wave): no software pipeline.
+        if (MS && has_lr) {
+            if (t < ROWS * PW) {
+                const f32x4 xc = clamp_h(lrreg);
+                const h4 hi = __builtin_convertvector(xc, h4);
+                *reinterpret_cast<h4*>(sL + t * 16) = hi;
+                *reinterpret_cast<h4*>(sL + t * 16 + 8) = __builtin_convertvector((xc - __builtin_convertvector(hi, f32x4)) * X3_SCALE, h4);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) *reinterpret_cast<f32x4*>(sR + c * X3_CHUNK + (t + 256 * i) * 16) = wreg[2 + c][i];
+            lds_barrier();
+            request_chunk(2);            // sets 2, 3 are free again: source 0's chunks 2, 3 (r_w is source 0's image here)
+            request_chunk(3);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                h8 xr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const char* bp = sL + ((2 * wrow + (u & 1)) * PW + lm) * 16 + (u >> 1) * 8;
+                    const h4 t0 = *reinterpret_cast<const h4*>(bp + rgb_off[kh][0]);
+                    const h4 t1 = *reinterpret_cast<const h4*>(bp + rgb_off[kh][1]);
+                    xr[u] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const char* bl = sR + kh * X3_CHUNK + (S4 ? 2 * wn + j : j) * UNIT + lane * 16;
+                    const h8 bh = *reinterpret_cast<const h8*>(bl), bo = *reinterpret_cast<const h8*>(bl + 4 * UNIT);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        acc_hi[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[r], bh, acc_hi[r][j], 0, 0, 0);
+                        acc_lo[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[2 + r], bh, acc_lo[r][j], 0, 0, 0);
+                        acc_lo[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[r], bo, acc_lo[r][j], 0, 0, 0);
+                    }
+                }
+            }
+            lds_barrier();               // ring slots 0, 1 are read: source 0's first chunks may overwrite them
+        }
+        // ---- MS: one pass per 64-channel source, all into the same accumulators (a conv over the virtual concat, iconvsr_ipb_par.py:90,125,
+        //      as ONE K = nsrc x 576 contraction); a single pass otherwise.  During pass p the halo of pass p + 1 (or of the next
+        //      tile's pass 0) and its first weight chunks are requested, exactly as a single-source tile requests the next tile's.
+        const int npass = MS ? a.nsrc : 1;
+#pragma nounroll
+        for (int pass = 0;; ++pass) {
+        const bool last = pass + 1 == npass;
+        const int nx_tile = last ? (has_next ? next : tile) : tile;
+        const bool nx_live = last ? has_next : true;
+        if (MS) {       // both descriptors are rebuilt in every pass (nothing loop-carried: a descriptor phi would leave the scalar registers)
+            // (static indices only: a run-time index into the kernel arguments would move them to scratch)
+            r_src = make_rsrc(uniform_ptr(last ? a.src : (pass == 0 ? a.src2[0] : a.src2[1])), map_bytes);        // whose halo this pass requests
+            r_w = make_rsrc(uniform_ptr(pass == 0 ? a.w : (pass == 1 ? a.w2[0] : a.w2[1])), 18u * X3_CHUNK);  // whose chunks it streams
+        }
+        want_lr = has_lr && last;
         // ---- fp32 halo -> the split A tile: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048); chunks 0, 1 -> ring
 #pragma unroll
         for (int k = 0; k < NREQ; ++k) {
@@ -228,32 +359,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             }
         }
         lds_barrier();
-        const int next = tile + per;
-        const bool has_next = next < band_hi;
         if (DBG) dbg_b = __builtin_amdgcn_s_memtime();
 
-        // ---- K loop: chunk c (one 32-deep k-step) from ring slot c % 3: hi*hi -> acc_hi, lo*hi + hi*lo -> acc_lo
-        f32x4 acc_hi[2][NTW], acc_lo[2][NTW];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                acc_hi[r][j] = (f32x4)(0.f);
-                acc_lo[r][j] = (f32x4)(0.f);
-            }
-        auto fold = [&](bool with_bias) {          // acc_hi <- ((acc_hi + acc_lo / 2048) [+ bias]) [* gamma]; acc_lo <- 0
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const f32x4 v = acc_hi[r][j] + acc_lo[r][j] * X3_INV;
-                    acc_hi[r][j] = with_bias ? (v + bco[j]) * gco[j] : v;
-                    acc_lo[r][j] = (f32x4)(0.f);
-                }
-        };
-        f32x4 res4[EIT];
-#pragma unroll
-        for (int i = 0; i < EIT; ++i) res4[i] = (f32x4)(0.f);
         // fragments: A of a chunk = [hi row 0, hi row 1, lo row 0, lo row 1]; B of (chunk, N tile j) = (hi, lo); chunk units in the
         // ring slot: [hi N0..N3, lo N0..N3]
         auto load_a = [&](int c, int u) {                   // c, u compile-time after unrolling
@@ -277,20 +384,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             // (HBM, ~2.5 us) ahead of a weight chunk (L2) would hold the chunk back.  Residual rows / partial sums of THIS tile first
             // (the epilogue needs them); the halo of the NEXT tile is requested behind the loop.
             if (c == RQR) {
-                if (!PAR) {
 #pragma unroll
-                    for (int i = 0; i < EIT; ++i) {       // the wave's pixel p = ep + PPI i: row p >> 4, column p & 15
-                        const int p = ep + PPI * i, gx = tx0 + (p & 15);
-                        const unsigned ro = ((unsigned)(ty0 + 2 * wrow + (p >> 4)) * (unsigned)W + (unsigned)gx) * 256u +
-                                            (unsigned)wn * 128u + (unsigned)ec * 16u;
-                        res4[i] = buf_load4(r_res, gx < W ? ro : OOB);
-                    }
+                for (int i = 0; i < EIT; ++i) {           // the wave's pixel p = ep + PPI i: row p >> 4, column p & 15
+                    const int p = ep + PPI * i, gx = tx0 + (p & 15);
+                    const unsigned ro = ((unsigned)(ty0 + 2 * wrow + (p >> 4)) * (unsigned)W + (unsigned)gx) * 256u +
+                                        (unsigned)wn * 128u + (unsigned)ec * 16u;
+                    if (PAR) res4[i] = (f32x4)(0.f);
+                    else res4[i] = buf_load4(r_res, (last & (gx < W)) ? ro : OOB);     // (not the last pass: out of range, zeros)
                 }
             }
             // the next tile's halo: requested where registers are free -- the weight sets of chunks 14..17 are dead once written to
             // the ring (two chunks ahead), so rows [0,4) can leave at chunk 14, [4,6) at 15, [6,8) at 16; the rest follows behind the
             // loop.  (All of it behind the loop: the epilogue's stores queue behind 20 loads in the CU's memory pipe, +2 k cycles.)
-            if (!PAR && c >= 14 && c <= 16) request_tile_part(has_next ? next : tile, has_next, c - 14);
+            if (!PAR && c >= 14 && c <= 16) request_tile_part(nx_tile, nx_live, c - 14);
             h8 xa[4] = {fa[0], fa[1], fa[2], fa[3]};
             if (PAR && c >= 18) {
                 if (c == 18) fold(true);                   // (conv + bias) * gamma BEFORE the 1x1 partition branches
@@ -363,8 +469,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         // the next halo only now: inside the loop its 48 registers do not fit beside the fragments of the 16x16x32 pipeline (23 spills),
         // and the epilogue is long enough to cover the latency (the branch variant always requested it here: same prologue time)
         if (PAR) request_tile(has_next ? next : tile, has_next);
-        else request_tile_part(has_next ? next : tile, has_next, 3);
-        request_first_chunks();          // every set is free again; the latency hides behind the epilogue
+        else request_tile_part(nx_tile, nx_live, 3);
+        if (MS) r_w = make_rsrc(uniform_ptr(last ? a.w : (pass == 0 ? a.w2[0] : a.w2[1])), 18u * X3_CHUNK);        // the next pass's weights
+        request_first_chunks(has_lr && last);     // every set is free again; the latency hides behind the epilogue (or the next pass's split)
+        if (last) break;
+        }                                // pass loop
         fold(!PAR || ncr == 18);         // PAR with branches: bias / gamma went in before them; otherwise here
 
         // ---- epilogue: transpose through the dead A tile, [+ partial sum], activation, [+ residual], whole pixel rows to HBM
@@ -435,10 +544,11 @@ __global__ __launch_bounds__(256) void f16x3_image_kernel(const float* __restric
     d[4 * 512] = lo;
 }
 
-template <bool PAR, bool DBG, bool S4>
+template <bool PAR, bool DBG, bool S4, bool MS = false>
 int launch_x3_t(const X3Args& xa, hipStream_t stream) {
-    auto kern = conv3x3_f16x3_kernel<PAR, DBG, S4>;
-    constexpr int lds = (S4 ? 4 + 2 : TH + 2) * XRSB + XPARK + X3_RING * X3_CHUNK;
+    auto kern = conv3x3_f16x3_kernel<PAR, DBG, S4, MS>;
+    constexpr int lds = (S4 ? 4 + 2 : TH + 2) * XRSB + XPARK + (MS ? (S4 ? 4 + 2 : TH + 2) * PW * 16 : 0) + X3_RING * X3_CHUNK;
+    static_assert(2 * lds <= 160 * 1024, "two blocks per CU");
     static PnpPerDevice once;
     const hipError_t attr_err = once.run([&](int, int&) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -454,10 +564,10 @@ int launch_x3_t(const X3Args& xa, hipStream_t stream) {
 
 // frames with at most one 8x16 tile per CU run on 4x16 tiles -- twice the blocks, half the work each.  Measured: 128x128 (128
 // tiles) 2240 -> 2888 frames/s; 180x320 (460 tiles, three clips) loses 9 % on them and stays on 8x16.
-template <bool PAR, bool DBG>
+template <bool PAR, bool DBG, bool MS = false>
 int launch_x3(const X3Args& xa, hipStream_t stream) {
     const int tiles8 = ((xa.W + TW - 1) / TW) * ((xa.H + TH - 1) / TH);
-    return tiles8 <= 256 ? launch_x3_t<PAR, DBG, true>(xa, stream) : launch_x3_t<PAR, DBG, false>(xa, stream);
+    return tiles8 <= 256 ? launch_x3_t<PAR, DBG, true, MS>(xa, stream) : launch_x3_t<PAR, DBG, false, MS>(xa, stream);
 }
 
 }  // namespace
@@ -482,6 +592,8 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         const unsigned pix = (unsigned)a.out_cstride * 4u;
         for (int y = 0; y < ny; ++y) {
             X3Args x;
+            memset(&x, 0, sizeof(x));
+            x.nsrc = 1;
             x.src = a.src[0];
             x.w = reinterpret_cast<const _Float16*>(a.wsrc_h[0]) + 2 * (long)y * a.w_ystride;     // split image: 2 halfs per float
             x.wpar = nullptr;
@@ -519,7 +631,8 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         else wide[nwide++] = s;
     }
     bool have_partial = false;
-    if (lr_idx >= 0) {
+    const bool fold_lr = lr_idx >= 0 && a.wsrc_h[lr_idx] && !a.dbg;       // the RGB frame inside the MS launch (its split image exists)
+    if (lr_idx >= 0 && !fold_lr) {
         ConvArgs r = a;
         r.prec = 0;
         r.nsrc = 1;
@@ -533,9 +646,40 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         if (rc) return rc;
         have_partial = true;
     }
+    if ((nwide > 1 || fold_lr) && !a.dbg) {
+        // all 64-channel sources in ONE launch (MS kernel): one K = nwide x 576 contraction per tile, no partial sums through HBM
+        // between the sources; the RGB link's partial sums (if any) come in as the pre-activation residual
+        X3Args x;
+        memset(&x, 0, sizeof(x));
+        x.nsrc = nwide;
+        x.src = a.src[wide[0]];
+        x.w = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[0]]);
+        for (int k = 1; k < nwide; ++k) {
+            x.src2[k - 1] = a.src[wide[k]];
+            x.w2[k - 1] = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]);
+        }
+        if (fold_lr) {
+            x.lr4 = a.src[lr_idx];
+            x.wlr = reinterpret_cast<const _Float16*>(a.wsrc_h[lr_idx]);
+        }
+        x.bias = have_partial ? nullptr : a.bias;
+        x.residual = have_partial ? a.out : (nwide == 1 ? a.residual : nullptr);
+        x.res_pre = have_partial ? 1 : 0;
+        x.out = a.out;
+        x.H = a.H;
+        x.W = a.W;
+        x.act = a.act;
+        x.o_sy = (unsigned)a.W * 256u;
+        x.o_sx = 256u;
+        x.o_c0 = 0;
+        x.out_bytes = (unsigned)a.H * (unsigned)a.W * 256u;
+        return launch_x3<false, false, true>(x, stream);
+    }
     for (int k = 0; k < nwide; ++k) {
         const bool last = k == nwide - 1;
         X3Args x;
+        memset(&x, 0, sizeof(x));
+        x.nsrc = 1;
         x.src = a.src[wide[k]];
         x.w = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]);
         x.wpar = reinterpret_cast<const _Float16*>(a.wpar_h);

@@ -198,7 +198,9 @@ def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=N
             return p
         return f16x3_image(p)
 
-    x3 = [split(p, s.shape[2] == 64) for p, s in zip(packed_w, srcs)]
+    # the RGB frame's image is split too (k = 4 tap + channel: two 32-deep chunks): with it the whole conv is ONE launch; the fp32
+    # image still travels for the traced variant, where the RGB link stays on the exact fp32 kernel
+    x3 = [split(p) for p in packed_w]
     p_x3 = split(packed_w1x1)
     packed_w = [(_chk(p, 'packed_w') if p.dtype == torch.float32 else None) for p in packed_w]
     vp = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])

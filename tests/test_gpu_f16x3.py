@@ -89,9 +89,10 @@ def test_f16x3_small_magnitudes_keep_their_relative_accuracy(scale):
 
 @pytest.mark.parametrize('nwide', [1, 2, 3])
 @pytest.mark.parametrize('with_lr', [False, True])
-def test_f16x3_conv_virtual_concat_is_a_launch_chain(nwide, with_lr):
-    """input_conv over [lr(3), wide...]: the RGB frame on the exact fp32 kernel, then one split launch per 64-channel source;
-    partial sums through `out`, the activation on the last link."""
+def test_f16x3_conv_virtual_concat_is_one_launch(nwide, with_lr):
+    """input_conv over [lr(3), wide...] (iconvsr_ipb_par.py:90,125) in ONE launch of the multi-source kernel: the RGB frame as two
+    32-deep chunks in front, then one pass per 64-channel source into the same accumulators; 40x56 runs the 4x16-tile variant,
+    the 264x272 case below the 8x16 one.  (With a trace buffer the r03 launch chain runs instead: see the last assertion.)"""
     from pnp_vcve_amd import ops
     h, w = 40, 56
     cin = (3 if with_lr else 0) + 64 * nwide
@@ -108,6 +109,34 @@ def test_f16x3_conv_virtual_concat_is_a_launch_chain(nwide, with_lr):
     packed = ([ops.pack_conv3x3(wg, 0, 3)] if with_lr else []) + [ops.pack_conv3x3(wg, c0 + 64 * j, 64) for j in range(nwide)]
     out = ops.conv3x3_f16x3(srcs, packed, bias=G(b), act=2)
     assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < TOL_CONV / 2
+    # the traced variant keeps the launch chain (RGB link on the exact fp32 kernel, partial sums through `out`): same result to
+    # the last few bits, not bit for bit (one long accumulation vs one per source)
+    dbg = torch.zeros(512 * 8, dtype=torch.int64, device=dev())
+    chain = ops.conv3x3_f16x3(srcs, packed, bias=G(b), act=2, trace=dbg)
+    assert maxdiff(chain, out.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize('nwide,with_lr', [(1, True), (2, True), (3, True), (3, False)])
+def test_f16x3_multi_source_kernel_on_8x16_tiles_with_ragged_edges(nwide, with_lr):
+    """the same conv on a frame of more than 256 8x16 tiles (264 x 272: ragged right column of tiles, 33 x 17 = 561 tiles) against fp64"""
+    from pnp_vcve_amd import ops
+    h, w = 264, 272
+    cin = (3 if with_lr else 0) + 64 * nwide
+    lr = gu.syn.uniform(37, 'lr', (1, 3, h, w), 0, 1)
+    wides = [gu.syn.uniform(37, f's{j}', (1, 64, h, w), -1, 1) for j in range(nwide)]
+    wt = gu.syn.uniform(37, f'w{cin}', (64, cin, 3, 3), -0.05, 0.05)
+    b = gu.syn.uniform(37, 'b', (64,), -0.1, 0.1)
+    cat = np.concatenate(([lr] if with_lr else []) + wides, axis=1)
+    ref = F.leaky_relu(F.conv2d(D(cat), D(wt), D(b), padding=1), 0.1)
+    lr4 = np.concatenate([lr, np.zeros((1, 1, h, w), np.float32)], axis=1)
+    srcs = ([ops.nchw_to_nhwc(G(lr4))[0]] if with_lr else []) + [ops.nchw_to_nhwc(G(s))[0] for s in wides]
+    wg = G(wt)
+    c0 = 3 if with_lr else 0
+    packed = ([ops.pack_conv3x3(wg, 0, 3)] if with_lr else []) + [ops.pack_conv3x3(wg, c0 + 64 * j, 64) for j in range(nwide)]
+    out = ops.conv3x3_f16x3(srcs, packed, bias=G(b), act=2)
+    assert maxdiff(ops.nhwc_to_nchw(out.unsqueeze(0)), ref) < TOL_CONV / 2
+    again = ops.conv3x3_f16x3(srcs, packed, bias=G(b), act=2)
+    assert torch.equal(again, out)
 
 
 def test_f16x3_conv_unsupported_shapes_are_refused_not_silently_rerouted():
