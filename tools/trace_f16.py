@@ -20,7 +20,19 @@ par = (torch.rand(3, h, w, device=dev) > 0.66).float() / 255.0
 bias = torch.randn(64, device=dev) * 0.1
 
 
+cls = torch.randint(0, 3, ((h + 7) // 8, (w + 7) // 8), device=dev)
+parb = torch.stack([(cls == j).float() for j in range(3)]).repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :h, :w].contiguous() / 255.0
+flags = ops.par_tile_flags(parb)
+gam = torch.rand(64, device=dev) + 0.5
+x16 = x.half()
+
+
 def run(trace=None):
+    if mode in ('front', 'front16'):       # the BAE front half as the pipeline runs it: fp16 `o` map out, block-class partition map + flags
+        return ops.conv3x3_f16_maps([x16 if mode == 'front16' else x], [pw], bias=bias, gamma=gam, packed_w1x1=p1, par=parb,
+                                    par_flags=flags, act=1, out_f16=True, trace=trace)
+    if mode == 'hr':                       # conv_hr: fp32 slot in, fp16 map out
+        return ops.conv3x3_f16_maps([x], [pw], bias=bias, act=2, out_f16=True, trace=trace)
     if mode == 'res':
         return ops.conv3x3([x], [pw], bias=bias, residual=x2, fp16=True, trace=trace)
     if mode == 'par':
