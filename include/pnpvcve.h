@@ -195,7 +195,9 @@ int pnp_pixel_shuffle_conv_f32(const float* x_dev, const float* packed_dev, int 
 /* Which of the three 1x1 partition branches (sr_backbone_utils.py:310-311, Sum_j par_j * conv1x1_j(x)) an 8x16 pixel tile
  * needs at all: par_dev (3,h,w) -> flags_dev[((w+15)/16) * ((h+7)/8)] ints, bit j set iff plane j is nonzero somewhere in
  * the tile.  pnp_generator_forward computes these once per frame; its persistent conv kernel skips a branch on tiles
- * where the plane is zero (exact zeros: bit-identical result).  Codec partition maps are one-hot per >= 8x8 block. */
+ * where the plane is zero (exact zeros: bit-identical result).  Codec partition maps are one-hot per >= 8x8 block.
+ * Bit 3 + j: every value of plane j in the tile is 0 or exactly 1/255 (what loading_ipb.py writes: uint8 one-hot / 255.) -- the
+ * split-fp16 kernel then contracts a masked operand with weights scaled at pack time; consumers of bits 0..2 mask with 7. */
 int pnp_par_tile_flags_f32(const float* par_dev, int* flags_dev, int h, int w, void* stream);
 
 /* The same op with fp16 MFMA operands (fp32 sources, accumulation and output): packed_w_f16 are fp16 images

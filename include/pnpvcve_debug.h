@@ -58,7 +58,10 @@ int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs_dev, const int* src_
                          const float* const* packed_w_f32_dev, const void* const* packed_w_x3_dev, const float* bias_dev,
                          const float* gamma_dev, const void* packed_w1x1_x3_dev, const float* par_dev,
                          const int* par_flags_dev, const float* residual_dev, int act, float* out_dev, int h, int w,
-                         void* trace_dev, void* stream);
+                         int w1x1_scaled, void* trace_dev, void* stream);
+/* w1x1_scaled != 0: packed_w1x1_x3_dev holds 12 split chunks -- the three branch images and then the same three scaled by 1/255
+ * (what pnp_generator_pack lays out) -- and tiles whose partition values are all 0 or exactly 1/255 (par_flags bits 3..5) contract
+ * the branches with the scaled images and a masked A operand instead of re-splitting par_j(pixel) * x.  trace_dev may be NULL. */
 
 /* pnp_mv_warp_nhwc_f32 writing its result as an fp16 (h,w,c) map (saturating round-to-nearest-even of the fp32 value). */
 int pnp_mv_warp_nhwc_f16out(const float* feat_dev, const float* flow_x_dev, const float* flow_y_dev, void* out16_dev, int h,

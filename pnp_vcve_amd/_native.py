@@ -84,7 +84,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     'pnp_conv3x3_f16x3_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'pnp_conv3x3_f32_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p]),

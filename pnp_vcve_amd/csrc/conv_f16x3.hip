@@ -23,6 +23,10 @@
 #include "conv_mfma.h"
 #include "f16_util.h"
 #include <string.h>
+#include <utility>
+
+template <int V> struct X3Tag { static constexpr int v = V; };                  // a compile-time int as a lambda argument
+template <int... I, class F> __device__ __forceinline__ void x3_static_for(std::integer_sequence<int, I...>, F&& f) { (f(X3Tag<I>{}), ...); }
 
 namespace {
 
@@ -35,7 +39,8 @@ constexpr float X3_SCALE = 2048.f, X3_INV = 1.f / 2048.f;
 struct X3Args {
     const float* src;            // NHWC64 fp32
     const _Float16* w;           // split image (launch_f16x3_image): 18 chunks of 8 units
-    const _Float16* wpar;        // 6 chunks (branch, k-half) or nullptr
+    const _Float16* wpar;        // 6 chunks (branch, k-half) or nullptr; wpar_scaled: 6 more, the same images x PNP_PAR_UNIT
+    int wpar_scaled;
     const float* par;
     long par_plane;
     const int* par_flags;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     // weight chunks through descriptors too: voffset = 16 t for every load, the chunk in the SCALAR offset -- no per-chunk
     // 64-bit address pairs for the compiler to hoist out of the tile loop and spill
     __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.w, 18u * X3_CHUNK);       // the weights whose chunks are requested next (MS: per pass)
-    const __amdgpu_buffer_rsrc_t r_wp = make_rsrc(PAR ? (const void*)a.wpar : (const void*)a.w, 6u * X3_CHUNK);
+    const __amdgpu_buffer_rsrc_t r_wp = make_rsrc(PAR ? (const void*)a.wpar : (const void*)a.w, (PAR && a.wpar_scaled ? 12u : 6u) * X3_CHUNK);
     const bool has_lr = MS && a.lr4 != nullptr;
     const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(has_lr ? (const void*)a.lr4 : (const void*)a.src, has_lr ? (unsigned)H * (unsigned)W * 16u : 0);
     const __amdgpu_buffer_rsrc_t r_wlr = make_rsrc(has_lr ? (const void*)a.wlr : (const void*)a.w, 2u * X3_CHUNK);
@@ -160,17 +165,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         gco[j] = a.gamma ? a.gamma[wn * 32 + j * 16 + lm] : 1.f;
     }
     const int a_off = 2 * wrow * XRSB + lm * XPSB + 16 * lg;         // + row r, tap (dy, dx), plane (128), k-half (64)
-    // per-thread halo bases (see above)
-    const int hp = t >> 4, hcs = t & 15;
-    const int h2r = t >> 5, h2x = 16 + ((t >> 4) & 1);
-    const unsigned g_main = (unsigned)hp * 256u + (unsigned)hcs * 16u;                       // + (row k) * row_bytes
-    const unsigned g_side = (unsigned)h2r * row_bytes + (unsigned)h2x * 256u + (unsigned)hcs * 16u;   // + 8 rows for request 11
-    char* const l_main = smem + hp * XPSB + hcs * 8;                                        // + k * XRSB
-    // request 11 covers rows 8, 9 only (t < 64): the other threads park their (zero) value behind the tile
-    char* const l_side = smem + h2r * XRSB + h2x * XPSB + hcs * 8;
-    char* const l_park = smem + ROWS * XRSB + hcs * 8;
-    char* const l_side11 = t < 64 ? l_side + 8 * XRSB : l_park;
-    char* const l_side6 = t < 192 ? l_side : l_park;          // S4: the one side request covers rows 0..5
+    // per-thread halo bases (see above), from a thread index tq
+    struct HaloBases {
+        int hp, hcs, h2r, h2x;
+        unsigned g_main, g_side;
+    };
+    auto halo_bases = [&](int tq) {
+        HaloBases b;
+        b.hp = tq >> 4, b.hcs = tq & 15;
+        b.h2r = tq >> 5, b.h2x = 16 + ((tq >> 4) & 1);
+        b.g_main = (unsigned)b.hp * 256u + (unsigned)b.hcs * 16u;                                        // + (row k) * row_bytes
+        b.g_side = (unsigned)b.h2r * row_bytes + (unsigned)b.h2x * 256u + (unsigned)b.hcs * 16u;         // + 8 rows for request 11
+        return b;
+    };
 
     // ---- requests that travel ahead of their tile: the fp32 halo (12 x 16 B per thread) and its partition values / flags
     f32x4 areg[NREQ];
@@ -182,8 +189,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     auto request_tile_part = [&](int tl, bool live, int part) {     // !live: every offset out of range (loads return 0, no branch)
         const int ty0 = (tl / tiles_x) * THX, tx0 = (tl % tiles_x) * TW;
         const unsigned hbase = (unsigned)((ty0 - 1) * W + (tx0 - 1)) * 256u;
-        const bool ok_main = live & ((unsigned)(tx0 - 1 + hp) < (unsigned)W);    // rows outside the image leave the descriptor by themselves
-        const bool ok_side = live & ((unsigned)(tx0 - 1 + h2x) < (unsigned)W);
+        const HaloBases hb = halo_bases(t);
+        const unsigned g_main = hb.g_main, g_side = hb.g_side;
+        const bool ok_main = live & ((unsigned)(tx0 - 1 + hb.hp) < (unsigned)W);    // rows outside the image leave the descriptor by themselves
+        const bool ok_side = live & ((unsigned)(tx0 - 1 + hb.h2x) < (unsigned)W);
         constexpr int K1 = S4 ? 2 : 4, K2 = S4 ? 3 : 6, K3 = S4 ? 4 : 8;
         const int k0 = part == 0 ? 0 : (part == 1 ? K1 : (part == 2 ? K2 : K3));
         const int k1 = part == 0 ? K1 : (part == 1 ? K2 : (part == 2 ? K3 : ROWS));
@@ -220,12 +229,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         for (int part = 0; part < 4; ++part) request_tile_part(tl, live, part);
     };
     int ncr = NC, bs0 = 0, bs1 = 1, bs2 = 2;
+    // PAR, per tile: every partition value of the needed planes is 0 or exactly PNP_PAR_UNIT (flag bits 3..5: what the reference's loader
+    // writes) and the scaled branch images are there -> the branch chunks contract a MASKED A operand with weights scaled at pack time
+    // instead of re-splitting par_j(pixel) * x per fragment (~180 vector instructions per chunk and wave: the front half's bound)
+    bool fast = false;
     auto bsel = [&](int j) { return j == 0 ? bs0 : (j == 1 ? bs1 : bs2); };
     f32x4 wreg[NSET][WPT];
     auto request_chunk = [&](int c) {                       // c < 18 compile-time, branch chunks via bsel; into set c % NSET
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int so = (c < 18 ? c : bsel((c - 18) >> 1) * 2 + (c & 1)) * X3_CHUNK + i * 4096;
+            const int so = (c < 18 ? c : bsel((c - 18) >> 1) * 2 + (c & 1) + (fast ? 6 : 0)) * X3_CHUNK + i * 4096;
             wreg[c % NSET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c < 18 ? r_w : r_wp, t * 16, so, 0));
         }
     };
@@ -329,6 +342,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         }
         want_lr = has_lr && last;
         // ---- fp32 halo -> the split A tile: hi = fp16(x) (saturating), lo = fp16((x - hi) * 2048); chunks 0, 1 -> ring
+        const HaloBases hs = halo_bases(t);
+        char* const l_main = smem + hs.hp * XPSB + hs.hcs * 8;                                        // + k * XRSB
+        // request 11 covers rows 8, 9 only (t < 64): the other threads park their (zero) value behind the tile
+        char* const l_side = smem + hs.h2r * XRSB + hs.h2x * XPSB + hs.hcs * 8;
+        char* const l_park = smem + ROWS * XRSB + hs.hcs * 8;
+        char* const l_side11 = t < 64 ? l_side + 8 * XRSB : l_park;
+        char* const l_side6 = t < 192 ? l_side : l_park;          // S4: the one side request covers rows 0..5
 #pragma unroll
         for (int k = 0; k < NREQ; ++k) {
             // x saturates at +-65504 as a WHOLE: the remainder is taken from the clamped value, so it is at most half an fp16 ulp
@@ -349,8 +369,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         if (PAR) {
             ncr = NC;
             bs0 = 0, bs1 = 1, bs2 = 2;
+            fast = false;
             if (a.par_flags) {
-                const int f0 = __builtin_amdgcn_readfirstlane(pfn) & 7;
+                const int fraw = __builtin_amdgcn_readfirstlane(pfn);
+                const int f0 = fraw & 7;
+                fast = a.wpar_scaled != 0 && ((fraw >> 3) & f0) == f0;
                 const int f1 = f0 & (f0 - 1), f2 = f1 & (f1 - 1);
                 ncr = 18 + 2 * __builtin_popcount(f0);
                 bs0 = f0 ? __builtin_ctz(f0) : 0;
@@ -376,10 +399,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         fb[0] = load_b(0, 0, 0);
         fb[1] = load_b(0, 0, 1);
         fbn[0] = fb[0], fbn[1] = fb[1];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (PAR && c >= 18 && c >= ncr) break;
-            if (c + NSET < NC && (!PAR || c + NSET < ncr)) request_chunk(c + NSET);
+        // one chunk, as a generic lambda over compile-time (chunk, FAST): the 3x3 chunks run once, the branch chunks exist in TWO copies
+        // picked per tile -- a run-time "fast" inside the chunk would put the operand preparation into blocks of its own in front of the
+        // quarter's MFMAs instead of into their gaps
+        auto chunk = [&](auto c_tag, auto fast_tag) __attribute__((always_inline)) {
+            constexpr int c = decltype(c_tag)::v;
+            constexpr bool FAST = decltype(fast_tag)::v != 0;
+            // (branch chunks are requested and written to the ring whether or not the tile runs them: a run-time guard here would cut
+            //  chunks 14.. into basic blocks and the dealt schedule with them; an unneeded chunk is 8 KiB from L2 into a free slot)
+            if (c + NSET < NC) request_chunk(c + NSET);
             // After the last 3x3 chunk request (chunk 17, at the top of chunk 13): memory returns in order, so a tile-data request
             // (HBM, ~2.5 us) ahead of a weight chunk (L2) would hold the chunk back.  Residual rows / partial sums of THIS tile first
             // (the epilogue needs them); the halo of the NEXT tile is requested behind the loop.
@@ -401,16 +429,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             if (PAR && c >= 18) {
                 if (c == 18) fold(true);                   // (conv + bias) * gamma BEFORE the 1x1 partition branches
                 const int bi = bsel((c - 18) >> 1);
+                // the branch's plane at the lane's two pixels, picked by ARITHMETIC (x 1 / x 0 on wave-uniform factors: exact for
+                // finite maps): a select of vector registers on a uniform condition is lowered to branches, which cut the chunk into
+                // basic blocks and the dealt schedule with them
+                const float m0 = bi == 0 ? 1.f : 0.f, m1 = bi == 1 ? 1.f : 0.f, m2 = bi == 2 ? 1.f : 0.f;
+                const float pjr[2] = {pv[0][0] * m0 + pv[1][0] * m1 + pv[2][0] * m2, pv[0][1] * m0 + pv[1][1] * m1 + pv[2][1] * m2};
                 // par_j(pixel) * x as a split number again: (hi + lo / 2048) is exact in fp32 (22 bits), one fp32 rounding for the
                 // product, then the same split as the halo (saturating as a whole)
                 typedef float f32x8 __attribute__((ext_vector_type(8)));
+                if (FAST) {
+                    // pj is 0 or 1/255 and the weights carry the 1/255: the operand is x or nothing.  As a bit mask (one v_cndmask + 8
+                    // v_and per row): a per-lane select on the fragments compiles to divergent branches, which cut the chunk into
+                    // basic blocks and the dealt schedule with it (measured: K loop 24.5 k -> 23.3 k instead of -> 17 k)
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const float pj = bi == 0 ? pv[0][r] : (bi == 1 ? pv[1][r] : pv[2][r]);
-                    f32x8 v = (__builtin_convertvector(fa[r], f32x8) + __builtin_convertvector(fa[2 + r], f32x8) * X3_INV) * pj;
-                    v = __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x8)(-65504.f)), (f32x8)(65504.f));
-                    xa[r] = __builtin_convertvector(v, h8);
-                    xa[2 + r] = __builtin_convertvector((v - __builtin_convertvector(xa[r], f32x8)) * X3_SCALE, h8);
+                    for (int r = 0; r < 2; ++r) {
+                        const unsigned mk = pjr[r] != 0.f ? 0xffffffffu : 0u;
+                        xa[r] = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, fa[r]) & mk);
+                        xa[2 + r] = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, fa[2 + r]) & mk);
+                    }
+                } else {
+                    // general maps: par_j(pixel) * x as a split number again -- (hi + lo / 2048) is exact in fp32 (22 bits), one fp32
+                    // rounding for the product, then the same split as the halo (saturating as a whole).  SCALAR arithmetic on purpose
+                    // (and the file is built with -fno-slp-vectorize): with the same formula on float vectors hipcc emits v_pk_*_f32,
+                    // whose results, converted and fed to the MFMAs of the same dealt basic block, came out wrong and run-to-run
+                    // varying (r04: 7e-4 on 40 % of the pixels; the fast path above and every other kernel were bit-stable) -- the
+                    // signature of round 3's DCN hazard: packed fp32 vector arithmetic next to MFMA operands.
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const float pj = pjr[r];
+                        h8 nh, nl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float v = ((float)fa[r][e] + (float)fa[2 + r][e] * X3_INV) * pj;
+                            v = fminf(fmaxf(v, -65504.f), 65504.f);
+                            const _Float16 hh = (_Float16)v;
+                            nh[e] = hh;
+                            nl[e] = (_Float16)((v - (float)hh) * X3_SCALE);
+                        }
+                        xa[r] = nh;
+                        xa[2 + r] = nl;
+                    }
                 }
             }
             const bool more = c + 1 < NC;                   // (a branch tile that stops early reads a stale ring slot: unused)
@@ -435,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                 for (int r = 0; r < 2; ++r) acc_lo[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[2 + r], fb[0], acc_lo[r][q], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) acc_lo[r][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[r], fb[1], acc_lo[r][q], 0, 0, 0);
-                if (q == (S4 ? 0 : 1) && c + 2 < NC && (!PAR || c + 2 < ncr)) {
+                if (q == (S4 ? 0 : 1) && c + 2 < NC) {
                     // ring write of chunk c + 2 (into the slot of chunk c - 1, which every wave left before the previous barrier)
                     // in the MIDDLE of the chunk: the barrier below then waits for it, not for the fragment reads behind it
                     char* d = sR + ((c + 2) % X3_RING) * X3_CHUNK;
@@ -464,6 +523,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             if (c + 1 >= NC) lds_barrier();
             else if (S4) asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(6)\n\ts_barrier" ::: "memory");
+        };
+        x3_static_for(std::make_integer_sequence<int, 18>{}, [&](auto c_tag) __attribute__((always_inline)) { chunk(c_tag, X3Tag<0>{}); });
+        if constexpr (PAR) {
+            auto branches = [&](auto fast_tag) __attribute__((always_inline)) {        // ncr = 18 + 2 x (branches this tile runs)
+                if (ncr > 18) {
+                    chunk(X3Tag<18>{}, fast_tag);
+                    chunk(X3Tag<19>{}, fast_tag);
+                    if (ncr > 20) {
+                        chunk(X3Tag<20>{}, fast_tag);
+                        chunk(X3Tag<21>{}, fast_tag);
+                        if (ncr > 22) {
+                            chunk(X3Tag<22>{}, fast_tag);
+                            chunk(X3Tag<23>{}, fast_tag);
+                        }
+                    }
+                }
+            };
+            if (fast) branches(X3Tag<1>{});
+            else branches(X3Tag<0>{});
         }
         if (DBG) dbg_c = __builtin_amdgcn_s_memtime();
         // the next halo only now: inside the loop its 48 registers do not fit beside the fragments of the 16x16x32 pipeline (23 spills),
@@ -683,6 +761,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         x.src = a.src[wide[k]];
         x.w = reinterpret_cast<const _Float16*>(a.wsrc_h[wide[k]]);
         x.wpar = reinterpret_cast<const _Float16*>(a.wpar_h);
+        x.wpar_scaled = a.wpar_h_scaled;
         x.par = a.par;
         x.par_plane = a.par_plane;
         x.par_flags = a.par_flags;

@@ -13,6 +13,7 @@ struct ConvArgs {
     const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo
                             // interleaved, twice the halfs; conv_f16x3.hip launch_f16x3_image)
     const void* wpar_h;
+    int wpar_h_scaled;      // prec == 2: wpar_h holds 12 split chunks -- the three branch images, then the same three scaled by PNP_PAR_UNIT
     int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
                             // 2 split fp16 (hi + lo / 2048, three MFMAs per product, fp32-level results; where conv_f16x3_eligible)
     int src_f16, out_f16;   // prec 1, out_mode 0: bit s of src_f16: src[s] IS an fp16 NHWC64 map (the mirror its producer
@@ -20,7 +21,7 @@ struct ConvArgs {
     void* out16;            // prec 1, out_mode 0, !out_f16: additionally write an fp16 NHWC64 mirror of the fp32 output
     int no_multi16;         // 1: several fp16 sources are refused instead of running the one-launch input-conv kernel
     const float* par;       // 3 NCHW planes of the partition map, nullptr if wpar == nullptr
-    const int* par_flags;   // optional, one int per 8x16 tile (row-major): bit j set <=> plane j has a nonzero value in
+    const int* par_flags;   // optional, one int per 8x16 tile (row-major; consumers read bits 0..2 through `& 7`): bit j set <=> plane j has a nonzero value in
                             // the tile (launch_par_tile_flags).  The persistent kernel skips the 1x1 branches whose
                             // plane is zero over its whole tile -- exact zeros, bit-identical result for finite activations (a skipped
                             // 0 * inf would have been NaN).  nullptr: none skipped
@@ -109,7 +110,10 @@ static inline bool conv_f16x3_eligible(const ConvArgs& a, int cfg, int grid_y) {
 }
 int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream);
 
-// per-tile summary of a partition map for ConvArgs::par_flags (conv_persist.hip); flags: ((W+15)/16) * ((H+7)/8) ints
+// the partition value the reference's loader produces for an active plane: float32(1) / float32(255) (loading_ipb.py)
+#define PNP_PAR_UNIT (1.0f / 255.0f)
+// per-tile summary of a partition map for ConvArgs::par_flags (conv_persist.hip); flags: ((W+15)/16) * ((H+7)/8) ints;
+// bits 0..2: plane j has a nonzero value in the tile; bits 3..5: every value of plane j in the tile is 0 or PNP_PAR_UNIT
 // frames consecutive (3, H, W) maps -> frames consecutive flag arrays
 int launch_par_tile_flags(const float* par, long par_plane, int* flags, int frames, int H, int W, hipStream_t stream);
 

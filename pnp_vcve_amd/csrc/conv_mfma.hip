@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a) 
 
     // ---- which 1x1 partition branches this tile needs (flags are per 8x16 tile; a 4x16 tile uses its parent's)
     int par_need = a.wpar ? 7 : 0;
-    if (a.wpar && a.par_flags) par_need = a.par_flags[(ty0 >> 3) * ((W + 15) >> 4) + (tx0 >> 4)];
+    if (a.wpar && a.par_flags) par_need = a.par_flags[(ty0 >> 3) * ((W + 15) >> 4) + (tx0 >> 4)] & 7;
     const int par_cnt = (par_need & 1) + ((par_need >> 1) & 1) + ((par_need >> 2) & 1);
     const int par_j0 = (par_need & 1) ? 0 : ((par_need & 2) ? 1 : 2);
     const int par_j1 = ((par_need & 3) == 3) ? 1 : 2;

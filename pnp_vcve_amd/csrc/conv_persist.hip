@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_persist_kernel(const ConvArgs 
             // The 1x1 partition branches are a K extension whose A operand is x scaled by the branch's plane: a branch
             // whose plane is zero over the whole tile contributes exact zeros and is skipped (codec partition maps are
             // one-hot per >= 8x8 block, so an 8x16 tile needs 0..2 of the 3 branches; a P/B frame of random blocks 1.67).
-            const int need = a.par_flags ? a.par_flags[tile] : 7;                 // block-uniform (scalar load)
+            const int need = a.par_flags ? (a.par_flags[tile] & 7) : 7;           // block-uniform (scalar load)
             const int cnt = (need & 1) + ((need >> 1) & 1) + ((need >> 2) & 1);
             const int j0 = (need & 1) ? 0 : ((need & 2) ? 1 : 2);                 // first needed branch (branch 2 with an
             const int j1 = ((need & 3) == 3) ? 1 : 2;                             // all-zero plane if none); second; third = 2
@@ -416,6 +416,10 @@ __global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __rest
     for (int j = 0; j < 3; ++j) {
         const float v = in ? par[j * plane + (long)gy * W + gx] : 0.f;
         if (__syncthreads_or(v != 0.f)) bits |= 1 << j;
+        // bit 3 + j: every value of plane j in the tile is 0 or exactly 1/255 -- what the reference's loader writes
+        // (loading_ipb.py: one-hot uint8 planes / 255.).  The split-fp16 kernel then contracts the branch with weights scaled by
+        // 1/255 at pack time and a MASKED A operand instead of re-splitting par_j(pixel) * x per fragment (conv_f16x3.hip).
+        if (__syncthreads_and(v == 0.f || v == PNP_PAR_UNIT)) bits |= 8 << j;
     }
     if (threadIdx.x == 0) flags[tile] = bits;
 }

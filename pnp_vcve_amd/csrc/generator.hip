@@ -41,7 +41,7 @@ struct ParamInfo {
 struct BlockPk {
     int64_t conv1_img = -1;       // packed, static conv1 (one_layer)
     int64_t conv1_bias = -1;      // flat
-    int64_t w1x1 = -1;            // packed, 3 chunks
+    int64_t w1x1 = -1;            // packed, 3 chunks + 3 chunks scaled by PNP_PAR_UNIT (split-fp16 fast path on binary partition maps)
     int dyn_conv2 = -1, dyn_conv1 = -1;
 };
 
@@ -186,7 +186,7 @@ int build_layout(pnp_generator* g) {
             }
             static const char* k1[3] = {"conv16x16", "conv16x8", "conv8x8"};
             for (int j = 0; j < 3; ++j) g->f_1x1_w[b][i * 3 + j] = g->add_param(p + k1[j] + ".weight", {64, 64, 1, 1});
-            B.blocks[i].w1x1 = g->add_packed(3 * IMG_CHUNK);
+            B.blocks[i].w1x1 = g->add_packed(6 * IMG_CHUNK);      // conv16x16 / conv16x8 / conv8x8, then the same three x PNP_PAR_UNIT
         }
     }
     if (c.deform != 0) {
@@ -258,6 +258,7 @@ PackArgs plain_pack(const float* w, int cin_total, int ktaps, int kind, int cbas
     a.kind = kind;
     a.cbase = cbase;
     a.ntb = ntb;
+    a.scale = 1.f;
     a.dst = dst;
     return a;
 }
@@ -504,10 +505,10 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
                     plain_pack(flat + g->f_conv1_w[b][i], 64, 9, PACK_WIDE, 0, 2, 64, packed + K.conv1_img), 1, st);
                 if (rc) return rc;
             }
-            for (int j = 0; j < 3; ++j) {
-                rc = launch_pack_weights(plain_pack(flat + g->f_1x1_w[b][i * 3 + j], 64, 1, PACK_1X1, 0, 2, 64,
-                                                    packed + K.w1x1 + j * IMG_CHUNK),
-                                         1, st);
+            for (int j = 0; j < 6; ++j) {
+                PackArgs pa = plain_pack(flat + g->f_1x1_w[b][i * 3 + j % 3], 64, 1, PACK_1X1, 0, 2, 64, packed + K.w1x1 + j * IMG_CHUNK);
+                if (j >= 3) pa.scale = PNP_PAR_UNIT;
+                rc = launch_pack_weights(pa, 1, st);
                 if (rc) return rc;
             }
         }
@@ -620,6 +621,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         }
         a.wpar = q.wpar_;
         a.wpar_h = twin(q.wpar_);
+        a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
         a.par_flags = q.par_flags_;
         a.par_plane = (long)q.H * q.W;
@@ -766,6 +768,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 a.kind = PACK_WIDE;
                 a.cbase = 0;
                 a.ntb = 2;
+                a.scale = 1.f;
                 a.dst = W.mixw + (int64_t)u * g->ndyn * IMG_WIDE;
                 a.w_ystride = (int64_t)E * 64 * 64 * 9;
                 a.dst_ystride = IMG_WIDE;
@@ -1278,13 +1281,13 @@ int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs, const int* src_channel
                       const void* const* packed_w_x3, const float* bias, const float* gamma, const void* packed_w1x1_x3,
                       const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w, void* st) {
     return pnp_conv3x3_f16x3_ex(nsrc, srcs, src_channels, packed_w_f32, packed_w_x3, bias, gamma, packed_w1x1_x3, par, par_flags,
-                                residual, act, out, h, w, nullptr, st);
+                                residual, act, out, h, w, 0, nullptr, st);
 }
 
 int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w_f32,
                          const void* const* packed_w_x3, const float* bias, const float* gamma, const void* packed_w1x1_x3,
                          const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
-                         void* trace, void* st) {
+                         int w1x1_scaled, void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4 || !srcs || !src_channels || !packed_w_x3 || !out) return PNP_ERR_BAD_ARG;
     if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;      // 32-bit byte offsets into a map
     ConvArgs a;
@@ -1299,6 +1302,7 @@ int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs, const int* src_chan
         if (src_channels[s] == 4 && (s != 0 || !a.wsrc[s])) return PNP_ERR_BAD_ARG;    // the RGB frame: source 0, fp32 image
     }
     a.wpar_h = packed_w1x1_x3;
+    a.wpar_h_scaled = (packed_w1x1_x3 && w1x1_scaled) ? 1 : 0;
     a.par = par;
     a.par_flags = par_flags;
     a.par_plane = (long)h * w;

@@ -42,6 +42,7 @@ struct PackArgs {
     int kind;           // PACK_*
     int cbase;          // first input channel of this source inside the virtual concat
     int ntb;            // N tiles of 32 in the image (2 -> 64 channels, 1 -> 32)
+    float scale;        // every packed value is multiplied by this (1: plain; PNP_PAR_UNIT: the 1x1 branch images of the split-fp16 fast path)
     float* dst;         // 9 chunks (PACK_WIDE) or 1 chunk
     long w_ystride;     // blockIdx.y batching: floats between consecutive convs in w / dst
     long dst_ystride;

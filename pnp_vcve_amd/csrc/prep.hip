@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
             v = w[0];
         }
     }
-    a.dst[(long)blockIdx.y * a.dst_ystride + idx] = v;
+    a.dst[(long)blockIdx.y * a.dst_ystride + idx] = v * a.scale;        // (x 1.0f is exact)
 }
 
 __global__ void mix_bias_kernel(const float* __restrict__ b, const float* __restrict__ ew, float* __restrict__ out,

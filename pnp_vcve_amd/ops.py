@@ -181,7 +181,7 @@ def f16x3_image(packed):
 
 @_on_device_of_first_tensor
 def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, par_flags=None, residual=None, act=0,
-                  trace=None):
+                  trace=None, scaled_w1x1=False):
     """conv3x3 in split fp16 (pnp_conv3x3_f16x3, PNP_PREC_F16X3): packed_w / packed_w1x1 are the fp32 images of conv3x3 (their
     split images are made here) or, for 64-channel sources / the 1x1 branches, float16 tensors that already are f16x3_image()
     results.  fp32 sources, fp32 result at fp32-level accuracy."""
@@ -201,6 +201,12 @@ def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=N
     # the RGB frame's image is split too (k = 4 tap + channel: two 32-deep chunks): with it the whole conv is ONE launch; the fp32
     # image still travels for the traced variant, where the RGB link stays on the exact fp32 kernel
     x3 = [split(p) for p in packed_w]
+    # scaled_w1x1 (include/pnpvcve_debug.h): the branch images followed by the same images x 1/255, as pnp_generator_pack lays them
+    # out -- tiles whose partition values are all 0 or exactly 1/255 (par_flags bits 3..5) then take the masked-operand fast path
+    if scaled_w1x1:
+        if packed_w1x1 is None or packed_w1x1.dtype != torch.float32:
+            raise TypeError('scaled_w1x1: packed_w1x1 must be the fp32 images of pack_conv1x1')
+        packed_w1x1 = torch.cat([packed_w1x1.reshape(-1), packed_w1x1.reshape(-1) * (torch.ones((), device=packed_w1x1.device) / 255.0)])
     p_x3 = split(packed_w1x1)
     packed_w = [(_chk(p, 'packed_w') if p.dtype == torch.float32 else None) for p in packed_w]
     vp = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
@@ -208,14 +214,15 @@ def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=N
     sc = (ctypes.c_int * n)(*[s.shape[2] for s in srcs])
     keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, par, residual)]
     one = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    if trace is None:
+    if trace is None and not scaled_w1x1:
         _native.check(_native.lib().pnp_conv3x3_f16x3(n, vp(srcs), sc, vp(packed_w), vp(x3), _ptr(keep[0]), _ptr(keep[1]),
                                                       one(p_x3), _ptr(keep[2]), one(par_flags), _ptr(keep[3]), act,
                                                       _ptr(out), h, w, _stream()), 'pnp_conv3x3_f16x3')
     else:       # include/pnpvcve_debug.h: in-kernel timeline
         _native.check(_native.lib().pnp_conv3x3_f16x3_ex(n, vp(srcs), sc, vp(packed_w), vp(x3), _ptr(keep[0]), _ptr(keep[1]),
                                                          one(p_x3), _ptr(keep[2]), one(par_flags), _ptr(keep[3]), act,
-                                                         _ptr(out), h, w, one(trace), _stream()), 'pnp_conv3x3_f16x3_ex')
+                                                         _ptr(out), h, w, int(bool(scaled_w1x1)), one(trace), _stream()),
+                      'pnp_conv3x3_f16x3_ex')
     return out
 
 

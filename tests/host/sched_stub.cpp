@@ -211,7 +211,7 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
     }
     if (a.wpar || a.wpar_h) {
         if (f16) RD("the fp16 1x1 weight images", a.wpar_h, 3 * 4096 * 2);
-        else if (x3) RD("the split fp16 1x1 weight images", a.wpar_h, 3 * 4096 * 4);
+        else if (x3) RD("the split fp16 1x1 weight images (+ their 1/255-scaled twins)", a.wpar_h, (a.wpar_h_scaled ? 6 : 3) * 4096 * 4);
         else RD("the 1x1 weight images", a.wpar, 3 * 4096 * 4);
         RD("the partition planes", a.par, (size_t)(2 * a.par_plane + hw) * 4);
         if (a.par_flags) RD("the partition tile flags", a.par_flags, (size_t)((a.W + 15) / 16) * ((a.H + 7) / 8) * 4);

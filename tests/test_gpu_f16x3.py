@@ -337,3 +337,68 @@ def test_f16x3_operands_saturate_instead_of_overflowing():
     o2 = ops.conv3x3_f16x3([ops.nchw_to_nhwc(G(np.clip(x, -1, 1)))[0]], [ops.pack_conv3x3(G(wbig))], bias=G(b))
     r2 = F.conv2d(D(np.clip(x, -1, 1)), D(np.clip(wbig, -65504.0, 65504.0)), D(b), padding=1)
     assert torch.isfinite(o2).all() and float((ops.nhwc_to_nchw(o2.unsqueeze(0)).cpu().double() - r2).abs().max()) < 1e-6 * float(r2.abs().max())
+
+
+@pytest.mark.parametrize('hw', [(40, 56), (264, 272)])
+def test_f16x3_front_half_fast_path_on_binary_partition_maps(hw):
+    """Tiles whose partition values are all 0 or exactly 1/255 (flag bits 3..5; what the reference's loader writes,
+    loading_ipb.py: one-hot uint8 planes / 255.) contract the 1x1 branches with weight images scaled by 1/255 at pack time and a MASKED
+    A operand instead of re-splitting par_j(pixel) * x per fragment.  Against fp64 at the conv tolerance; against the general path to
+    the last bits; and a frame in which ONE tile carries another value must still be right everywhere (that tile falls back)."""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x, wt, b, gam, w1, par = _front_half_inputs(39, h, w, 1.0)
+    par = (par * (np.float32(1.0) / np.float32(255.0))).astype(np.float32)        # one-hot / 255 per 8x8 block, like the loader
+    assert set(np.unique(par).tolist()) == {0.0, float(np.float32(1.0) / np.float32(255.0))}
+    w1 = [v * np.float32(40.0) for v in w1]                                       # make the branches count: sum |par * conv1x1| ~ 0.1
+
+    def ref_of(pm):
+        r = F.conv2d(D(x), D(wt), D(b), padding=1) * D(gam).view(1, 64, 1, 1)
+        for j in range(3):
+            r = r + D(pm[j]).view(1, 1, h, w) * F.conv2d(D(x), D(w1[j]))
+        return F.relu(r)
+
+    xs = ops.nchw_to_nhwc(G(x))[0]
+    pw, p1 = ops.pack_conv3x3(G(wt)), ops.pack_conv1x1([G(v) for v in w1])
+
+    def run(pm, scaled):
+        pg = G(pm)
+        fl = ops.par_tile_flags(pg)
+        return ops.nhwc_to_nchw(ops.conv3x3_f16x3([xs], [pw], bias=G(b), gamma=G(gam), packed_w1x1=p1, par=pg, par_flags=fl, act=1,
+                                                  scaled_w1x1=scaled).unsqueeze(0)), fl
+
+    fast, fl = run(par, True)
+    gen, _ = run(par, False)
+    assert int(((fl >> 3) & 7).min()) == 7                                        # every tile qualifies
+    ref = ref_of(par)
+    assert float((ref - ref_of(par * 0)).abs().max()) > 1e-2                      # the branches are visible
+    assert maxdiff(fast, ref) < TOL_CONV / 2 and maxdiff(gen, ref) < TOL_CONV / 2
+    d = maxdiff(fast, gen.cpu())
+    assert 0 < d < 2e-6                                                           # another rounding point, the same result
+    # one tile with a different value (0.5 on a nonzero block of plane 1): its flag bit drops and it takes the general path
+    pm = par.copy()
+    ys, xs_ = np.nonzero(pm[1])
+    pm[1, ys[0], xs_[0]] = 0.5
+    mixed, fl2 = run(pm, True)
+    assert int(((fl2 >> 3) & 7).min()) < 7 and int((((fl2 >> 3) & 7) == 7).sum()) >= fl2.numel() - 1
+    assert maxdiff(mixed, ref_of(pm)) < TOL_CONV / 2
+
+
+@pytest.mark.parametrize('scaled', [True, False])
+def test_f16x3_front_half_is_bit_stable_under_unrelated_traffic(scaled):
+    """Both branch forms give the same bits launch after launch while another kernel keeps the memory system busy.  r04: an
+    intermediate build whose general re-split was float-VECTOR code (v_pk_*_f32 feeding the MFMA operands of the same dealt block)
+    differed from itself by 7e-4 on 40 % of the pixels; the scalar form, built with -fno-slp-vectorize, is what this pins."""
+    from pnp_vcve_amd import ops
+    h, w = 180, 320
+    x, wt, b, gam, w1, par = _front_half_inputs(38, h, w, 1.0)
+    par = (par * (np.float32(1.0) / np.float32(255.0))).astype(np.float32)
+    xs, pg = ops.nchw_to_nhwc(G(x))[0], G(par)
+    assert int(((ops.par_tile_flags(pg) >> 3) & 7).min()) == 7                   # scaled: every tile takes the masked-operand form
+    args = dict(bias=G(b), gamma=G(gam), packed_w1x1=ops.pack_conv1x1([G(v) for v in w1]), par=pg, par_flags=ops.par_tile_flags(pg),
+                act=1, scaled_w1x1=scaled)
+    pw = [ops.pack_conv3x3(G(wt))]
+    first = ops.conv3x3_f16x3([xs], pw, **args).clone()
+    for _ in range(6):
+        torch.randn(1 << 22, device='cuda').sin_()
+        assert torch.equal(ops.conv3x3_f16x3([xs], pw, **args), first)

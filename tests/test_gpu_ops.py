@@ -501,7 +501,11 @@ def test_par_tile_flags_vs_numpy():
         for tx in range(exp.shape[1]):
             blk = par[:, ty * 8:ty * 8 + 8, tx * 16:tx * 16 + 16]
             exp[ty, tx] = sum(int((blk[j] != 0).any()) << j for j in range(3))
-    assert np.array_equal(got, exp) and got[0, 0] == 1 and got[1, 1] == 2 and got[2, 0] == 6 and got[-1, -1] == 4
+            # bits 3..5 (r04): every value of plane j in the tile is 0 or exactly float32(1) / float32(255) -- the reference loader's value
+            unit = np.float32(1.0) / np.float32(255.0)
+            exp[ty, tx] |= sum(int(((blk[j] == 0) | (blk[j] == unit)).all()) << (3 + j) for j in range(3))
+    assert np.array_equal(got, exp)
+    assert got[0, 0] == 1 | 56 and got[1, 1] == 2 | 8 | 32 and got[2, 0] == 6 | 8 and got[-1, -1] == 4 | 8 | 16 and got[5, 5] == 56
 
 
 def test_torch_custom_ops_call_the_hip_kernels():

@@ -139,12 +139,14 @@ def test_forward_refuses_maps_beyond_32_bit_offsets_before_touching_memory(lib):
         lib.pnp_generator_destroy(h)
 
 
-def test_dcn_is_built_without_slp_vectorisation():
+def test_dcn_and_split_conv_are_built_without_slp_vectorisation():
     """DESIGN.md 3.5 / profiles/r03_dcn_hazard_report.txt: every build of dcn.hip whose gather arithmetic hipcc's SLP vectoriser had
     packed gave run-to-run varying samples in the fp16 instantiation under some timing; the flag is part of the kernel's
-    correctness, so dropping it has to fail a test (the behaviour itself is held by the -m gpu determinism tests)."""
+    correctness, so dropping it has to fail a test (the behaviour itself is held by the -m gpu determinism tests).  Same for
+    conv_f16x3.hip since r04 (DESIGN.md 3.6 finding 5: the general partition re-split)."""
     from pnp_vcve_amd import build_native
     assert '-fno-slp-vectorize' in build_native.EXTRA_FLAGS.get('dcn.hip', [])
+    assert '-fno-slp-vectorize' in build_native.EXTRA_FLAGS.get('conv_f16x3.hip', [])
     assert all(src in build_native.SOURCES for src in build_native.EXTRA_FLAGS)
 
 
