@@ -353,11 +353,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         for (int k = 0; k < NREQ; ++k) {
             // x saturates at +-65504 as a WHOLE: the remainder is taken from the clamped value, so it is at most half an fp16 ulp
             // (<= 16) and its scaled form (<= 32768) needs no clamp of its own; in-range values are untouched
+            char* d = k < ROWS ? l_main + k * XRSB : (S4 ? l_side6 : (k == ROWS ? l_side : l_side11));
+#ifdef X3_EXP_VERBATIM        /* upper bound of producer-split maps: the 16 bytes go to LDS as they are (wrong results) */
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2*>(d) = areg[k].xy;
+            *reinterpret_cast<f32x2*>(d + 128) = areg[k].zw;
+#else
             const f32x4 xc = clamp_h(areg[k]);
             const h4 hi = __builtin_convertvector(xc, h4);
-            char* d = k < ROWS ? l_main + k * XRSB : (S4 ? l_side6 : (k == ROWS ? l_side : l_side11));
             *reinterpret_cast<h4*>(d) = hi;
             *reinterpret_cast<h4*>(d + 128) = __builtin_convertvector((xc - __builtin_convertvector(hi, f32x4)) * X3_SCALE, h4);
+#endif
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -436,7 +442,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                 const float pjr[2] = {pv[0][0] * m0 + pv[1][0] * m1 + pv[2][0] * m2, pv[0][1] * m0 + pv[1][1] * m1 + pv[2][1] * m2};
                 // par_j(pixel) * x as a split number again: (hi + lo / 2048) is exact in fp32 (22 bits), one fp32 rounding for the
                 // product, then the same split as the halo (saturating as a whole)
-                typedef float f32x8 __attribute__((ext_vector_type(8)));
                 if (FAST) {
                     // pj is 0 or 1/255 and the weights carry the 1/255: the operand is x or nothing.  As a bit mask (one v_cndmask + 8
                     // v_and per row): a per-lane select on the fragments compiles to divergent branches, which cut the chunk into
@@ -556,19 +561,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
 
         // ---- epilogue: transpose through the dead A tile, [+ partial sum], activation, [+ residual], whole pixel rows to HBM
         // accumulator element e of lane (lm, lg), M tile r, N tile j = pixel (row r, column 4 lg + e), channel 16 j + lm of the wave
-        static_assert(4 * 2048 * NTW <= ROWS * XRSB, "the transposition slices fit the dead A tile");
-        float* sT = reinterpret_cast<float*>(smem + wave * (2048 * NTW));        // [32 pixels][16 NTW channels] fp32 per wave
-        const f32x4* sT4 = reinterpret_cast<const f32x4*>(sT);
+        // pixel stride 16 NTW + 4 floats: a write instruction's four lane groups (pixels 4 lg + e) then start 16 banks apart -- with the
+        // bare stride all four met in the same 16 banks (SQ_LDS_BANK_CONFLICT: 2 cycles per write, 1.84e6 per 720p launch)
+        constexpr int TPS = 16 * NTW + 4;
+        static_assert(4 * 32 * TPS * 4 <= ROWS * XRSB, "the transposition slices fit the dead A tile");
+        float* sT = reinterpret_cast<float*>(smem + wave * (32 * TPS * 4));      // [32 pixels][16 NTW channels + 4] fp32 per wave
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sT[(16 * r + 4 * lg + e) * (16 * NTW) + j * 16 + lm] = acc_hi[r][j][e];
+                for (int e = 0; e < 4; ++e) sT[(16 * r + 4 * lg + e) * TPS + j * 16 + lm] = acc_hi[r][j][e];
         asm volatile("" ::: "memory");
         f32x4 rows[EIT];
 #pragma unroll
-        for (int i = 0; i < EIT; ++i) rows[i] = sT4[(ep + PPI * i) * CW + ec];
+        for (int i = 0; i < EIT; ++i) rows[i] = *reinterpret_cast<const f32x4*>(sT + (ep + PPI * i) * TPS + ec * 4);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < EIT; ++i) {
