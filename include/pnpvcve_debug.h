@@ -53,7 +53,7 @@ int pnp_conv3x3_f16_maps(int nsrc, const void* const* srcs_dev, const int* src_c
 
 /* pnp_conv3x3_f16x3 with the in-kernel timeline: trace_dev = 8 u64 per persistent block (512 at most): s_memtime at kernel
  * start; cycles spent waiting for / splitting the halo into the A tiles; cycles in the K loops; s_memtime at the end; cycles in the
- * epilogues; tiles done; block lifetime in 100 MHz s_memrealtime ticks. */
+ * epilogues; tiles done; block lifetime in 100 MHz s_memrealtime ticks; HW_REG_LDS_ALLOC (low byte 0: the first block on its CU). */
 int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs_dev, const int* src_channels,
                          const float* const* packed_w_f32_dev, const void* const* packed_w_x3_dev, const float* bias_dev,
                          const float* gamma_dev, const void* packed_w1x1_x3_dev, const float* par_dev,

@@ -605,6 +605,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         d[4] = dbg_e;
         d[5] = dbg_n;
         d[6] = __builtin_amdgcn_s_memrealtime() - dbg_r0;       // 100 MHz
+        d[7] = __builtin_amdgcn_s_getreg(6 | (31 << 11));       // HW_REG_LDS_ALLOC: LDS base 0 = the block that reached its CU first
     }
 }
 

@@ -43,6 +43,11 @@ def trace(name, fn):
     for nm, v in (('A tiles: wait + split + LDS', d[:, 1] / n), ('K loop', d[:, 2] / n), ('epilogue', d[:, 4] / n), ('total per tile', tot / n)):
         print(f'    {nm:28s} mean {v.mean():8.0f}  p10 {np.percentile(v, 10):8.0f}  p50 {np.percentile(v, 50):8.0f}  p90 {np.percentile(v, 90):8.0f}')
     print(f'    in-kernel clock: {np.median(tot / (d[:, 6] / 100.0)) / 1e3:.3f} GHz (s_memtime cycles per 100 MHz s_memrealtime tick)')
+    base = d[:, 7] & 0xff          # HW_REG_LDS_ALLOC's LDS_BASE: 0 = the block that reached its CU first (it wins the issue arbitration)
+    for bb in np.unique(base):
+        m = base == bb
+        print(f'    blocks at LDS base {int(bb):3d}: {int(m.sum()):3d}, tiles each {n[m].min()}..{n[m].max()}, K loop {np.mean(d[m, 2] / n[m]):6.0f}, '
+              f'per tile {np.mean(tot[m] / n[m]):6.0f}, lifetime {tot[m].mean():.0f}')
     print(f'    block lifetime: mean {tot.mean():.0f} cycles, max {tot.max()}; 12 MFMAs x 32 cycles per wave and chunk = 384, 18 chunks = 6912')
 
 
