@@ -25,7 +25,8 @@ extern "C" {
 #define PNP_ERR_SIZE_ASSERT 1004 /* reference: AssertionError, h/w < 64 (iconvsr_ipb_par.py:51) */
 #define PNP_ERR_SIZE_VALUE 1005  /* reference: ValueError from flow_warp.py:27-29 (h/w % 4 != 0) */
 
-int pnp_abi_version(void); /* 3: the never-implemented fused-block option / query of v2 removed, PNP_OPT_* renumbered, PNP_OPT_SPARSE_EVAL, PNP_OPT_F16_MIRRORS */
+int pnp_abi_version(void); /* 4: pnp_generator_cfg grew num_group / flow_inter / blocktype (3: the never-implemented fused-block option / query of v2
+                              removed, PNP_OPT_* renumbered, PNP_OPT_SPARSE_EVAL, PNP_OPT_F16_MIRRORS) */
 
 /* ------------------------------------------------------------------ generator (a1/a2)
  * Constructor kwargs of IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par
@@ -43,6 +44,14 @@ typedef struct pnp_generator_cfg {
                        sr_backbone_utils.py:262-302): branch j where plane j != 0, later planes overwrite, result / 255.
                        Identical to the dense path for one-hot maps in {0, 1/255}; one clip at a time (n == 1): the
                        reference indexes sample 0 only */
+    int num_group;  /* groups of every conv of a BAE block (sr_backbone_utils.py:285-289): a divisor of 64 (0 = 1); packed as the dense
+                       conv it equals.  Not with sparse_val (the reference's sparse_conv multiplies a (64, 64/groups) weight
+                       with 64-channel columns and raises) */
+    int flow_inter; /* 0 'bilinear', 1 'nearest' (flow_warp.py:8,47 -> F.grid_sample mode): the MV alignment and the warp inside
+                       the 'basic' aligner */
+    int blocktype;  /* 0 'drt'; 1 'drt_woqp' (ResidualBlockNoBNDynamic_drt_wo_qp, sr_backbone_utils.py:336-384): both 3x3 convs
+                       are plain convs, no expert mix and no gain; needs one_layer = 1 (with Dynamic_conv2d_se convs the
+                       reference indexes a tensor with 'x' and raises) */
 } pnp_generator_cfg;
 
 typedef struct pnp_generator pnp_generator;
@@ -141,6 +150,12 @@ int pnp_flow_warp_nchw_f32(const float* x_dev, const float* flow_dev, float* out
  * iconvsr_mv.py:17-18): feat/out (h,w,c) ; flow_x/flow_y (h,w) planes. */
 int pnp_mv_warp_nhwc_f32(const float* feat_dev, const float* flow_x_dev, const float* flow_y_dev,
                          float* out_dev, int h, int w, int c, void* stream);
+/* Both with flow_warp's `interpolation` argument (flow_warp.py:8,47 -> F.grid_sample mode): mode 0 'bilinear', 1 'nearest' (the
+ * pixel at nearbyint of the sampling position, ties to even, 0 outside the image -- ATen's grid_sampler_2d). */
+int pnp_flow_warp_nchw_mode_f32(const float* x_dev, const float* flow_dev, float* out_dev, int n, int c, int h, int w, int mode,
+                                void* stream);
+int pnp_mv_warp_nhwc_mode_f32(const float* feat_dev, const float* flow_x_dev, const float* flow_y_dev, float* out_dev, int h,
+                              int w, int c, int mode, void* stream);
 
 int pnp_nchw_to_nhwc_f32(const float* in_dev, float* out_dev, int n, int c, int h, int w, void* stream);
 int pnp_nhwc_to_nchw_f32(const float* in_dev, float* out_dev, int n, int c, int h, int w, void* stream);

@@ -20,9 +20,10 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------
 # K1  MV-guided bilinear alignment
 # --------------------------------------------------------------------------
-def flow_warp(x, flow):
-    """common/flow_warp.py:6-50 (bilinear, zeros padding, align_corners=True)
-    as used by VOSAlignment.forward, backbones/sr_backbones/iconvsr_mv.py:12-18.
+def flow_warp(x, flow, interpolation='bilinear'):
+    """common/flow_warp.py:6-50 (bilinear or nearest, zeros padding, align_corners=True)
+    as used by VOSAlignment.forward, backbones/sr_backbones/iconvsr_mv.py:12-18 (interpolation = the
+    constructor's flow_inter, iconvsr_ipb.py:16-24).
 
     x (n,c,h,w); flow (n,h,w,2) in pixels, last dim = (dx, dy).
     Written as an explicit 4-tap gather (not F.grid_sample) so that it is an
@@ -40,6 +41,16 @@ def flow_warp(x, flow):
     ny = 2.0 * py / max(h - 1, 1) - 1.0
     ix = ((nx + 1) / 2) * (w - 1)          # ATen grid_sampler_unnormalize, align_corners=True
     iy = ((ny + 1) / 2) * (h - 1)
+    if interpolation == 'nearest':
+        # ATen grid_sampler_2d, GridSamplerInterpolation::Nearest: std::nearbyint of the un-normalised coordinate (ties to
+        # even, which is what torch.round does), the pixel if it lies inside the image, else 0
+        xn, yn = torch.round(ix), torch.round(iy)
+        ok = (xn >= 0) & (xn <= w - 1) & (yn >= 0) & (yn <= h - 1)
+        idx = (yn.clamp(0, h - 1) * w + xn.clamp(0, w - 1)).long().reshape(n, 1, h * w).expand(n, c, h * w)
+        v = torch.gather(x.reshape(n, c, h * w), 2, idx).reshape(n, c, h, w)
+        return v * ok.to(x.dtype).unsqueeze(1)
+    if interpolation != 'bilinear':
+        raise NotImplementedError(f'flow_warp: interpolation {interpolation!r}')
     x0 = torch.floor(ix)
     y0 = torch.floor(iy)
     x1 = x0 + 1
@@ -111,11 +122,12 @@ def modulated_deform_conv2d(x, offset, mask, weight, bias, deform_groups=16):
 def deform_align(sd, cfg, feat, flow_nchw):
     """iconvsr_ipb.py:19-24 dispatch + iconvsr_mv.py:12-84."""
     mode = cfg.get('deform', 'vos')
+    inter = cfg.get('flow_inter', 'bilinear')
     if mode == 'vos':
-        return flow_warp(feat, flow_nchw.permute(0, 2, 3, 1))
+        return flow_warp(feat, flow_nchw.permute(0, 2, 3, 1), inter)
     p = 'deform_align.'
     if mode == 'basic':                                   # iconvsr_mv.py:68-84
-        warped = flow_warp(feat, flow_nchw.permute(0, 2, 3, 1))
+        warped = flow_warp(feat, flow_nchw.permute(0, 2, 3, 1), inter)
         extra = torch.cat([warped, flow_nchw], dim=1)
     elif mode == 'fvc':                                   # iconvsr_mv.py:31-41
         extra = torch.cat([feat, flow_nchw], dim=1)
@@ -163,14 +175,14 @@ def bias_predictor(sd, cfg, q):
 # --------------------------------------------------------------------------
 # K3/K4  expert-mixture ("dynamic") conv
 # --------------------------------------------------------------------------
-def dynamic_conv_se(x, ew, weight, bias, gamma, with_se):
+def dynamic_conv_se(x, ew, weight, bias, gamma, with_se, groups=1):
     """common/sr_backbone_utils.py:193-209 (Dynamic_conv2d_se.forward).
-    x (b,64,h,w); ew (b,E); weight (E,64,64,3,3); bias (E,64); gamma (b,64)."""
+    x (b,64,h,w); ew (b,E); weight (E,64,64/groups,3,3); bias (E,64); gamma (b,64)."""
     b, c, h, w = x.shape
     E = weight.shape[0]
-    wagg = torch.mm(ew, weight.view(E, -1)).view(b * c, c, 3, 3)
+    wagg = torch.mm(ew, weight.view(E, -1)).view(b * c, c // groups, 3, 3)
     bagg = torch.mm(ew, bias).view(-1)
-    out = F.conv2d(x.reshape(1, b * c, h, w), wagg, bagg, padding=1, groups=b).view(b, c, h, w)
+    out = F.conv2d(x.reshape(1, b * c, h, w), wagg, bagg, padding=1, groups=groups * b).view(b, c, h, w)
     if with_se:
         out = out * gamma.unsqueeze(-1).unsqueeze(-1)
     return out
@@ -199,25 +211,33 @@ def sparse_conv(sd, prefix, feature, par):
 # K5/K6  one BAE block
 # --------------------------------------------------------------------------
 def bae_block(sd, cfg, prefix, x, par, ew, gamma):
-    """common/sr_backbone_utils.py:304-333 (ResidualBlockNoBNDynamic_drt.forward).
-    par (b,3,1,h,w)."""
+    """common/sr_backbone_utils.py:304-333 (ResidualBlockNoBNDynamic_drt.forward) and, for blocktype 'drt_woqp', :366-384
+    (ResidualBlockNoBNDynamic_drt_wo_qp.forward: both 3x3 convs are called on the bare map, which only a plain nn.Conv2d
+    accepts -- i.e. one_layer=True; with one_layer=False the reference indexes a tensor with 'x' and raises).
+    par (b,3,1,h,w).  Every conv of the block has groups = num_group (:285-289)."""
     with_se = cfg.get('with_se', False)
     one_layer = cfg.get('one_layer', False)
+    g = cfg.get('num_group', 1)
+    woqp = cfg.get('blocktype', 'drt') == 'drt_woqp'
+    if woqp and not one_layer:
+        raise IndexError("too many indices for tensor of dimension 4")     # what inputs['x'] on a tensor raises (:376)
 
     def dyres(v):                                          # :310 / :324
         if cfg.get('sparse_val', False):                   # eval-only sparse evaluation, :308-309 / :322-323
             return sparse_conv(sd, prefix, v, par)
-        return (F.conv2d(v, sd[prefix + 'conv16x16.weight']) * par[:, 0] +
-                F.conv2d(v, sd[prefix + 'conv16x8.weight']) * par[:, 1] +
-                F.conv2d(v, sd[prefix + 'conv8x8.weight']) * par[:, 2])
+        return (F.conv2d(v, sd[prefix + 'conv16x16.weight'], groups=g) * par[:, 0] +
+                F.conv2d(v, sd[prefix + 'conv16x8.weight'], groups=g) * par[:, 1] +
+                F.conv2d(v, sd[prefix + 'conv8x8.weight'], groups=g) * par[:, 2])
 
     def conv1(v):
         if one_layer:
-            return F.conv2d(v, sd[prefix + 'conv1.weight'], sd[prefix + 'conv1.bias'], padding=1)
-        return dynamic_conv_se(v, ew, sd[prefix + 'conv1.weight'], sd[prefix + 'conv1.bias'], gamma, with_se)
+            return F.conv2d(v, sd[prefix + 'conv1.weight'], sd[prefix + 'conv1.bias'], padding=1, groups=g)
+        return dynamic_conv_se(v, ew, sd[prefix + 'conv1.weight'], sd[prefix + 'conv1.bias'], gamma, with_se, g)
 
     def conv2(v):
-        return dynamic_conv_se(v, ew, sd[prefix + 'conv2.weight'], sd[prefix + 'conv2.bias'], gamma, with_se)
+        if woqp:                                           # :343-344: a plain conv too, no expert mix, no gain
+            return F.conv2d(v, sd[prefix + 'conv2.weight'], sd[prefix + 'conv2.bias'], padding=1, groups=g)
+        return dynamic_conv_se(v, ew, sd[prefix + 'conv2.weight'], sd[prefix + 'conv2.bias'], gamma, with_se, g)
 
     if cfg.get('channel_first', True):                     # :305-313
         out = F.relu(conv2(x) + dyres(x))

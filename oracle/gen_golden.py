@@ -6,7 +6,7 @@ tests/golden_util.py.  Only outputs are stored; inputs are regenerated from
 seeds on whichever machine runs the tests.
 
     python oracle/gen_golden.py                    # (re)write every fixture + manifest
-    python oracle/gen_golden.py --only a,b         # only the named generator cases, merged into the manifest
+    python oracle/gen_golden.py --only a,b         # only the named generator / flow_warp cases, merged into the manifest
 """
 import json
 import os
@@ -75,23 +75,26 @@ def main():
         print(case['name'], list(ref.shape), 'oracle-vs-ref', d, sens, flush=True)
         assert d < 1e-5
 
-    if only is not None:
-        with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json'), 'w') as f:
-            json.dump(manifest, f, indent=1, sort_keys=True)
-        print('updated', sorted(only))
-        return
-
     # ---- flow_warp --------------------------------------------------------
     for case in gu.WARP_CASES:
+        if only is not None and case['name'] not in only:
+            continue
         x, flow = gu.warp_case_inputs(case)
+        mode = case.get('mode', 'bilinear')
         with torch.no_grad():
-            ref = ref_flow_warp(T(x), T(flow))
-            mine = cpu_ref.flow_warp(T(x), T(flow))
+            ref = ref_flow_warp(T(x), T(flow), interpolation=mode)
+            mine = cpu_ref.flow_warp(T(x), T(flow), mode)
         d = float((ref - mine).abs().max())
         np.savez(os.path.join(gu.GOLDEN_DIR, case['name'] + '.npz'), out=ref.numpy())
         manifest['cases'][case['name']] = dict(kind='flow_warp', shape=list(ref.shape), oracle_vs_reference_maxabs=d)
         print(case['name'], d, flush=True)
         assert d < 1e-5
+
+    if only is not None:
+        with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json'), 'w') as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        print('updated', sorted(only))
+        return
 
     # ---- CAA predictors ---------------------------------------------------
     cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG)

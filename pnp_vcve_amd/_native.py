@@ -16,7 +16,8 @@ PNP_ERR = {1001: 'bad argument', 1002: 'unsupported configuration', 1003: 'works
 class GeneratorCfg(ctypes.Structure):
     _fields_ = [(k, c_int) for k in (
         'mid_channels', 'num_blocks', 'num_experts', 'with_cat', 'use_base_qp', 'expert_softmax', 'with_bias',
-        'with_se', 'one_layer', 'channel_first', 'align_key', 'vsr', 'deform', 'sparse_val')]
+        'with_se', 'one_layer', 'channel_first', 'align_key', 'vsr', 'deform', 'sparse_val', 'num_group', 'flow_inter',
+        'blocktype')]
 
 
 # name -> (restype, argtypes); every symbol include/pnpvcve.h declares
@@ -45,6 +46,8 @@ SIGNATURES = {
                                            POINTER(ctypes.c_double)]),
     'pnp_flow_warp_nchw_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_mv_warp_nhwc_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'pnp_flow_warp_nchw_mode_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'pnp_mv_warp_nhwc_mode_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_nchw_to_nhwc_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_nhwc_to_nchw_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'pnp_caa_predict_f32': (c_int, [POINTER(c_float), POINTER(c_float), c_int, c_int, c_int, c_void_p, c_void_p,

@@ -41,6 +41,8 @@ struct ParamInfo {
 struct BlockPk {
     int64_t conv1_img = -1;       // packed, static conv1 (one_layer)
     int64_t conv1_bias = -1;      // flat
+    int64_t conv2_img = -1;       // packed, static conv2 (blocktype 'drt_woqp': a plain nn.Conv2d too, sr_backbone_utils.py:343-344)
+    int64_t conv2_bias = -1;      // flat
     int64_t w1x1 = -1;            // packed, 3 chunks + 3 chunks scaled by PNP_PAR_UNIT (split-fp16 fast path on binary partition maps)
     int dyn_conv2 = -1, dyn_conv1 = -1;
 };
@@ -94,7 +96,7 @@ struct pnp_generator {
     // flat offsets needed by pack()
     int64_t f_in_w[2] = {-1, -1}, f_hr_w = -1, f_last_w = -1, f_last_b = -1, f_up_w[2] = {-1, -1},
             f_up_b[2] = {-1, -1};
-    std::vector<int64_t> f_conv1_w[2], f_1x1_w[2];   // per block (1x1: 3 consecutive entries)
+    std::vector<int64_t> f_conv1_w[2], f_conv2_w[2], f_1x1_w[2];   // per block (1x1: 3 consecutive entries; conv2: 'drt_woqp' only)
 
     int64_t add_param(const std::string& name, std::vector<int64_t> shape) {
         ParamInfo p;
@@ -123,8 +125,16 @@ int build_layout(pnp_generator* g) {
     if (c.with_se && !c.with_bias) return PNP_ERR_BAD_ARG;   // reference: gamma is None -> crash
     if (c.with_bias && !c.use_base_qp) return PNP_ERR_BAD_ARG;   // iconvsr_ipb_par.py:27 assert
     if (c.deform < 0 || c.deform > 2) return PNP_ERR_BAD_ARG;
+    if (c.flow_inter < 0 || c.flow_inter > 1 || c.blocktype < 0 || c.blocktype > 1) return PNP_ERR_BAD_ARG;
+    if (c.num_group < 1 || c.num_group > 64 || 64 % c.num_group) return PNP_ERR_BAD_ARG;    // nn.Conv2d: channels % groups != 0 -> ValueError
+    // 'drt_woqp' calls both 3x3 convs on the bare map (sr_backbone_utils.py:376-377,379,384), which a Dynamic_conv2d_se indexes with
+    // 'x': it runs only with one_layer=True.  sparse_val multiplies the (64, 64/groups) 1x1 weight with 64-channel columns (:295).
+    if (c.blocktype == 1 && !c.one_layer) return PNP_ERR_UNSUPPORTED;
+    if (c.sparse_val && c.num_group != 1) return PNP_ERR_UNSUPPORTED;
     const int nb = c.num_blocks, E = c.num_experts;
-    const int dpb = c.one_layer ? 1 : 2;
+    const int gc = 64 / c.num_group;                 // input channels per group of every conv of a block (:285-289)
+    const bool woqp = c.blocktype == 1;
+    const int dpb = woqp ? 0 : (c.one_layer ? 1 : 2);   // expert-mixed convs per block
     g->ndyn = 2 * nb * dpb;
     static const char* brn[2] = {"backward_resblocks", "forward_resblocks"};
     // 1) dynamic conv banks first, with uniform strides (batched expert mixing indexes them by blockIdx.y)
@@ -133,11 +143,12 @@ int build_layout(pnp_generator* g) {
         g->br[b].blocks.resize(nb);
         for (int i = 0; i < nb; ++i) {
             const std::string p = std::string(brn[b]) + ".main." + std::to_string(i) + ".";
+            if (woqp) continue;
             g->br[b].blocks[i].dyn_conv2 = (b * nb + i) * dpb;
-            g->add_param(p + "conv2.weight", {E, 64, 64, 3, 3});
+            g->add_param(p + "conv2.weight", {E, 64, gc, 3, 3});
             if (!c.one_layer) {
                 g->br[b].blocks[i].dyn_conv1 = (b * nb + i) * dpb + 1;
-                g->add_param(p + "conv1.weight", {E, 64, 64, 3, 3});
+                g->add_param(p + "conv1.weight", {E, 64, gc, 3, 3});
             }
         }
     }
@@ -145,6 +156,7 @@ int build_layout(pnp_generator* g) {
     for (int b = 0; b < 2; ++b)
         for (int i = 0; i < nb; ++i) {
             const std::string p = std::string(brn[b]) + ".main." + std::to_string(i) + ".";
+            if (woqp) continue;
             g->add_param(p + "conv2.bias", {E, 64});
             if (!c.one_layer) g->add_param(p + "conv1.bias", {E, 64});
         }
@@ -176,16 +188,22 @@ int build_layout(pnp_generator* g) {
         for (int s = 0; s < B.n_wide; ++s) B.in_wide[s] = g->add_packed(IMG_WIDE);
         if (c.with_cat && c.align_key) B.in_wide01 = g->add_packed(IMG_WIDE);
         g->f_conv1_w[b].assign(nb, -1);
+        g->f_conv2_w[b].assign(nb, -1);
         g->f_1x1_w[b].assign(nb * 3, -1);
         for (int i = 0; i < nb; ++i) {
             const std::string p = std::string(brn[b]) + ".main." + std::to_string(i) + ".";
             if (c.one_layer) {
-                g->f_conv1_w[b][i] = g->add_param(p + "conv1.weight", {64, 64, 3, 3});
+                g->f_conv1_w[b][i] = g->add_param(p + "conv1.weight", {64, gc, 3, 3});
                 B.blocks[i].conv1_bias = g->add_param(p + "conv1.bias", {64});
                 B.blocks[i].conv1_img = g->add_packed(IMG_WIDE);
             }
+            if (woqp) {
+                g->f_conv2_w[b][i] = g->add_param(p + "conv2.weight", {64, gc, 3, 3});
+                B.blocks[i].conv2_bias = g->add_param(p + "conv2.bias", {64});
+                B.blocks[i].conv2_img = g->add_packed(IMG_WIDE);
+            }
             static const char* k1[3] = {"conv16x16", "conv16x8", "conv8x8"};
-            for (int j = 0; j < 3; ++j) g->f_1x1_w[b][i * 3 + j] = g->add_param(p + k1[j] + ".weight", {64, 64, 1, 1});
+            for (int j = 0; j < 3; ++j) g->f_1x1_w[b][i * 3 + j] = g->add_param(p + k1[j] + ".weight", {64, gc, 1, 1});
             B.blocks[i].w1x1 = g->add_packed(6 * IMG_CHUNK);      // conv16x16 / conv16x8 / conv8x8, then the same three x PNP_PAR_UNIT
         }
     }
@@ -416,12 +434,13 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
 
 extern "C" {
 
-int pnp_abi_version(void) { return 3; }
+int pnp_abi_version(void) { return 4; }
 
 int pnp_generator_create(const pnp_generator_cfg* cfg, pnp_generator** out) {
     if (!cfg || !out) return PNP_ERR_BAD_ARG;
     pnp_generator* g = new pnp_generator();
     g->cfg = *cfg;
+    if (g->cfg.num_group == 0) g->cfg.num_group = 1;      // a zeroed field is the reference's default (num_group=1)
     const int rc = build_layout(g);
     if (rc != PNP_OK) {
         delete g;
@@ -500,13 +519,23 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
         }
         for (int i = 0; i < c.num_blocks; ++i) {
             const BlockPk& K = B.blocks[i];
+            // grouped convs (num_group > 1) are packed as the dense conv they equal: zeros outside the diagonal blocks
+            const int gcin = c.num_group > 1 ? 64 / c.num_group : 0;
             if (c.one_layer) {
-                rc = launch_pack_weights(
-                    plain_pack(flat + g->f_conv1_w[b][i], 64, 9, PACK_WIDE, 0, 2, 64, packed + K.conv1_img), 1, st);
+                PackArgs p1 = plain_pack(flat + g->f_conv1_w[b][i], 64, 9, PACK_WIDE, 0, 2, 64, packed + K.conv1_img);
+                p1.group_cin = gcin;
+                rc = launch_pack_weights(p1, 1, st);
+                if (rc) return rc;
+            }
+            if (c.blocktype == 1) {
+                PackArgs p2 = plain_pack(flat + g->f_conv2_w[b][i], 64, 9, PACK_WIDE, 0, 2, 64, packed + K.conv2_img);
+                p2.group_cin = gcin;
+                rc = launch_pack_weights(p2, 1, st);
                 if (rc) return rc;
             }
             for (int j = 0; j < 6; ++j) {
                 PackArgs pa = plain_pack(flat + g->f_1x1_w[b][i * 3 + j % 3], 64, 1, PACK_1X1, 0, 2, 64, packed + K.w1x1 + j * IMG_CHUNK);
+                pa.group_cin = gcin;
                 if (j >= 3) pa.scale = PNP_PAR_UNIT;
                 rc = launch_pack_weights(pa, 1, st);
                 if (rc) return rc;
@@ -668,7 +697,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         int r;
         if (c.deform == 0 || c.deform == 1) {   // 'vos', and the pre-warp of 'basic' (:69)
             ProfScope ps(g, st, PNP_PROF_WARP, (mirrors ? 392.0 : 520.0) * (double)hw);     // 8 flow + 256 gather + 256 | 128 write
-            r = launch_mv_warp_nhwc(feat, fxp, fyp, c.deform == 0 ? W.kw : W.tmp0, h, w, 64, st, mirrors);   // mirrors: kw is fp16
+            r = launch_mv_warp_nhwc(feat, fxp, fyp, c.deform == 0 ? W.kw : W.tmp0, h, w, 64, st, mirrors, c.flow_inter == 1);   // mirrors: kw is fp16
             if (r || c.deform == 0) return r;
         }
         r = launch_pack_flow4(fxp, fyp, W.flow4, h, w, st);
@@ -749,16 +778,22 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                     u = (int)k;
                     break;
                 }
+            if (u < 0 && g->ndyn == 0) {      // 'drt_woqp': no expert-mixed conv at all
+                u = (int)ufirst.size();
+                ufirst.push_back(i);
+            }
             if (u < 0) {
                 u = (int)ufirst.size();
                 ufirst.push_back(i);
+                const int gcm = 64 / c.num_group;
                 PackArgs a;
                 memset(&a, 0, sizeof(a));
                 a.w = flat + g->dyn_w;
                 a.ew = W.ew + (int64_t)i * E;
                 a.E = E;
-                a.e_stride = 64 * 64 * 9;
+                a.e_stride = 64 * gcm * 9;
                 a.cin_total = 64;
+                a.group_cin = c.num_group > 1 ? gcm : 0;
                 a.ktaps = 9;
                 a.co_mul = 1;
                 a.co_add = 0;
@@ -770,7 +805,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 a.ntb = 2;
                 a.scale = 1.f;
                 a.dst = W.mixw + (int64_t)u * g->ndyn * IMG_WIDE;
-                a.w_ystride = (int64_t)E * 64 * 64 * 9;
+                a.w_ystride = (int64_t)E * 64 * gcm * 9;
                 a.dst_ystride = IMG_WIDE;
                 rc = launch_pack_weights(a, g->ndyn, st);
                 if (rc) return rc;
@@ -813,8 +848,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 float* dst = (k == c.num_blocks - 1) ? slot : W.tmp0;
                 void* dst16 = !mirrors ? nullptr : (k == c.num_blocks - 1) ? (void*)(W.slots16 + (int64_t)i * fm)
                                                                                  : (chain16 ? (void*)W.x16 : nullptr);
-                const float* w2 = W.mixw + ((int64_t)u * g->ndyn + K.dyn_conv2) * IMG_WIDE;
-                const float* b2 = W.mixb + ((int64_t)u * g->ndyn + K.dyn_conv2) * 64;
+                const bool woqp = c.blocktype == 1;      // conv2 a plain conv as well: no expert mix, no gain (sr_backbone_utils.py:366-384)
+                const float* w2 = woqp ? packed + K.conv2_img : W.mixw + ((int64_t)u * g->ndyn + K.dyn_conv2) * IMG_WIDE;
+                const float* b2 = woqp ? flat + K.conv2_bias : W.mixb + ((int64_t)u * g->ndyn + K.dyn_conv2) * 64;
+                const float* g2 = woqp ? nullptr : gam;
                 const float* w1 = c.one_layer ? packed + K.conv1_img
                                               : W.mixw + ((int64_t)u * g->ndyn + K.dyn_conv1) * IMG_WIDE;
                 const float* b1 = c.one_layer ? flat + K.conv1_bias
@@ -823,7 +860,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 // the map between the two halves is read only as an MFMA A operand: an fp16 map on the fp16 path
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
-                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(gam)
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(g2)
                                  .partition(packed + K.w1x1, parp, pflags).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).residual(x).to(dst)
@@ -832,7 +869,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                     r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).mirror16(x16).bias(b1).gamma(g1).act(1).to(W.tmp1)
                                  .f16_map(o16));
                     if (!r)
-                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(gam)
+                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(g2)
                                      .partition(packed + K.w1x1, parp, pflags).residual(x).to(dst).f16_map(s16).also16(dst16));
                 }
                 if (r) return r;
@@ -1019,6 +1056,17 @@ int pnp_generator_profile_read(pnp_generator* g, int kind, double* total_ms, int
 int pnp_flow_warp_nchw_f32(const float* x, const float* flow, float* out, int n, int c, int h, int w, void* st) {
     if (n < 1 || c < 1 || h < 1 || w < 1) return PNP_ERR_BAD_ARG;
     return launch_flow_warp_nchw(x, flow, out, n, c, h, w, (hipStream_t)st);
+}
+
+int pnp_flow_warp_nchw_mode_f32(const float* x, const float* flow, float* out, int n, int c, int h, int w, int mode, void* st) {
+    if (n < 1 || c < 1 || h < 1 || w < 1 || mode < 0 || mode > 1) return PNP_ERR_BAD_ARG;
+    return launch_flow_warp_nchw(x, flow, out, n, c, h, w, (hipStream_t)st, mode == 1);
+}
+
+int pnp_mv_warp_nhwc_mode_f32(const float* feat, const float* fx, const float* fy, float* out, int h, int w, int c, int mode,
+                              void* st) {
+    if (h < 1 || w < 1 || c < 4 || mode < 0 || mode > 1) return PNP_ERR_BAD_ARG;
+    return launch_mv_warp_nhwc(feat, fx, fy, out, h, w, c, (hipStream_t)st, false, mode == 1);
 }
 
 int pnp_mv_warp_nhwc_f32(const float* feat, const float* fx, const float* fy, float* out, int h, int w, int c,

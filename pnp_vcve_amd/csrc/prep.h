@@ -35,6 +35,8 @@ struct PackArgs {
     int E;
     long e_stride;      // floats between experts
     int cin_total, ktaps;
+    int group_cin;      // 0: dense.  > 0: a grouped 64 -> 64 conv (cbase 0) whose weight is [cout][group_cin][ktaps]: packed as the dense conv it
+                        // equals, zeros outside the diagonal blocks (nn.Conv2d(groups=64 / group_cin), sr_backbone_utils.py:285-289)
     int co_mul, co_add; // reference output channel = co * co_mul + co_add
     int n_valid;        // packed output channels >= n_valid are zero
     int co_mode;        // 0: affine (co_mul, co_add); 1: DCN offset/mask permutation of packed channel 64*blockIdx.y + co

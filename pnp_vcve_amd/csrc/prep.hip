@@ -100,8 +100,14 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
         co_ref = pnp_dcn_ref_channel_impl(blockIdx.y * 64 + co);
         valid = valid && co_ref >= 0;
     }
+    int cin_w = a.cin_total;
+    if (a.group_cin > 0) {                  // grouped conv: only the diagonal blocks exist
+        valid = valid && (ci / a.group_cin == co_ref / a.group_cin);
+        ci %= a.group_cin;
+        cin_w = a.group_cin;
+    }
     if (valid) {
-        const float* w = a.w + (long)blockIdx.y * a.w_ystride + ((long)co_ref * a.cin_total + ci) * a.ktaps + tap;
+        const float* w = a.w + (long)blockIdx.y * a.w_ystride + ((long)co_ref * cin_w + ci) * a.ktaps + tap;
         if (a.ew) {
             for (int e = 0; e < a.E; ++e) v += a.ew[e] * w[(long)e * a.e_stride];
         } else {

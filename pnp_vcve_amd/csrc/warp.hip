@@ -16,16 +16,21 @@ namespace {
 
 // Coordinate arithmetic kept in the reference's order (normalise to [-1,1], flow_warp.py:41-42,
 // then ATen's align_corners=True un-normalise) so results track the CPU path to ~1e-7.
-__device__ __forceinline__ void tap_setup(float x, float y, float fx, float fy, int H, int W,
-                                          int& x0, int& y0, float& wx1, float& wy1) {
+__device__ __forceinline__ void sample_coords(float x, float y, float fx, float fy, int H, int W, float& ix, float& iy) {
     const float px = x + fx, py = y + fy;
     const float wm1 = (float)(W - 1 > 1 ? W - 1 : 1), hm1 = (float)(H - 1 > 1 ? H - 1 : 1);
     const float nx = 2.0f * px / wm1 - 1.0f, ny = 2.0f * py / hm1 - 1.0f;
-    float ix = ((nx + 1.0f) / 2.0f) * (float)(W - 1);
-    float iy = ((ny + 1.0f) / 2.0f) * (float)(H - 1);
+    ix = ((nx + 1.0f) / 2.0f) * (float)(W - 1);
+    iy = ((ny + 1.0f) / 2.0f) * (float)(H - 1);
     // keep the int conversion defined for wild vectors; anything beyond [-1, size] has no valid tap
     ix = fminf(fmaxf(ix, -2.0f), (float)W + 1.0f);
     iy = fminf(fmaxf(iy, -2.0f), (float)H + 1.0f);
+}
+
+__device__ __forceinline__ void tap_setup(float x, float y, float fx, float fy, int H, int W,
+                                          int& x0, int& y0, float& wx1, float& wy1) {
+    float ix, iy;
+    sample_coords(x, y, fx, fy, H, W, ix, iy);
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     x0 = (int)fx0;
     y0 = (int)fy0;
@@ -39,7 +44,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // OUT16: the aligned map is written as fp16 (8 B per lane).  On the fp16-operand conv path it is read only as an MFMA A
 // operand of the input conv, which would round it (saturating, round-to-nearest-even) on its way into LDS: rounding it
 // here instead is bit-identical and halves the bytes written and re-read.
-template <bool OUT16>
+// NEAREST (flow_inter='nearest', flow_warp.py:47 -> ATen grid_sampler_2d Nearest): the pixel at nearbyint of the un-normalised
+// coordinate (ties to even = rintf in the default rounding mode) if it lies in the image, else 0 -- one tap, 264 + 256 B per pixel.
+template <bool OUT16, bool NEAREST = false>
 __global__ __launch_bounds__(256) void mv_warp_nhwc_kernel(const float* __restrict__ feat,
                                                            const float* __restrict__ fxp,
                                                            const float* __restrict__ fyp,
@@ -52,6 +59,20 @@ __global__ __launch_bounds__(256) void mv_warp_nhwc_kernel(const float* __restri
         const long pix = i / C4;
         const int c4 = (int)(i - pix * C4);
         const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
+        if (NEAREST) {
+            float ix, iy;
+            sample_coords((float)x, (float)y, fxp[pix], fyp[pix], H, W, ix, iy);
+            const int xn = (int)rintf(ix), yn = (int)rintf(iy);
+            const bool ok = (xn >= 0) & (xn < W) & (yn >= 0) & (yn < H);
+            f32x4 v = ok ? f4[((long)yn * W + xn) * C4 + c4] : (f32x4)(0.f);
+            if (OUT16) {
+                v = __builtin_elementwise_min(__builtin_elementwise_max(v, (f32x4)(-65504.f)), (f32x4)(65504.f));
+                o16[i] = __builtin_convertvector(v, h4);
+            } else {
+                o4[i] = v;
+            }
+            continue;
+        }
         int x0, y0;
         float wx1, wy1;
         tap_setup((float)x, (float)y, fxp[pix], fyp[pix], H, W, x0, y0, wx1, wy1);
@@ -77,7 +98,8 @@ __global__ __launch_bounds__(256) void mv_warp_nhwc_kernel(const float* __restri
 // Drop-in for flow_warp(x, flow): x (n,c,h,w) NCHW, flow (n,h,w,2) = (dx,dy) pixels.
 __global__ __launch_bounds__(256) void flow_warp_nchw_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ flow,
-                                                             float* __restrict__ out, int N, int C, int H, int W) {
+                                                             float* __restrict__ out, int N, int C, int H, int W,
+                                                             int nearest) {
     const long hw = (long)H * W;
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (long)N * hw) return;
@@ -90,8 +112,16 @@ __global__ __launch_bounds__(256) void flow_warp_nchw_kernel(const float* __rest
     const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
     const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x0 + 1 >= 0) & (x0 + 1 < W);
     const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y0 + 1 >= 0) & (y0 + 1 < H);
-    const float w00 = (vx0 & vy0) ? wx0 * wy0 : 0.f, w01 = (vx1 & vy0) ? wx1 * wy0 : 0.f;
-    const float w10 = (vx0 & vy1) ? wx0 * wy1 : 0.f, w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;
+    float w00 = (vx0 & vy0) ? wx0 * wy0 : 0.f, w01 = (vx1 & vy0) ? wx1 * wy0 : 0.f;
+    float w10 = (vx0 & vy1) ? wx0 * wy1 : 0.f, w11 = (vx1 & vy1) ? wx1 * wy1 : 0.f;
+    if (nearest) {      // the one pixel at nearbyint(ix), nearbyint(iy) (ties to even) with weight 1, as tap 00
+        float ix, iy;
+        sample_coords((float)xx, (float)yy, flow[p * 2], flow[p * 2 + 1], H, W, ix, iy);
+        x0 = (int)rintf(ix);
+        y0 = (int)rintf(iy);
+        w00 = ((x0 >= 0) & (x0 < W) & (y0 >= 0) & (y0 < H)) ? 1.f : 0.f;
+        w01 = w10 = w11 = 0.f;
+    }
     const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
     const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
     const long o00 = (long)cy0 * W + cx0, o01 = (long)cy0 * W + cx1;
@@ -108,25 +138,22 @@ __global__ __launch_bounds__(256) void flow_warp_nchw_kernel(const float* __rest
 }  // namespace
 
 int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, void* out, int H, int W, int C,
-                        hipStream_t stream, bool out_f16) {
+                        hipStream_t stream, bool out_f16, bool nearest) {
     if (C % 4) return PNP_ERR_BAD_ARG;
     const long total = (long)H * W * (C / 4);
     long blocks = (total + 255) / 256;
     const long cap = 256L * 32;            // 32 blocks per CU worth of grid, grid-stride beyond
     if (blocks > cap) blocks = cap;
-    if (out_f16)
-        hipLaunchKernelGGL(mv_warp_nhwc_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, feat, fx, fy, out, H, W,
-                           C / 4, total);
-    else
-        hipLaunchKernelGGL(mv_warp_nhwc_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, feat, fx, fy, out, H, W,
-                           C / 4, total);
+    auto kern = out_f16 ? (nearest ? mv_warp_nhwc_kernel<true, true> : mv_warp_nhwc_kernel<true, false>)
+                        : (nearest ? mv_warp_nhwc_kernel<false, true> : mv_warp_nhwc_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, feat, fx, fy, out, H, W, C / 4, total);
     return (int)hipGetLastError();
 }
 
 int launch_flow_warp_nchw(const float* x, const float* flow, float* out, int N, int C, int H, int W,
-                          hipStream_t stream) {
+                          hipStream_t stream, bool nearest) {
     const long total = (long)N * H * W;
     hipLaunchKernelGGL(flow_warp_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, flow,
-                       out, N, C, H, W);
+                       out, N, C, H, W, nearest ? 1 : 0);
     return (int)hipGetLastError();
 }

@@ -17,6 +17,8 @@ from . import _native
 from .registry import BACKBONES
 
 _DEFORM = {'vos': 0, 'basic': 1, 'fvc': 2}
+_FLOW_INTER = {'bilinear': 0, 'nearest': 1}        # flow_warp.py:18
+_BLOCKTYPES = {'drt': 0, 'drt_woqp': 1}            # basicvsr_net.py:487-503
 
 
 def _kaiming_normal_fan_in(t, scale):
@@ -38,12 +40,21 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             raise TypeError('Not implemented yet')          # iconvsr_ipb.py:25-26
         if deform not in _DEFORM:
             raise TypeError('Not such DCN type')            # iconvsr_ipb.py:27-28
-        if blocktype not in ('drt',):
-            raise NotImplementedError(f"blocktype={blocktype!r}: only 'drt' (the shipped configs) is built")
-        if num_group != 1 or mid_channels != 64:
-            raise NotImplementedError('only mid_channels=64, num_group=1 (the shipped configs) are built')
-        if flow_inter != 'bilinear':
-            raise NotImplementedError("only flow_inter='bilinear'")
+        if blocktype not in _BLOCKTYPES:
+            # basicvsr_net.py:487-503 builds self.main for 'drt' and 'drt_woqp' only (any other value: AttributeError at forward)
+            raise NotImplementedError(f"blocktype={blocktype!r}: 'drt' | 'drt_woqp' (basicvsr_net.py:487-503)")
+        if blocktype == 'drt_woqp' and not one_layer:
+            # sr_backbone_utils.py:376-384 calls conv1 / conv2 on the bare map; a Dynamic_conv2d_se indexes it with 'x' and raises
+            raise NotImplementedError("blocktype='drt_woqp' runs only with one_layer=True (the reference raises in its first forward)")
+        if mid_channels != 64:
+            raise NotImplementedError('only mid_channels=64 (every shipped config; the kernels are built for 64-channel maps)')
+        if not isinstance(num_group, int) or num_group < 1 or 64 % num_group:
+            raise ValueError('in_channels must be divisible by groups')        # nn.Conv2d's own check
+        if sparse_val and num_group != 1:
+            raise NotImplementedError('sparse_val with num_group > 1: the reference multiplies a (64, 64/groups) weight with 64-channel '
+                                      'columns and raises (sr_backbone_utils.py:295)')
+        if flow_inter not in _FLOW_INTER:
+            raise NotImplementedError("flow_inter: 'bilinear' | 'nearest' (flow_warp.py:18)")
         if with_bias:
             assert use_base_qp is True or use_base_qp == 1     # iconvsr_ipb_par.py:27
         self.mid_channels = mid_channels
@@ -58,7 +69,8 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
             mid_channels=mid_channels, num_blocks=num_blocks, num_experts=num_experts, with_cat=int(with_cat),
             use_base_qp=int(use_base_qp), expert_softmax=int(expert_softmax), with_bias=int(with_bias),
             with_se=int(with_se), one_layer=int(one_layer), channel_first=int(channel_first),
-            align_key=int(align_key), vsr=int(vsr), deform=_DEFORM[deform], sparse_val=int(bool(sparse_val)))
+            align_key=int(align_key), vsr=int(vsr), deform=_DEFORM[deform], sparse_val=int(bool(sparse_val)),
+            num_group=int(num_group), flow_inter=_FLOW_INTER[flow_inter], blocktype=_BLOCKTYPES[blocktype])
         self._handle = ctypes.c_void_p()
         L = _native.lib()
         _native.check(L.pnp_generator_create(ctypes.byref(self._cfg), ctypes.byref(self._handle)),

@@ -44,6 +44,9 @@ def _chk(t, name):
     return t.contiguous()
 
 
+_WARP_MODES = {'bilinear': 0, 'nearest': 1}       # F.grid_sample modes flow_warp.py:47 can receive through flow_inter
+
+
 @_on_device_of_first_tensor
 def flow_warp(x, flow, interpolation='bilinear', padding_mode='zeros', align_corners=True):
     """Drop-in for mmedit.models.common.flow_warp (flow_warp.py:6-50).
@@ -51,24 +54,24 @@ def flow_warp(x, flow, interpolation='bilinear', padding_mode='zeros', align_cor
     if x.size()[-2:] != flow.size()[1:3]:
         raise ValueError(f'The spatial sizes of input ({x.size()[-2:]}) and '
                          f'flow ({flow.size()[1:3]}) are not the same.')
-    if interpolation != 'bilinear' or padding_mode != 'zeros' or not align_corners:
-        raise NotImplementedError('only bilinear / zeros / align_corners=True (what the hot path uses)')
+    if interpolation not in _WARP_MODES or padding_mode != 'zeros' or not align_corners:
+        raise NotImplementedError("only 'bilinear' | 'nearest' / zeros / align_corners=True (what the generator can ask for)")
     x, flow = _chk(x, 'x'), _chk(flow, 'flow')
     n, c, h, w = x.shape
     out = torch.empty_like(x)
-    _native.check(_native.lib().pnp_flow_warp_nchw_f32(_ptr(x), _ptr(flow), _ptr(out), n, c, h, w, _stream()),
-                  'pnp_flow_warp_nchw_f32')
+    _native.check(_native.lib().pnp_flow_warp_nchw_mode_f32(_ptr(x), _ptr(flow), _ptr(out), n, c, h, w, _WARP_MODES[interpolation],
+                                                            _stream()), 'pnp_flow_warp_nchw_mode_f32')
     return out
 
 
 @_on_device_of_first_tensor
-def mv_warp_nhwc(feat, flow_x, flow_y):
+def mv_warp_nhwc(feat, flow_x, flow_y, interpolation='bilinear'):
     """feat (h,w,c) pixel-major; flow_x/flow_y (h,w)."""
     feat, flow_x, flow_y = _chk(feat, 'feat'), _chk(flow_x, 'flow_x'), _chk(flow_y, 'flow_y')
     h, w, c = feat.shape
     out = torch.empty_like(feat)
-    _native.check(_native.lib().pnp_mv_warp_nhwc_f32(_ptr(feat), _ptr(flow_x), _ptr(flow_y), _ptr(out), h, w, c,
-                                                     _stream()), 'pnp_mv_warp_nhwc_f32')
+    _native.check(_native.lib().pnp_mv_warp_nhwc_mode_f32(_ptr(feat), _ptr(flow_x), _ptr(flow_y), _ptr(out), h, w, c,
+                                                          _WARP_MODES[interpolation], _stream()), 'pnp_mv_warp_nhwc_mode_f32')
     return out
 
 

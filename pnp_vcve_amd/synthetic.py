@@ -116,18 +116,24 @@ def state_dict_schema(cfg=None):
     for br in ('backward_resblocks', 'forward_resblocks'):
         sch[f'{br}.input_conv.0.weight'] = (mid, cin[br], 3, 3)
         sch[f'{br}.input_conv.0.bias'] = (mid,)
+        g = c.get('num_group', 1)                    # every conv of a block is grouped (sr_backbone_utils.py:285-289)
+        woqp = c.get('blocktype', 'drt') == 'drt_woqp'      # both 3x3 convs plain nn.Conv2d (:343-344, with one_layer)
         for i in range(nb):
             p = f'{br}.main.{i}.'
             if c.get('one_layer', False):
-                sch[p + 'conv1.weight'] = (mid, mid, 3, 3)
+                sch[p + 'conv1.weight'] = (mid, mid // g, 3, 3)
                 sch[p + 'conv1.bias'] = (mid,)
             else:
-                sch[p + 'conv1.weight'] = (E, mid, mid, 3, 3)
+                sch[p + 'conv1.weight'] = (E, mid, mid // g, 3, 3)
                 sch[p + 'conv1.bias'] = (E, mid)
-            sch[p + 'conv2.weight'] = (E, mid, mid, 3, 3)
-            sch[p + 'conv2.bias'] = (E, mid)
+            if woqp and c.get('one_layer', False):
+                sch[p + 'conv2.weight'] = (mid, mid // g, 3, 3)
+                sch[p + 'conv2.bias'] = (mid,)
+            else:
+                sch[p + 'conv2.weight'] = (E, mid, mid // g, 3, 3)
+                sch[p + 'conv2.bias'] = (E, mid)
             for k in ('conv16x16', 'conv16x8', 'conv8x8'):
-                sch[p + k + '.weight'] = (mid, mid, 1, 1)
+                sch[p + k + '.weight'] = (mid, mid // g, 1, 1)
     sch['conv_hr.weight'] = (64, 64, 3, 3)
     sch['conv_hr.bias'] = (64,)
     sch['conv_last.weight'] = (3, 64, 3, 3)

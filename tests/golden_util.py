@@ -65,6 +65,19 @@ GEN_CASES = [
     # than the old 1e-4 gate): partition branches x100, expert routing x30 -> par->0 2.2e-3, base*2 1.2e-3, allkey 3.3e-3, mvs->0 5e-3
     dict(name='gen_vsr_gain_64x64', cfg=dict(vsr=True), wseed=33, par_gain=100.0, caa_gain=30.0,
          clip=dict(seed=122, n=1, t=3, h=64, w=64, slices=[73, 66, 80], qp_mode='qp', crf=25)),
+    # r04: the constructor variants no shipped config uses and rounds 1-3 refused (VERDICT r03 "missing" 6): grouped convs
+    # (num_group, sr_backbone_utils.py:285-289), blocktype 'drt_woqp' (both 3x3 convs plain nn.Conv2d, :336-384; runs only with
+    # one_layer=True in the reference) and flow_inter='nearest' (flow_warp.py:8,47)
+    dict(name='gen_group4_64x64', cfg=dict(num_group=4, num_blocks=3), wseed=34, par_gain=10.0,
+         clip=dict(seed=123, n=1, t=3, h=64, w=64, slices=[73, 66, 80], qp_mode='qp', crf=25)),
+    dict(name='gen_group2_twolayer_chlast_64x64', cfg=dict(num_group=2, one_layer=False, channel_first=False, num_blocks=3), wseed=35,
+         par_gain=10.0, clip=dict(seed=124, n=1, t=3, h=64, w=64, slices='allP', qp_mode='ipb', crf=35)),
+    dict(name='gen_woqp_64x64', cfg=dict(blocktype='drt_woqp', num_blocks=3), wseed=36, par_gain=10.0,
+         clip=dict(seed=125, n=1, t=3, h=64, w=64, slices=[73, 66, 80], qp_mode='qp', crf=25)),
+    dict(name='gen_nearest_64x96', cfg=dict(flow_inter='nearest', num_blocks=3), wseed=37, par_gain=10.0,
+         clip=dict(seed=126, n=1, t=5, h=64, w=96, slices='IBBBP', qp_mode='qp', crf=25)),
+    dict(name='gen_woqp_group8_nearest_vsr_64x64', cfg=dict(blocktype='drt_woqp', num_group=8, flow_inter='nearest', vsr=True, num_blocks=2),
+         wseed=38, par_gain=10.0, clip=dict(seed=127, n=1, t=3, h=64, w=64, slices=[73, 80, 66], qp_mode='qp', crf=15)),
     # sparse_val=True (eval-time sparse evaluation of the 1x1 branches): maps with NON-binary values and overlapping
     # planes, so that "nonzero -> 1/255, later plane wins" is visible (a one-hot/255 map would equal the dense path)
     dict(name='gen_sparse_val_64x64', cfg=dict(sparse_val=True), wseed=25, par_gain=10.0, par_kind='overlap',
@@ -108,6 +121,10 @@ WARP_CASES = [
     dict(name='warp_oob_2x8x64x64', seed=203, shape=(2, 8, 64, 64), kind='oob'),
     dict(name='warp_block_1x64x40x56', seed=204, shape=(1, 64, 40, 56), kind='block'),
     dict(name='warp_zero_1x4x64x64', seed=205, shape=(1, 4, 64, 64), kind='zero'),
+    # r04: interpolation='nearest' (flow_inter); quarter-pel block vectors hit the .5 ties of nearbyint, 'oob' leaves the image
+    dict(name='warp_nearest_block_1x64x40x56', seed=206, shape=(1, 64, 40, 56), kind='block', mode='nearest'),
+    dict(name='warp_nearest_oob_2x8x64x64', seed=207, shape=(2, 8, 64, 64), kind='oob', mode='nearest'),
+    dict(name='warp_nearest_frac_1x16x64x96', seed=208, shape=(1, 16, 64, 96), kind='frac', mode='nearest'),
 ]
 
 

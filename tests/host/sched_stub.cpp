@@ -292,7 +292,7 @@ int launch_pack_last_valu(const float* w, float* dst, hipStream_t s) {
     stub::WR("vector-ALU conv_last weights", dst, 9 * 64 * 4 * 4);
     return 0;
 }
-int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, void* out, int H, int W, int C, hipStream_t s, bool f16) {
+int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, void* out, int H, int W, int C, hipStream_t s, bool f16, bool) {
     stub::cur = "launch_mv_warp_nhwc";
     stub::note_launch(s);
     const size_t hw = (size_t)H * W;
@@ -303,7 +303,7 @@ int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, voi
     stub::warps.push_back({feat, fx, out, f16});
     return 0;
 }
-int launch_flow_warp_nchw(const float* x, const float* flow, float* out, int N, int C, int H, int W, hipStream_t s) {
+int launch_flow_warp_nchw(const float* x, const float* flow, float* out, int N, int C, int H, int W, hipStream_t s, bool) {
     stub::cur = "launch_flow_warp_nchw";
     stub::note_launch(s);
     stub::RD("x", x, (size_t)N * C * H * W * 4);

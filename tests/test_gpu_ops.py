@@ -30,16 +30,17 @@ def maxdiff(a, b):
 
 def test_native_library_is_loaded():
     from pnp_vcve_amd import _native
-    assert _native.lib().pnp_abi_version() == 3
+    assert _native.lib().pnp_abi_version() == 4
 
 
 @pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])
 def test_flow_warp_nchw_vs_reference(case):
     from pnp_vcve_amd import ops
     x, flow = gu.warp_case_inputs(case)
-    out = ops.flow_warp(G(x), G(flow))
+    mode = case.get('mode', 'bilinear')
+    out = ops.flow_warp(G(x), G(flow), interpolation=mode)
     ref = gu.load_golden(case['name'])['out']
-    assert maxdiff(out, ref) < TOL_WARP
+    assert maxdiff(out, ref) < (TOL_WARP if mode == 'bilinear' else 1e-30)       # nearest copies pixels: bit-exact, ties included
 
 
 @pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])
@@ -49,9 +50,10 @@ def test_mv_warp_nhwc_vs_reference(case):
     ref = gu.load_golden(case['name'])['out']
     for n in range(x.shape[0]):
         feat = ops.nchw_to_nhwc(G(x[n:n + 1]))[0]
-        out = ops.mv_warp_nhwc(feat, G(flow[n, :, :, 0]), G(flow[n, :, :, 1]))
+        mode = case.get('mode', 'bilinear')
+        out = ops.mv_warp_nhwc(feat, G(flow[n, :, :, 0]), G(flow[n, :, :, 1]), interpolation=mode)
         back = ops.nhwc_to_nchw(out.unsqueeze(0))
-        assert maxdiff(back, ref[n:n + 1]) < TOL_WARP
+        assert maxdiff(back, ref[n:n + 1]) < (TOL_WARP if mode == 'bilinear' else 1e-30)
 
 
 def test_flow_warp_errors_like_reference():

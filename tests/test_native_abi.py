@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert debug == set(_native.DEBUG_SIGNATURES), debug ^ set(_native.DEBUG_SIGNATURES)
     for name in declared | debug:
         assert hasattr(lib, name), name
-    assert lib.pnp_abi_version() == 3
+    assert lib.pnp_abi_version() == 4
 
 
 def test_no_undeclared_pnp_symbol_is_exported(lib):
@@ -101,7 +101,26 @@ def test_c_abi_error_codes_without_a_gpu(lib):
     assert create(with_bias=0, with_se=1)[0] == 1001
     assert create(with_bias=1, use_base_qp=0)[0] == 1001
     assert create(deform=3)[0] == 1001
-    rc, h = create()
+    # r04 (ABI 4): num_group / flow_inter / blocktype
+    assert create(num_group=3)[0] == 1001 and create(num_group=128)[0] == 1001      # nn.Conv2d: channels % groups
+    assert create(flow_inter=2)[0] == 1001 and create(blocktype=2)[0] == 1001
+    assert create(blocktype=1, one_layer=0)[0] == 1002        # 'drt_woqp' with Dynamic_conv2d_se convs: the reference raises too
+    assert create(sparse_val=1, num_group=2)[0] == 1002       # ... and so does its sparse_conv on grouped 1x1 weights
+    rc, hg = create(num_group=4, blocktype=1, flow_inter=1)
+    assert rc == 0
+    lib.pnp_generator_param_name.restype = ctypes.c_char_p
+    shapes = {}
+    for i in range(lib.pnp_generator_num_params(hg)):
+        nm = lib.pnp_generator_param_name(hg, i).decode()
+        shapes[nm] = tuple(int(lib.pnp_generator_param_dim(hg, i, d)) for d in range(lib.pnp_generator_param_ndim(hg, i)))
+    assert shapes['forward_resblocks.main.1.conv2.weight'] == (64, 16, 3, 3)       # a plain conv, grouped
+    assert shapes['forward_resblocks.main.1.conv2.bias'] == (64,)
+    assert shapes['backward_resblocks.main.0.conv1.weight'] == (64, 16, 3, 3)
+    assert shapes['backward_resblocks.main.0.conv16x8.weight'] == (64, 16, 1, 1)
+    from pnp_vcve_amd import synthetic
+    assert shapes == {k: tuple(v) for k, v in synthetic.state_dict_schema(dict(num_blocks=2, num_group=4, blocktype='drt_woqp')).items()}
+    lib.pnp_generator_destroy(hg)
+    rc, h = create()            # (num_group left 0 = the reference's default 1)
     assert rc == 0 and h.value
     n32 = lib.pnp_generator_packed_floats(h)
     ctx = lib.pnp_generator_workspace_bytes(h, 7, 128, 128)

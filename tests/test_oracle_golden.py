@@ -43,9 +43,9 @@ def test_generator_matches_reference(case):
 @pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])
 def test_flow_warp_matches_reference(case):
     x, flow = gu.warp_case_inputs(case)
-    out = cpu_ref.flow_warp(T(x), T(flow)).numpy()
+    out = cpu_ref.flow_warp(T(x), T(flow), case.get('mode', 'bilinear')).numpy()
     ref = gu.load_golden(case['name'])['out']
-    assert np.abs(out - ref).max() < TOL
+    assert np.abs(out - ref).max() < (TOL if case.get('mode', 'bilinear') == 'bilinear' else 1e-30)      # nearest: a copy, bit-exact
 
 
 def test_flow_warp_size_mismatch_raises():
