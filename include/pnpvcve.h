@@ -103,7 +103,9 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     a chain of single-source launches through fp32 partial sums.  Bit-identical: same rounding points */
 #define PNP_OPT_F16_CHAIN_MIRRORS 7 /* with PNP_OPT_F16_MIRRORS: also mirror the running map x inside a branch (default 0: measured
                                     neutral at 720p -- the back half writes 128 B per pixel more for what the front half reads less) */
-#define PNP_OPT_COUNT 8
+#define PNP_OPT_TILE_QUEUE 8     /* PNP_PREC_F16X3: the split conv kernel's blocks draw their tiles from a per-XCD queue in the workspace instead of
+                                    walking a static share (tiles differ in cost and the two blocks of a CU in speed); results identical */
+#define PNP_OPT_COUNT 9
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 

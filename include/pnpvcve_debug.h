@@ -58,8 +58,11 @@ int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs_dev, const int* src_
                          const float* const* packed_w_f32_dev, const void* const* packed_w_x3_dev, const float* bias_dev,
                          const float* gamma_dev, const void* packed_w1x1_x3_dev, const float* par_dev,
                          const int* par_flags_dev, const float* residual_dev, int act, float* out_dev, int h, int w,
-                         int w1x1_scaled, void* trace_dev, void* stream);
-/* w1x1_scaled != 0: packed_w1x1_x3_dev holds 12 split chunks -- the three branch images and then the same three scaled by 1/255
+                         int w1x1_scaled, int* tile_queue_dev, void* trace_dev, void* stream);
+/* tile_queue_dev: NULL (every block walks a static share of the tiles) or 16 ints, zero on entry and zero again when the launch
+ * has finished: the blocks draw their tiles per XCD from it, as pnp_generator_forward's launches do from its workspace
+ * (PNP_OPT_TILE_QUEUE).
+ * w1x1_scaled != 0: packed_w1x1_x3_dev holds 12 split chunks -- the three branch images and then the same three scaled by 1/255
  * (what pnp_generator_pack lays out) -- and tiles whose partition values are all 0 or exactly 1/255 (par_flags bits 3..5) contract
  * the branches with the scaled images and a masked A operand instead of re-splitting par_j(pixel) * x.  trace_dev may be NULL. */
 

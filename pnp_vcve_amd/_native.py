@@ -87,7 +87,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     'pnp_conv3x3_f16x3_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'pnp_conv3x3_f32_ex': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p]),
@@ -105,7 +105,8 @@ DEBUG_SIGNATURES['pnp_conv3x3_f16_maps'] = (c_int, [c_int, POINTER(c_void_p), PO
 DEBUG_SIGNATURES['pnp_mv_warp_nhwc_f16out'] = (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p])
 
 # pnp_generator_set_option ids (include/pnpvcve.h)
-OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_SMALL_F16, OPT_SPARSE_EVAL, OPT_F16_MIRRORS, OPT_F16_CHAIN_MIRRORS = range(8)
+(OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_SMALL_F16, OPT_SPARSE_EVAL, OPT_F16_MIRRORS, OPT_F16_CHAIN_MIRRORS,
+ OPT_TILE_QUEUE) = range(9)
 CONV_AUTO, CONV_TILE, CONV_TILE_BIG = range(3)
 
 _lib = None

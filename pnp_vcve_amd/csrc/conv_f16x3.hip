@@ -32,7 +32,7 @@ namespace {
 
 constexpr int X3_RING = 3;
 constexpr int X3_CHUNK = 8 * UNIT;                            // 4 k-steps x 2 N tiles
-static_assert(2 * ((TH + 2) * PW * 288 + 256 + X3_RING * X3_CHUNK) <= 160 * 1024, "two blocks per CU");
+static_assert(2 * ((TH + 2) * PW * 288 + 272 + X3_RING * X3_CHUNK) <= 160 * 1024, "two blocks per CU");
 constexpr int X3_AIT = (NPIX * 16 + 255) / 256;               // 12 16-byte halo loads per thread (fp32 source)
 constexpr float X3_SCALE = 2048.f, X3_INV = 1.f / 2048.f;
 
@@ -58,6 +58,11 @@ struct X3Args {
     const _Float16* w2[2];
     const float* lr4;            // (H, W, 4) fp32, 4th channel zero, or nullptr
     const _Float16* wlr;         // its split image: 2 chunks (k = 4 tap + channel)
+    // Tile queue (r04) or nullptr: 8 per-XCD ticket counters + a count of finished blocks, all zero between launches.  A block's first
+    // tile is static (band_lo + blockIdx / 8); every further one is band_lo + per + ticket.  Tiles differ in cost (a front-half tile runs
+    // 18..24 chunks) and so do blocks (the one that reached its CU first wins the issue arbitration: 19.6 k against 24.6 k cycles per
+    // tile): on a static split the launch lasts as long as its unluckiest block
+    int* queue;
 };
 
 // Halo geometry: 10 rows x 18 pixels x 16 float4.  Requests 0..9: row k, pixels 0..15 (thread t: pixel t >> 4, float4 t & 15);
@@ -77,7 +82,7 @@ struct X3Args {
 // the first set lands on the even slots and the second on the odd ones for every tap -- conflict-free; the 144-B stride of the
 // 32x32x16 image (one plane per pixel) cannot do that for any lane -> pixel mapping.
 constexpr int XPSB = 288, XRSB = PW * XPSB;                  // pixel / row stride of the split A tile
-constexpr int XPARK = 256;                                   // where idle lanes of the side requests put their (unused) halves
+constexpr int XPARK = 256 + 16;                              // where idle lanes of the side requests put their (unused) halves; + the queue mailbox
 
 // a pointer chosen at run time by wave-uniform values, made PROVABLY uniform (the descriptor built from it must live in scalar
 // registers: otherwise every buffer access becomes a waterfall loop)
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     constexpr int NREQ = S4 ? ROWS + 1 : X3_AIT;             // 16-byte halo requests per thread
     constexpr int CW = NTW * 4, PPI = 64 / CW, EIT = 32 / PPI;   // epilogue: float4 per pixel in the wave's N range, pixels per instruction
     constexpr int RQR = 13;                              // chunk at whose top the residual rows are requested
+    constexpr int QW = 5, QR = 8;                        // chunks at whose top the queue ticket enters / leaves the mailbox (two barriers apart)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     unsigned long long dbg_t0 = 0, dbg_p = 0, dbg_k = 0, dbg_e = 0;
@@ -121,9 +127,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     // blocks walk the band interleaved (block i takes tiles i, i + per, ...), so at any moment an XCD works on one window of
     // consecutive tiles whose shared halo rows meet in its L2.
     const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;
-    const int band_hi = (int)((long)ntiles * (xcd + 1) / 8);
-    int tile = (int)((long)ntiles * xcd / 8) + (blockIdx.x >> 3);
-    if (tile >= band_hi) return;
+    const int band_lo = (int)((long)ntiles * xcd / 8), band_hi = (int)((long)ntiles * (xcd + 1) / 8);
+    int tile = band_lo + (blockIdx.x >> 3);
+    int* const queue = a.queue;                              // (uniform) nullptr: the static walk tile, tile + per, ...
+    auto leave_queue = [&]() {                               // the last block to leave zeroes the counters for the next launch
+        if (queue && t == 0) {
+            if (atomicAdd(queue + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(queue + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (tile >= band_hi) {
+        leave_queue();
+        return;
+    }
     char* const sR = smem + ABY;
 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
@@ -143,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
     const __amdgpu_buffer_rsrc_t r_lr = make_rsrc(has_lr ? (const void*)a.lr4 : (const void*)a.src, has_lr ? (unsigned)H * (unsigned)W * 16u : 0);
     const __amdgpu_buffer_rsrc_t r_wlr = make_rsrc(has_lr ? (const void*)a.wlr : (const void*)a.w, 2u * X3_CHUNK);
     char* const sL = smem + ROWS * XRSB + XPARK;
+    char* const mailbox = smem + ROWS * XRSB + 256;
     f32x4 lrreg = (f32x4)(0.f);                              // the thread's pixel of the next tile's RGB halo (t < ROWS * PW)
     // RGB A fragments: k = 32 kh + 8 lg + jj = 4 tap + channel -> the lane's 8 k values are taps 8 kh + 2 lg, + 1 (4 channels each);
     // taps beyond 8 carry zero weights and re-read tap 8 (finite values)
@@ -264,8 +283,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         unsigned long long dbg_a = 0, dbg_b = 0, dbg_c = 0;
         if (DBG) dbg_a = __builtin_amdgcn_s_memtime();
         const int ty0 = (tile / tiles_x) * THX, tx0 = (tile % tiles_x) * TW;
-        const int next = tile + per;
-        const bool has_next = next < band_hi;
+        // the tile after this one: static, or (queue) a ticket drawn now by thread 0, passed through the mailbox at chunks QW -> QR and
+        // known to every wave from chunk QR on (first needed at chunk 14)
+        int next = tile + per;
+        bool has_next = !queue && next < band_hi;
+        int ticket = 0;
+        if (queue && t == 0) ticket = atomicAdd(queue + xcd, 1);
         // ---- K loop: chunk c (one 32-deep k-step) from ring slot c % 3: hi*hi -> acc_hi, lo*hi + hi*lo -> acc_lo
         f32x4 acc_hi[2][NTW], acc_lo[2][NTW];
 #pragma unroll
@@ -333,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
 #pragma nounroll
         for (int pass = 0;; ++pass) {
         const bool last = pass + 1 == npass;
-        const int nx_tile = last ? (has_next ? next : tile) : tile;
-        const bool nx_live = last ? has_next : true;
+        int nx_tile = last ? (has_next ? next : tile) : tile;
+        bool nx_live = last ? has_next : true;
         if (MS) {       // both descriptors are rebuilt in every pass (nothing loop-carried: a descriptor phi would leave the scalar registers)
             // (static indices only: a run-time index into the kernel arguments would move them to scratch)
             r_src = make_rsrc(uniform_ptr(last ? a.src : (pass == 0 ? a.src2[0] : a.src2[1])), map_bytes);        // whose halo this pass requests
@@ -411,6 +434,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         auto chunk = [&](auto c_tag, auto fast_tag) __attribute__((always_inline)) {
             constexpr int c = decltype(c_tag)::v;
             constexpr bool FAST = decltype(fast_tag)::v != 0;
+            // every wave writes its own mailbox word (no run-time guard inside a chunk: it would cut the dealt block); wave 0's is the ticket
+            if (c == QW) *reinterpret_cast<volatile int*>(mailbox + wave * 4) = __builtin_amdgcn_readfirstlane(ticket);
+            if (c == QR) {
+                const int drawn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(mailbox));
+                next = queue ? band_lo + per + drawn : tile + per;
+                has_next = next < band_hi;
+                nx_tile = last ? (has_next ? next : tile) : tile;
+                nx_live = last ? has_next : true;
+            }
             // (branch chunks are requested and written to the ring whether or not the tile runs them: a run-time guard here would cut
             //  chunks 14.. into basic blocks and the dealt schedule with them; an unneeded chunk is 8 KiB from L2 into a free slot)
             if (c + NSET < NC) request_chunk(c + NSET);
@@ -596,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
         tile = next;
         lds_barrier();                   // the transposition rows are read: the next tile may overwrite the A tile
     }
+    leave_queue();
     if (DBG && t == 0) {
         unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
         d[0] = dbg_t0;
@@ -644,7 +677,9 @@ int launch_x3_t(const X3Args& xa, hipStream_t stream) {
     const int tiles = ((xa.W + TW - 1) / TW) * ((xa.H + th - 1) / th);
     int per_xcd = (tiles + 7) / 8;                // blocks per XCD: two per CU at most (32 CUs), one tile each on small frames
     if (per_xcd > 64) per_xcd = 64;
-    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(256), lds, stream, xa);
+    X3Args xq = xa;
+    if (tiles <= 8 * per_xcd) xq.queue = nullptr;       // one tile per block: nothing to hand out (128x128: 2870 -> 2230 frames/s with it)
+    hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(256), lds, stream, xq);
     return (int)hipGetLastError();
 }
 
@@ -694,6 +729,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
             x.H = a.H;
             x.W = a.W;
             x.act = a.act;
+            x.queue = a.tile_queue;
             x.dbg = nullptr;
             if (a.out_mode == 1) {
                 x.o_sy = (unsigned)a.W * 1024u;
@@ -755,6 +791,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         x.H = a.H;
         x.W = a.W;
         x.act = a.act;
+        x.queue = a.tile_queue;
         x.o_sy = (unsigned)a.W * 256u;
         x.o_sx = 256u;
         x.o_c0 = 0;
@@ -781,6 +818,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream) {
         x.H = a.H;
         x.W = a.W;
         x.act = last ? a.act : 0;
+        x.queue = a.tile_queue;
         x.dbg = a.dbg;
         x.o_sy = (unsigned)a.W * 256u;
         x.o_sx = 256u;

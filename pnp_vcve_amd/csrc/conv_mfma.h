@@ -14,6 +14,7 @@ struct ConvArgs {
                             // interleaved, twice the halfs; conv_f16x3.hip launch_f16x3_image)
     const void* wpar_h;
     int wpar_h_scaled;      // prec == 2: wpar_h holds 12 split chunks -- the three branch images, then the same three scaled by PNP_PAR_UNIT
+    int* tile_queue;        // prec == 2: 16 zeroed ints the split kernel hands its tiles out from (conv_f16x3.hip, X3Args::queue), or nullptr
     int prec;               // 0 fp32 MFMA | 1 fp16 operands, fp32 accumulate (where conv_f16_eligible)
                             // 2 split fp16 (hi + lo / 2048, three MFMAs per product, fp32-level results; where conv_f16x3_eligible)
     int src_f16, out_f16;   // prec 1, out_mode 0: bit s of src_f16: src[s] IS an fp16 NHWC64 map (the mirror its producer

@@ -68,7 +68,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
-    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0};   // pnp_generator_set_option (defaults: everything on)
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1};   // pnp_generator_set_option (defaults: everything on but the chain mirrors)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -373,6 +373,7 @@ struct Workspace {
     // the MV-aligned key frame is then fp16 only and lives in kw
     uint16_t *x16, *slots16;
     int* parflags;    // per frame, per 8x16 tile: which partition planes are nonzero there (ConvArgs::par_flags)
+    int* queue;       // PNP_PREC_F16X3: the split kernel's tile queue (ConvArgs::tile_queue), 16 ints, zero between launches
     int64_t bytes;
 };
 
@@ -426,6 +427,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     W.x16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32)) : nullptr;
     W.slots16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32 * t)) : nullptr;
     W.parflags = reinterpret_cast<int*>(take((int64_t)t * ((w + 15) / 16) * ((h + 7) / 8)));
+    W.queue = g->prec == PNP_PREC_F16X3 ? reinterpret_cast<int*>(take(16)) : nullptr;
     W.bytes = off;
     return W;
 }
@@ -653,6 +655,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
         a.par_flags = q.par_flags_;
+        a.tile_queue = (g->prec == PNP_PREC_F16X3 && g->opt[PNP_OPT_TILE_QUEUE]) ? W.queue : nullptr;
         a.par_plane = (long)q.H * q.W;
         a.bias = q.bias_;
         a.gamma = q.gamma_;
@@ -732,6 +735,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         const float* qe = c.use_base_qp ? bq : qp;
 
         g->prof_last = nullptr;           // untimed launches follow
+        if (W.queue) {                    // the last block of every launch leaves the queue zeroed; once per clip in case a launch was cut short
+            const hipError_t e = hipMemsetAsync(W.queue, 0, 16 * sizeof(int), st);
+            if (e != hipSuccess) return (int)e;
+        }
         rc = launch_pack_lr(lr_b, W.lr4, t, h, w, st);
         if (rc) return rc;
         if (c.sparse_val && g->opt[PNP_OPT_SPARSE_EVAL]) {   // the reference's (eval-mode) sparse evaluation as a dense map (prep.hip)
@@ -1329,13 +1336,13 @@ int pnp_conv3x3_f16x3(int nsrc, const float* const* srcs, const int* src_channel
                       const void* const* packed_w_x3, const float* bias, const float* gamma, const void* packed_w1x1_x3,
                       const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w, void* st) {
     return pnp_conv3x3_f16x3_ex(nsrc, srcs, src_channels, packed_w_f32, packed_w_x3, bias, gamma, packed_w1x1_x3, par, par_flags,
-                                residual, act, out, h, w, 0, nullptr, st);
+                                residual, act, out, h, w, 0, nullptr, nullptr, st);
 }
 
 int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w_f32,
                          const void* const* packed_w_x3, const float* bias, const float* gamma, const void* packed_w1x1_x3,
                          const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
-                         int w1x1_scaled, void* trace, void* st) {
+                         int w1x1_scaled, int* tile_queue, void* trace, void* st) {
     if (nsrc < 1 || nsrc > 4 || !srcs || !src_channels || !packed_w_x3 || !out) return PNP_ERR_BAD_ARG;
     if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;      // 32-bit byte offsets into a map
     ConvArgs a;
@@ -1353,6 +1360,7 @@ int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs, const int* src_chan
     a.wpar_h_scaled = (packed_w1x1_x3 && w1x1_scaled) ? 1 : 0;
     a.par = par;
     a.par_flags = par_flags;
+    a.tile_queue = tile_queue;
     a.par_plane = (long)h * w;
     a.bias = bias;
     a.gamma = gamma;

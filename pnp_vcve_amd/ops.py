@@ -184,10 +184,11 @@ def f16x3_image(packed):
 
 @_on_device_of_first_tensor
 def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=None, par_flags=None, residual=None, act=0,
-                  trace=None, scaled_w1x1=False):
+                  trace=None, scaled_w1x1=False, tile_queue=None):
     """conv3x3 in split fp16 (pnp_conv3x3_f16x3, PNP_PREC_F16X3): packed_w / packed_w1x1 are the fp32 images of conv3x3 (their
     split images are made here) or, for 64-channel sources / the 1x1 branches, float16 tensors that already are f16x3_image()
-    results.  fp32 sources, fp32 result at fp32-level accuracy."""
+    results.  fp32 sources, fp32 result at fp32-level accuracy.  tile_queue: 16 zeroed int32 (the generator's per-context queue:
+    blocks draw their tiles from it instead of walking a static share; left zeroed by every launch)."""
     srcs = [_chk(s, 'src') for s in srcs]
     h, w = srcs[0].shape[:2]
     n = len(srcs)
@@ -217,14 +218,16 @@ def conv3x3_f16x3(srcs, packed_w, bias=None, gamma=None, packed_w1x1=None, par=N
     sc = (ctypes.c_int * n)(*[s.shape[2] for s in srcs])
     keep = [(_chk(t, 'arg') if t is not None else None) for t in (bias, gamma, par, residual)]
     one = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    if trace is None and not scaled_w1x1:
+    if tile_queue is not None and (tile_queue.dtype != torch.int32 or tile_queue.numel() < 16 or not tile_queue.is_cuda):
+        raise TypeError('tile_queue: 16 int32 on the device')
+    if trace is None and not scaled_w1x1 and tile_queue is None:
         _native.check(_native.lib().pnp_conv3x3_f16x3(n, vp(srcs), sc, vp(packed_w), vp(x3), _ptr(keep[0]), _ptr(keep[1]),
                                                       one(p_x3), _ptr(keep[2]), one(par_flags), _ptr(keep[3]), act,
                                                       _ptr(out), h, w, _stream()), 'pnp_conv3x3_f16x3')
-    else:       # include/pnpvcve_debug.h: in-kernel timeline
+    else:       # include/pnpvcve_debug.h: in-kernel timeline, scaled branch images, tile queue
         _native.check(_native.lib().pnp_conv3x3_f16x3_ex(n, vp(srcs), sc, vp(packed_w), vp(x3), _ptr(keep[0]), _ptr(keep[1]),
                                                          one(p_x3), _ptr(keep[2]), one(par_flags), _ptr(keep[3]), act,
-                                                         _ptr(out), h, w, int(bool(scaled_w1x1)), one(trace), _stream()),
+                                                         _ptr(out), h, w, int(bool(scaled_w1x1)), one(tile_queue), one(trace), _stream()),
                       'pnp_conv3x3_f16x3_ex')
     return out
 

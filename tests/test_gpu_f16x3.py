@@ -402,3 +402,31 @@ def test_f16x3_front_half_is_bit_stable_under_unrelated_traffic(scaled):
     for _ in range(6):
         torch.randn(1 << 22, device='cuda').sin_()
         assert torch.equal(ops.conv3x3_f16x3([xs], pw, **args), first)
+
+
+@pytest.mark.parametrize('hw', [(264, 272), (720, 1280)], ids=lambda s: '%dx%d' % s)
+def test_f16x3_tile_queue_hands_out_the_same_tiles_and_resets_itself(hw):
+    """PNP_OPT_TILE_QUEUE / pnp_conv3x3_f16x3_ex(tile_queue): blocks draw their tiles from per-XCD ticket counters instead of
+    walking a static share (561 and 7200 tiles on 512 blocks here).  Which block computes a tile does not enter its value: the
+    result is bit-identical; the last block to leave zeroes the 9 counters, so back-to-back launches need no host reset."""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x, wt, b, gam, w1, par = _front_half_inputs(40, h, w, 1.0)
+    par = (par * (np.float32(1.0) / np.float32(255.0))).astype(np.float32)
+    xs, pg = ops.nchw_to_nhwc(G(x))[0], G(par)
+    res = torch.randn(h, w, 64, device=dev(), generator=torch.Generator(device=dev()).manual_seed(5))
+    pw = [ops.pack_conv3x3(G(wt))]
+    q = torch.zeros(16, dtype=torch.int32, device=dev())
+    front = dict(bias=G(b), gamma=G(gam), packed_w1x1=ops.pack_conv1x1([G(v) for v in w1]), par=pg, par_flags=ops.par_tile_flags(pg),
+                 act=1, scaled_w1x1=True)
+    back = dict(bias=G(b), residual=res)
+    for kw in (front, back):
+        ref = ops.conv3x3_f16x3([xs], pw, **kw)
+        for _ in range(3):
+            assert torch.equal(ops.conv3x3_f16x3([xs], pw, tile_queue=q, **kw), ref)
+            assert int(q.abs().sum()) == 0
+    # several sources in one launch (the MS instantiation walks its passes inside a tile)
+    ref = ops.conv3x3_f16x3([xs, res], pw + pw, bias=G(b), act=2)
+    assert torch.equal(ops.conv3x3_f16x3([xs, res], pw + pw, bias=G(b), act=2, tile_queue=q), ref) and int(q.abs().sum()) == 0
+    with pytest.raises(TypeError):
+        ops.conv3x3_f16x3([xs], pw, tile_queue=torch.zeros(16, device=dev()))

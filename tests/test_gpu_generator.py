@@ -738,3 +738,20 @@ def test_exact_and_split_paths_are_run_to_run_deterministic_under_unrelated_traf
         junk = torch.randn(1 << 24, device=dev())
         junk.sin_().mul_(junk)                               # unrelated traffic and arithmetic between the runs
         assert torch.equal(once(), first), (precision, hw, rep)
+
+
+def test_split_path_tile_queue_switch_changes_no_bit():
+    """PNP_OPT_TILE_QUEUE (default on): the split-fp16 conv launches of a 720p clip with and without the tile queue give the same
+    bits, two samples on two streams included (each context has its own queue in the workspace)."""
+    from pnp_vcve_amd import _native
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    sd_np = gu.syn.make_state_dict(cfg, seed=173, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=174, n=2, t=3, h=720, w=1280, slices='IBBBP', par_classes=3)
+    m = build(cfg, sd_np)
+    m.precision = 'f16x3'
+    assert m.get_option(_native.OPT_TILE_QUEUE) == 1
+    with_queue = run(m, clip)
+    m.set_option(_native.OPT_TILE_QUEUE, 0)
+    assert torch.equal(run(m, clip), with_queue)
+    m.set_option(_native.OPT_TILE_QUEUE, 1)
+    assert torch.equal(run(m, clip), with_queue)

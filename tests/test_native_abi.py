@@ -129,10 +129,10 @@ def test_c_abi_error_codes_without_a_gpu(lib):
     assert lib.pnp_generator_set_precision(h, 1) == 0 and lib.pnp_generator_get_precision(h) == 1
     assert lib.pnp_generator_packed_floats(h) == n32 + n32 // 2          # fp16 mirror of every image
     assert lib.pnp_generator_workspace_bytes(h, 7, 128, 128) > ctx       # + mirror of the mixed experts
-    for opt in range(8):                                                 # per-handle switches, default on (the last one off)
+    for opt in range(9):                                                 # per-handle switches, default on (the chain mirrors off)
         assert lib.pnp_generator_get_option(h, opt) == (0 if opt == 7 else 1)
     assert lib.pnp_generator_set_option(h, 3, 0) == 0 and lib.pnp_generator_get_option(h, 3) == 0
-    assert lib.pnp_generator_set_option(h, 8, 0) == 1001 and lib.pnp_generator_get_option(h, 8) == -1     # v2's fused-block switch is gone
+    assert lib.pnp_generator_set_option(h, 9, 0) == 1001 and lib.pnp_generator_get_option(h, 9) == -1
     assert n32 % 4096 == 0 and ctx % 256 == 0
     lib.pnp_generator_destroy(h)
 

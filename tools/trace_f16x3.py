@@ -29,7 +29,11 @@ gam = torch.rand(64, device=dev) + 0.5
 tiles = ((h + 7) // 8) * ((w + 15) // 16)
 
 
-def trace(name, fn):
+QUEUE = torch.zeros(16, dtype=torch.int32, device=dev) if '--queue' in sys.argv else None    # the generator's tile queue
+
+
+def trace(name, fn0):
+    fn = lambda t: fn0(t, QUEUE)
     dbg = torch.zeros(512 * 8, dtype=torch.int64, device=dev)
     for _ in range(3):
         fn(None)
@@ -51,15 +55,15 @@ def trace(name, fn):
     print(f'    block lifetime: mean {tot.mean():.0f} cycles, max {tot.max()}; 12 MFMAs x 32 cycles per wave and chunk = 384, 18 chunks = 6912')
 
 
-trace('conv_hr-like (no branches, no residual)', lambda t: ops.conv3x3_f16x3([x], [pw3], bias=bias, act=2, trace=t))
-trace('back half (+ residual)', lambda t: ops.conv3x3_f16x3([x], [pw3], bias=bias, residual=r, trace=t))
-trace('front half (branch skipping)', lambda t: ops.conv3x3_f16x3([x], [pw3], bias=bias, gamma=gam, packed_w1x1=p13, par=par, par_flags=flags, act=1, trace=t))
+trace('conv_hr-like (no branches, no residual)', lambda t, q: ops.conv3x3_f16x3([x], [pw3], bias=bias, act=2, trace=t, tile_queue=q))
+trace('back half (+ residual)', lambda t, q: ops.conv3x3_f16x3([x], [pw3], bias=bias, residual=r, trace=t, tile_queue=q))
+trace('front half (branch skipping)', lambda t, q: ops.conv3x3_f16x3([x], [pw3], bias=bias, gamma=gam, packed_w1x1=p13, par=par, par_flags=flags, act=1, trace=t, tile_queue=q))
 p1_f32 = ops.pack_conv1x1([torch.randn(64, 64, 1, 1, device=dev) * 0.1 for _ in range(3)])
 par255 = (par * 255.0).round() * (torch.ones((), device=dev) / 255.0)          # exactly 0 or float32(1) / float32(255)
 flags255 = ops.par_tile_flags(par255)
 print('tiles on the binary-map fast path:', int((((flags255 >> 3) & flags255 & 7) == (flags255 & 7)).sum()), 'of', flags255.numel())
 trace('front half, binary-map fast path (masked operand, weights x 1/255)',
-      lambda t: ops.conv3x3_f16x3([x], [pw3], bias=bias, gamma=gam, packed_w1x1=p1_f32, par=par255, par_flags=flags255, act=1, trace=t,
+      lambda t, q: ops.conv3x3_f16x3([x], [pw3], bias=bias, gamma=gam, packed_w1x1=p1_f32, par=par255, par_flags=flags255, act=1, trace=t, tile_queue=q,
                                   scaled_w1x1=True))
 trace('front half, same map, general path',
-      lambda t: ops.conv3x3_f16x3([x], [pw3], bias=bias, gamma=gam, packed_w1x1=p1_f32, par=par255, par_flags=flags255, act=1, trace=t))
+      lambda t, q: ops.conv3x3_f16x3([x], [pw3], bias=bias, gamma=gam, packed_w1x1=p1_f32, par=par255, par_flags=flags255, act=1, trace=t, tile_queue=q))
