@@ -703,8 +703,8 @@ def opt_in_720p(sec):
     """compact summary of the opt-in arithmetics at the headline shape (the headline `value` itself is exact fp32)"""
     out = {'unit': 'frames/s'}
     for e in sec:
-        if e.get('workload') == '720p' and e.get('precision') == 'fp32' and e.get('clips_per_step') == 2:
-            out['fp32_two_clips_interleaved'] = e['value']
+        if e.get('workload') == '720p' and e.get('precision') in ('fp32', 'f16x3') and e.get('clips_per_step') == 2:
+            out[e['precision'] + '_two_clips_interleaved'] = e['value']
         if e.get('workload') == '720p' and e.get('precision') in ('fp16', 'f16x3') and e.get('clips_per_step') == 1:
             out[e['precision']] = e['value']
             out[e['precision'] + '_frac'] = e['roofline']['frac']
@@ -844,6 +844,8 @@ def secondary_workloads(dev, T, no_cpu_baseline=False):
         dict(name='7x3x720x1280 fp32, 2 clips per step interleaved on two streams (each fills the partial last round of tiles and the '
                   'dispatch gaps of the other\'s conv launches; bit-identical to one at a time)', workload='720p', precision='fp32',
              vsr=False, clips=2, steps=3, warmup=1),
+        dict(name='7x3x720x1280 split-fp16 convs, 2 clips per step interleaved on two streams (as above; each context has its own tile '
+                  'queue)', workload='720p', precision='f16x3', vsr=False, clips=2, steps=3, warmup=1),
     ]
     cpu128 = None if no_cpu_baseline else cpu_baseline_128(T)
     for sp in specs:

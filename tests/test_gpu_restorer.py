@@ -183,18 +183,19 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
     assert 'cpu' not in ns                                      # --no-cpu-baseline covers the 128x128 CPU leg too
     assert d['secondary_file'] == 'bench_secondary.json'
     oi = d['opt_in_720p']                                       # the opt-in arithmetics at the headline shape, compact
-    assert oi['fp32_two_clips_interleaved'] > 1.005 * d['value']
+    assert oi['fp32_two_clips_interleaved'] > 1.005 * d['value'] and oi['f16x3_two_clips_interleaved'] > 1.005 * oi['f16x3']
     assert oi['f16x3'] > 1.8 * d['value'] and oi['fp16'] > 3 * d['value'] and oi['f16x3_bound'] == 'mfma' and oi['fp16_bound'] == 'hbm'
     with open(side) as fh:
         full = json.load(fh, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
     assert full['value'] == d['value'] or abs(full['value'] - d['value']) < 1e-4 * d['value']
     assert 'definition' in full['roofline'] and 'device_ms_per_step' in full['roofline']      # the prose lives here, not on stdout
     sec = full['secondary']
-    assert len(sec) == 10 and sec[8]['clips_per_step'] == 2 and sec[8]['workload'] == '720p' and sec[8]['roofline']['per_launch_frac'] > 0
-    e2e = sec[9]                                   # the whole tools/test.py loop on an on-disk tree
+    assert len(sec) == 11 and sec[8]['clips_per_step'] == 2 and sec[8]['workload'] == '720p' and sec[8]['roofline']['per_launch_frac'] > 0
+    assert sec[9]['clips_per_step'] == 2 and sec[9]['precision'] == 'f16x3'
+    e2e = sec[10]                                   # the whole tools/test.py loop on an on-disk tree
     assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
     assert e2e['seconds_total'] >= e2e['seconds_generator_forward'] > 0
-    for e in sec[:9]:
+    for e in sec[:10]:
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
             rf = e['roofline']
