@@ -11,6 +11,10 @@
 // pixels' taps are neighbouring segments (L2/TA friendly).  No LDS is needed: there is no
 // reuse beyond what a 4-tap footprint shares through L1/L2.
 #include "warp.h"
+#include "f16_util.h"
+#ifndef WARP_RPT
+#define WARP_RPT 2
+#endif
 
 namespace {
 
@@ -37,8 +41,6 @@ __device__ __forceinline__ void tap_setup(float x, float y, float fx, float fy, 
     wx1 = ix - fx0;
     wy1 = iy - fy0;
 }
-
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 // feat/out: [H][W][C4*4] ; fxp/fyp: [H][W] planes (two channel planes of the NCHW mvs tensor)
 // OUT16: the aligned map is written as fp16 (8 B per lane).  On the fp16-operand conv path it is read only as an MFMA A
@@ -95,6 +97,71 @@ __global__ __launch_bounds__(256) void mv_warp_nhwc_kernel(const float* __restri
     }
 }
 
+// The 64-channel case (every call of the generator): 16 lanes per pixel, RPT pixel rows per thread, no index division (grid.x walks a
+// row in groups of 16 pixels, grid.y the row groups) and every tap through a buffer descriptor -- a tap outside the image gets the
+// offset OOB and loads zeros, so the 4 x RPT loads of a thread are in flight together with no exec-mask juggling in between.
+// r04: 97 us -> see DESIGN.md 3.2 (the grid-stride kernel above spent two 64-bit divisions per float4 and issued its taps under
+// four divergent branches).
+template <bool OUT16, bool NEAREST, int RPT>
+__global__ __launch_bounds__(256) void mv_warp_nhwc64_kernel(const float* __restrict__ feat, const float* __restrict__ fxp,
+                                                             const float* __restrict__ fyp, void* __restrict__ out, int H, int W) {
+    const int c4 = threadIdx.x & 15, x = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(feat, map_bytes);
+    const __amdgpu_buffer_rsrc_t r_fx = make_rsrc(fxp, (unsigned)H * (unsigned)W * 4u), r_fy = make_rsrc(fyp, (unsigned)H * (unsigned)W * 4u);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(out, OUT16 ? map_bytes / 2 : map_bytes);
+    const bool col_ok = x < W;
+    float fx[RPT], fy[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int y = blockIdx.y * RPT + r;
+        const unsigned po = (col_ok & (y < H)) ? ((unsigned)y * (unsigned)W + (unsigned)x) * 4u : OOB;
+        fx[r] = buf_load1(r_fx, po);
+        fy[r] = buf_load1(r_fy, po);
+    }
+    f32x4 v[RPT][4];
+    float wt[RPT][4];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int y = blockIdx.y * RPT + r;
+        if (NEAREST) {
+            float ix, iy;
+            sample_coords((float)x, (float)y, fx[r], fy[r], H, W, ix, iy);
+            const int xn = (int)rintf(ix), yn = (int)rintf(iy);
+            const bool ok = (xn >= 0) & (xn < W) & (yn >= 0) & (yn < H);
+            v[r][0] = buf_load4(r_in, ok ? ((unsigned)yn * (unsigned)W + (unsigned)xn) * 256u + (unsigned)c4 * 16u : OOB);
+        } else {
+            int x0, y0;
+            float wx1, wy1;
+            tap_setup((float)x, (float)y, fx[r], fy[r], H, W, x0, y0, wx1, wy1);
+            const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;   // == (x0+1) - ix
+            const bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x0 + 1 >= 0) & (x0 + 1 < W);
+            const bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y0 + 1 >= 0) & (y0 + 1 < H);
+            const unsigned r0 = (unsigned)(y0 * W + x0) * 256u + (unsigned)c4 * 16u, r1 = r0 + (unsigned)W * 256u;
+            v[r][0] = buf_load4(r_in, (vx0 & vy0) ? r0 : OOB);
+            v[r][1] = buf_load4(r_in, (vx1 & vy0) ? r0 + 256u : OOB);
+            v[r][2] = buf_load4(r_in, (vx0 & vy1) ? r1 : OOB);
+            v[r][3] = buf_load4(r_in, (vx1 & vy1) ? r1 + 256u : OOB);
+            wt[r][0] = wx0 * wy0, wt[r][1] = wx1 * wy0, wt[r][2] = wx0 * wy1, wt[r][3] = wx1 * wy1;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int y = blockIdx.y * RPT + r;
+        // the same expression, in the same order, as the general kernel above (bit-identical results)
+        f32x4 o = NEAREST ? v[r][0] : v[r][0] * wt[r][0] + v[r][1] * wt[r][1] + v[r][2] * wt[r][2] + v[r][3] * wt[r][3];
+        const unsigned pix = (unsigned)y * (unsigned)W + (unsigned)x;
+        const bool ok = col_ok & (y < H);
+        if (OUT16) {
+            const h4 hv = to_h4(o);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), r_out, ok ? (int)(pix * 128u + (unsigned)c4 * 8u) : (int)OOB, 0, 0);
+        } else {
+            buf_store4(r_out, ok ? pix * 256u + (unsigned)c4 * 16u : OOB, o);
+        }
+    }
+}
+
 // Drop-in for flow_warp(x, flow): x (n,c,h,w) NCHW, flow (n,h,w,2) = (dx,dy) pixels.
 __global__ __launch_bounds__(256) void flow_warp_nchw_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ flow,
@@ -140,6 +207,14 @@ __global__ __launch_bounds__(256) void flow_warp_nchw_kernel(const float* __rest
 int launch_mv_warp_nhwc(const float* feat, const float* fx, const float* fy, void* out, int H, int W, int C,
                         hipStream_t stream, bool out_f16, bool nearest) {
     if (C % 4) return PNP_ERR_BAD_ARG;
+    if (C == 64 && (long)H * W * 256 < (1L << 32)) {        // 32-bit byte offsets through buffer descriptors
+        constexpr int RPT = WARP_RPT;
+        auto k64 = out_f16 ? (nearest ? mv_warp_nhwc64_kernel<true, true, RPT> : mv_warp_nhwc64_kernel<true, false, RPT>)
+                           : (nearest ? mv_warp_nhwc64_kernel<false, true, RPT> : mv_warp_nhwc64_kernel<false, false, RPT>);
+        hipLaunchKernelGGL(k64, dim3((unsigned)((W + 15) / 16), (unsigned)((H + RPT - 1) / RPT)), dim3(256), 0, stream, feat, fx, fy, out,
+                           H, W);
+        return (int)hipGetLastError();
+    }
     const long total = (long)H * W * (C / 4);
     long blocks = (total + 255) / 256;
     const long cap = 256L * 32;            // 32 blocks per CU worth of grid, grid-stride beyond
