@@ -4,22 +4,24 @@
 // is contracted as three MFMAs -- hi*hi into one fp32 accumulator, lo*hi + hi*lo into a second one that is scaled by 1/2048 at
 // the end (the scaling keeps the low parts in fp16's normal range; the dropped lo*lo term is 2^-22 relative).  hi + lo carries
 // 22 of fp32's 24 significand bits and every fp16 x fp16 product is exact in fp32, so a conv differs from the exact-fp32 MFMA
-// kernels by ~1e-6 relative -- inside north_star's 1e-3 gate, which the plain fp16 operands (PNP_PREC_F16: 2e-2 on a clip)
-// are not -- at 3 MFMAs of v_mfma_f32_32x32x16_f16 per 16-deep k-step against 8 of v_mfma_f32_32x32x2_f32 at 1/16 of the
-// rate: ~5x fewer matrix-pipe cycles than the fp32 path.  Feature maps stay fp32 in HBM (reader and writer both): the mode
+// kernels by ~1e-6 relative (1.2e-7 on a clip, the fp32 path's own distance from the reference; plain fp16 operands,
+// PNP_PREC_F16: 4e-5) -- at 3 fp16 MFMAs per product against fp32 MFMAs at 1/16 of the rate: ~5x fewer matrix-pipe cycles than the
+// fp32 path.  Feature maps stay fp32 in HBM (reader and writer both): the mode
 // changes no data layout, only how a conv multiplies.  Opt-in (PNP_PREC_F16X3); the default and the headline stay exact fp32.
 //
-// Kernel: persistent 4-wave blocks, two per CU, each walking 8x16 tiles: two fp16 A tiles (hi, lo) converted from the fp32 halo
-// -- which is requested one tile ahead and rides in registers through the end of the K loop --, weight chunks streamed from L2
-// through a 3-slot ring.  The weight image interleaves the two halves of the split so that every 8 KiB chunk is self-contained:
-// chunk (tap, k-half) = 2 k-steps x [hi N0, hi N1, lo N0, lo N1] units, i.e. per k-step 6 fragment reads (A hi, A lo, 4 x B) for
-// 6 MFMAs -- one read per MFMA, at which two waves sharing a SIMD keep the matrix pipe full (33 cycles per MFMA and SIMD;
-// a wave on its own: 48, profiles/r03_ub_mfma_issue.txt).  Chunks are requested four ahead into register sets (L2 latency) and
-// written into the ring two ahead, in the middle of a chunk, so that the per-chunk barrier waits for that write only (counted
-// lgkmcnt) while the next k-step's fragments, fetched before the barrier, stay in flight.  80.9 KiB of LDS -> two blocks per CU.
-// A partition branch scales its A fragments by par_j(pixel) in fp32 and splits the product again (VALU work beside the MFMAs).
+// Kernel (the r04 form; details in front of the kernel below and in DESIGN.md 3.6): persistent 4-wave blocks, two per CU, each
+// drawing 8x16 tiles from a per-XCD queue (X3Args::queue): the fp32 halo -- requested one tile ahead, riding in registers through
+// the end of the K loop -- is split into the (hi, lo) A tile in LDS; weight chunks stream from L2 through a 3-slot ring.  The
+// weight image interleaves the two halves of the split so that every 8 KiB chunk (tap, k-half) = [hi N0..3, lo N0..3] units is
+// self-contained: one 32-deep k-step of v_mfma_f32_16x16x32_f16, 4 A + 8 B fragment reads for 24 MFMAs per wave, the reads dealt
+// one per MFMA gap (a wave issues in order: a burst of reads in front of the MFMAs costs a lone wave 48-60 cycles per MFMA, dealt
+// reads 33).  Chunks are requested four ahead into register sets (L2 latency) and written into the ring two ahead, in the middle
+// of a chunk, so that the per-chunk barrier waits for that write only (counted lgkmcnt) while the next k-step's fragments,
+// fetched before the barrier, stay in flight.  75 KiB of LDS -> two blocks per CU.  A partition branch contracts a MASKED A
+// fragment with weights scaled by 1/255 at pack time on tiles whose partition values are all 0 or 1/255 (what the reference's
+// loader writes), and re-splits par_j(pixel) * x per fragment otherwise.  An input conv over the virtual concat is ONE launch (MS).
 // Pixel-shuffle (out_mode 1) and channel-block (out_mode 4) convs are one launch per 64-channel output block with an affine
-// output mapping (o_sy, o_sx, o_c0).  DESIGN.md 3.6 has the timeline and what bounds it.
+// output mapping (o_sy, o_sx, o_c0).
 #include "conv_mfma.h"
 #include "f16_util.h"
 #include <string.h>
