@@ -413,9 +413,9 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
                                'per_launch_* = work / sum of HIP-event launch durations (undersells overlapping launches)')
     if wp['launches']:
         gbs = wp['work'] / (wp['ms'] * 1e-3) / 1e9
-        res['roofline_mv_warp'] = {'kernel': 'mv_warp_nhwc_kernel (MV-guided bilinear alignment)', 'bound': 'hbm',
+        res['roofline_mv_warp'] = {'kernel': 'mv_warp_nhwc64_kernel (MV-guided bilinear alignment)', 'bound': 'hbm',
                                    'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                                   'traffic': _launch_weighted_traffic(pmc, 'mv_warp_nhwc_kernel'),
+                                   'traffic': _launch_weighted_traffic(pmc, 'mv_warp_nhwc'),
                                    'traffic_source': pmc_src, 'launches': wp['launches'],
                                    'avg_launch_us': 1e3 * wp['ms'] / wp['launches'],
                                    'algorithmic_bytes_per_launch': wp['work'] / wp['launches']}

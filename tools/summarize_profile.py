@@ -8,7 +8,7 @@ from collections import defaultdict
 
 def short(name):
     for k in ('conv3x3_persist_kernel', 'conv3x3_mfma_kernel', 'conv3x3_f16x3_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_f16_kernel', 'par_tile_flags_kernel', 'conv_last_valu_kernel', 'dcn_window_kernel',
-              'mv_warp_nhwc_kernel', 'psnr_sse_kernel', 'flow_warp_nchw_kernel', 'pack_weights_kernel',
+              'mv_warp_nhwc64_kernel', 'mv_warp_nhwc_kernel', 'psnr_sse_kernel', 'flow_warp_nchw_kernel', 'pack_weights_kernel',
               'pack_lr_kernel', 'caa_predict_kernel', 'mix_bias_kernel'):
         if k in name:
             if k == 'conv3x3_mfma_kernel':
@@ -17,12 +17,12 @@ def short(name):
                 if not mm:
                     mm = re.search(r'conv3x3_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
                 return k + ('<%s,%s,%s,%s>' % mm.groups() if mm else '')
-            if k in ('conv3x3_f16x3_kernel', 'conv3x3_f16_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_persist_kernel', 'dcn_window_kernel', 'mv_warp_nhwc_kernel'):     # keep the template arguments
+            if k in ('conv3x3_f16x3_kernel', 'conv3x3_f16_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_persist_kernel', 'dcn_window_kernel', 'mv_warp_nhwc_kernel', 'mv_warp_nhwc64_kernel'):     # keep the template arguments
                 import re
                 mm = re.search(k + r'<([^>]*)>', name)
                 if mm:
                     return k + '<' + mm.group(1).replace(' ', '') + '>'
-                mm = re.search(k + r'I((?:Lb[01]E)+)(?:Li\d+E)?E', name)                          # mangled bools
+                mm = re.search(k + r'I((?:Lb[01]E)+)(?:Li\d+E)*E', name)                          # mangled bools
                 if mm:
                     return k + '<' + ','.join('true' if b == '1' else 'false' for b in re.findall(r'Lb([01])E', mm.group(1))) + '>'
             return k
