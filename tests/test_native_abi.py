@@ -2,6 +2,7 @@
 host-side schema logic (no GPU compute)."""
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -182,3 +183,17 @@ def test_op_level_convs_refuse_maps_beyond_32_bit_offsets_before_touching_memory
         assert lib.pnp_conv3x3_f16(1, srcs, chans, w, None, None, None, None, None, 0, fake, hw[0], hw[1], None) == rc_exp
         assert lib.pnp_conv3x3_f16x3(1, srcs, chans, w, w, None, None, None, None, None, None, 0, fake, hw[0], hw[1], None) == rc_exp
     assert lib.pnp_conv3x3_f16x3(0, srcs, chans, w, w, None, None, None, None, None, None, 0, fake, 64, 64, None) == 1001
+
+
+def test_graft_entry_build_runs_and_agrees_with_the_header_on_the_abi_version():
+    """__graft_entry__.build() is the driver's "does it build" check: it must pass on a CPU box (hipcc cross-compiles) and its ABI
+    assertion must follow include/pnpvcve.h (r04: the header went to 4 while build() still asserted 3)."""
+    import importlib
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    ge = importlib.import_module('__graft_entry__')
+    ge.build()
+    with open(os.path.join(root, 'include', 'pnpvcve.h')) as fh:
+        declared = int(re.search(r'pnp_abi_version\(void\); /\* (\d+):', fh.read()).group(1))
+    assert _native.lib().pnp_abi_version() == declared
