@@ -13,9 +13,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # timing (the round-2 code shape rarely, others always), every build without it is correct under every perturbation tried
 # (tools/repro/dcn_f16_hazard.py, profiles/r03_dcn_hazard_report.txt).
 EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize'],
-               # conv_f16x3.hip (r04): the branch re-split of the general partition path showed the same signature once its chunk became one
-               # dealt basic block -- packed fp32 arithmetic feeding MFMA operands, wrong and run-to-run varying; it is scalar code now and
-               # must stay scalar
+               # conv_f16x3.hip (r04): an intermediate build of the general partition re-split (float-vector code inside a cut-up chunk)
+               # showed the same signature; the committed structure is bit-stable with or without the flag
+               # (tools/repro/f16x3_resplit_hazard.py) -- kept as the conservative form, scalar code + this flag
                'conv_f16x3.hip': ['-fno-slp-vectorize']}
 
 

@@ -489,11 +489,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
                     }
                 } else {
                     // general maps: par_j(pixel) * x as a split number again -- (hi + lo / 2048) is exact in fp32 (22 bits), one fp32
-                    // rounding for the product, then the same split as the halo (saturating as a whole).  SCALAR arithmetic on purpose
-                    // (and the file is built with -fno-slp-vectorize): with the same formula on float vectors hipcc emits v_pk_*_f32,
-                    // whose results, converted and fed to the MFMAs of the same dealt basic block, came out wrong and run-to-run
-                    // varying (r04: 7e-4 on 40 % of the pixels; the fast path above and every other kernel were bit-stable) -- the
-                    // signature of round 3's DCN hazard: packed fp32 vector arithmetic next to MFMA operands.
+                    // rounding for the product, then the same split as the halo (saturating as a whole).  SCALAR arithmetic and the file
+                    // built with -fno-slp-vectorize: the conservative form.  An intermediate r04 build (fast / general chosen inside the
+                    // chunk) with this formula on float vectors gave run-to-run varying results; in this structure all four forms are
+                    // bit-stable (tools/repro/f16x3_resplit_hazard.py, DESIGN.md 3.6 finding 5).
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const float pj = pjr[r];
