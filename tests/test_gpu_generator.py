@@ -755,3 +755,17 @@ def test_split_path_tile_queue_switch_changes_no_bit():
     assert torch.equal(run(m, clip), with_queue)
     m.set_option(_native.OPT_TILE_QUEUE, 1)
     assert torch.equal(run(m, clip), with_queue)
+
+
+def test_split_path_tile_queue_under_hipgraph_replay():
+    """use_graphs replays a clip as one hipGraph: the queue's per-clip memset becomes a node and every launch leaves the counters
+    zeroed for the next one -- replays of a 264x272 clip (561 tiles on 512 blocks: the queue is active) equal the eager result."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
+    sd_np = gu.syn.make_state_dict(cfg, seed=175, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=176, n=1, t=3, h=264, w=272, slices='IBBBP', par_classes=3)
+    m = build(cfg, sd_np)
+    m.precision = 'f16x3'
+    eager = run(m, clip)
+    m.use_graphs = True
+    for _ in range(3):
+        assert torch.equal(run(m, clip), eager)
