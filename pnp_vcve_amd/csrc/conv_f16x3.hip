@@ -441,7 +441,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const X3Args a) {
             if (c == QR) {
                 const int drawn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(mailbox));
                 next = queue ? band_lo + per + drawn : tile + per;
-                has_next = next < band_hi;
+                // (a ticket outside [0, tiles left) ends the walk: counters that were NOT zero on entry must not send a block through
+                //  2^31 tickets -- wrong results then, but no five-minute launch)
+                has_next = queue ? (unsigned)drawn < (unsigned)(band_hi - band_lo - per) : next < band_hi;
                 nx_tile = last ? (has_next ? next : tile) : tile;
                 nx_live = last ? has_next : true;
             }

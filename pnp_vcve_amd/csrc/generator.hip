@@ -735,9 +735,11 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         const float* qe = c.use_base_qp ? bq : qp;
 
         g->prof_last = nullptr;           // untimed launches follow
-        if (W.queue) {                    // the last block of every launch leaves the queue zeroed; once per clip in case a launch was cut short
-            const hipError_t e = hipMemsetAsync(W.queue, 0, 16 * sizeof(int), st);
-            if (e != hipSuccess) return (int)e;
+        if (W.queue) {
+            // the last block of every launch leaves the queue zeroed; once per clip for a fresh workspace or a launch that was cut short.
+            // A KERNEL, not hipMemsetAsync: as a memset node of a captured graph (generator.use_graphs) the 64 bytes came back as
+            // pointer-like garbage from the second replay on (ROCm 7.2; tools/repro/graph_memset_node.py), i.e. endless ticket loops
+            hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<float*>(W.queue), 0.0f, 16);
         }
         rc = launch_pack_lr(lr_b, W.lr4, t, h, w, st);
         if (rc) return rc;
