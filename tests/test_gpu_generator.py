@@ -758,8 +758,10 @@ def test_split_path_tile_queue_switch_changes_no_bit():
 
 
 def test_split_path_tile_queue_under_hipgraph_replay():
-    """use_graphs replays a clip as one hipGraph: the queue's per-clip memset becomes a node and every launch leaves the counters
-    zeroed for the next one -- replays of a 264x272 clip (561 tiles on 512 blocks: the queue is active) equal the eager result."""
+    """use_graphs replays a clip as one hipGraph: the queue's per-clip zeroing is a node of it and every launch leaves the counters
+    zeroed for the next one -- replays of a 264x272 clip (561 tiles on 512 blocks: the queue is active) equal the eager result.
+    (r04: with hipMemsetAsync as that node the SECOND replay read pointer-like garbage as tickets -- wrong frames after a
+    five-minute launch; ROCm 7.2, tools/repro/graph_memset_node.py.  The zeroing is a kernel now.)"""
     cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2)
     sd_np = gu.syn.make_state_dict(cfg, seed=175, par_gain=10.0)
     clip = gu.syn.make_clip(seed=176, n=1, t=3, h=264, w=272, slices='IBBBP', par_classes=3)
