@@ -771,3 +771,21 @@ def test_split_path_tile_queue_under_hipgraph_replay():
     m.use_graphs = True
     for _ in range(3):
         assert torch.equal(run(m, clip), eager)
+
+
+@pytest.mark.parametrize('prec,extra,hw,n', [
+    ('fp32', {}, (264, 272), 1), ('fp16', {}, (264, 272), 1), ('f16x3', {}, (264, 272), 2), ('f16x3', dict(vsr=True), (136, 144), 1),
+    ('fp32', dict(deform='basic'), (136, 144), 1), ('f16x3', dict(blocktype='drt_woqp', num_group=4, flow_inter='nearest'), (264, 272), 1)],
+    ids=['fp32', 'fp16', 'f16x3-two-contexts', 'f16x3-vsr', 'fp32-dcn', 'f16x3-variants'])
+def test_hipgraph_replays_equal_the_eager_clip_beyond_small_frames(prec, extra, hw, n):
+    """use_graphs away from the 128x128 case it was built for: persistent kernels, two samples on two streams, the x4 heads, the
+    DCN aligner and the r04 constructor variants -- three replays (new input tensors each) equal the eager result bit for bit."""
+    cfg = dict(gu.syn.DEFAULT_GENERATOR_CFG, num_blocks=2, **extra)
+    sd_np = gu.syn.make_state_dict(cfg, seed=177, par_gain=10.0)
+    clip = gu.syn.make_clip(seed=178, n=n, t=3, h=hw[0], w=hw[1], slices='IBBBP', par_classes=3)
+    m = build(cfg, sd_np)
+    m.precision = prec
+    eager = run(m, clip)
+    m.use_graphs = True
+    for _ in range(3):
+        assert torch.equal(run(m, clip), eager)
