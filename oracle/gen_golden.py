@@ -6,7 +6,7 @@ tests/golden_util.py.  Only outputs are stored; inputs are regenerated from
 seeds on whichever machine runs the tests.
 
     python oracle/gen_golden.py                    # (re)write every fixture + manifest
-    python oracle/gen_golden.py --only a,b         # only the named generator / flow_warp cases, merged into the manifest
+    python oracle/gen_golden.py --only a,b         # only the named generator / flow_warp / metrics cases, merged into the manifest
 """
 import json
 import os
@@ -89,6 +89,46 @@ def main():
         manifest['cases'][case['name']] = dict(kind='flow_warp', shape=list(ref.shape), oracle_vs_reference_maxabs=d)
         print(case['name'], d, flush=True)
         assert d < 1e-5
+
+    # ---- PSNR / tensor2img / BasicVSR.evaluate (row 8f-2): the reference's own functions -------------
+    ref_psnr, ref_tensor2img, RefBasicVSR = ref_shim.reference_metrics()
+
+    class _Cfg(dict):                      # mmcv.Config stand-in: attribute access + .get (names only)
+        __getattr__ = dict.__getitem__
+
+    for case in gu.METRIC_CASES:
+        if only is not None and case['name'] not in only:
+            continue
+        out_np, gt_np = gu.metric_case_inputs(case)
+        out_t, gt_t = T(out_np), T(gt_np)
+        nt = out_t.shape[1]
+        img_out = np.stack([ref_tensor2img(out_t[:, i]) for i in range(nt)])          # (T, h, w, 3) uint8 BGR
+        img_gt = np.stack([ref_tensor2img(gt_t[:, i]) for i in range(nt)])
+        store = dict(img_out=img_out, img_gt=img_gt)
+        worst = 0.0
+        for crop in (0, 3):
+            vals = np.array([ref_psnr(img_out[i], img_gt[i], crop) for i in range(nt)], np.float64)
+            store[f'psnr_crop{crop}'] = vals
+            model = RefBasicVSR.__new__(RefBasicVSR)                                   # evaluate() reads test_cfg only
+            model.test_cfg = _Cfg(metrics=['PSNR'], crop_border=crop)
+            finite = [i for i in range(nt) if np.isfinite(vals[i])]
+            store[f'evaluate_all_crop{crop}'] = np.float64(RefBasicVSR.evaluate(model, out_t, gt_t)['PSNR'])
+            store[f'evaluate_finite_crop{crop}'] = np.float64(
+                RefBasicVSR.evaluate(model, out_t[:, finite], gt_t[:, finite])['PSNR'])
+            mine = [cpu_ref.psnr_uint8(cpu_ref.tensor2img_uint8(out_t[0, i]), cpu_ref.tensor2img_uint8(gt_t[0, i]), crop)
+                    for i in range(nt)]
+            for i in range(nt):
+                assert np.array_equal(cpu_ref.tensor2img_uint8(out_t[0, i]), img_out[i])
+                if np.isfinite(vals[i]):
+                    worst = max(worst, abs(mine[i] - vals[i]))
+                else:
+                    assert mine[i] == vals[i]
+            store[f'finite_frames_crop{crop}'] = np.array(finite, np.int64)
+        np.savez(os.path.join(gu.GOLDEN_DIR, case['name'] + '.npz'), **store)
+        manifest['cases'][case['name']] = dict(kind='metrics', oracle_vs_reference_maxabs=worst,
+                                               psnr_crop0=[float(v) for v in store['psnr_crop0']])
+        print(case['name'], 'oracle-vs-ref dB', worst, store['psnr_crop0'], store['evaluate_finite_crop0'], flush=True)
+        assert worst < 1e-5
 
     if only is not None:
         with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json'), 'w') as f:

@@ -201,5 +201,44 @@ def reference_loader_class():
     return mod.LoadImageFromFileList_ipb
 
 
+def reference_metrics():
+    """(psnr, tensor2img, BasicVSR) of the reference itself: mmedit/core/evaluation/metrics.py:170-215,
+    mmedit/core/misc.py:9-74, mmedit/models/restorers/basicvsr.py:14 (its `evaluate`, :119-153).  Name-only stand-ins for
+    what those files import and the PSNR path never calls: cv2, torchvision.utils.make_grid (4-D batches only),
+    MATLABLikeResize (NIQE only).  No arithmetic is supplied from here."""
+    reference_loader_class()          # sets up the mmedit.core / mmedit.datasets stand-in packages
+    if 'cv2' not in sys.modules:
+        cv2 = types.ModuleType('cv2')
+        for n in ('filter2D', 'getGaussianKernel', 'BORDER_REPLICATE', 'resize'):
+            setattr(cv2, n, _absent)
+        sys.modules['cv2'] = cv2
+    if 'torchvision' not in sys.modules:
+        tv = types.ModuleType('torchvision')
+        tvu = types.ModuleType('torchvision.utils')
+        tvu.make_grid = _absent
+        tv.utils = tvu
+        sys.modules['torchvision'] = tv
+        sys.modules['torchvision.utils'] = tvu
+    if 'mmedit.datasets.pipelines.matlab_like_resize' not in sys.modules:
+        mlr = types.ModuleType('mmedit.datasets.pipelines.matlab_like_resize')
+        mlr.MATLABLikeResize = type('MATLABLikeResize', (), {})
+        sys.modules['mmedit.datasets.pipelines.matlab_like_resize'] = mlr
+    core = sys.modules['mmedit.core']
+    core.__path__ = [os.path.join(REFERENCE_ROOT, 'mmedit', 'core')]
+    if 'mmedit.core.evaluation' not in sys.modules:
+        ev = types.ModuleType('mmedit.core.evaluation')
+        ev.__path__ = [os.path.join(REFERENCE_ROOT, 'mmedit', 'core', 'evaluation')]
+        sys.modules['mmedit.core.evaluation'] = ev
+    metrics = importlib.import_module('mmedit.core.evaluation.metrics')
+    misc = importlib.import_module('mmedit.core.misc')
+    core.psnr, core.ssim, core.tensor2img = metrics.psnr, metrics.ssim, misc.tensor2img
+    if 'mmedit.models.restorers' not in sys.modules:
+        r = types.ModuleType('mmedit.models.restorers')
+        r.__path__ = [os.path.join(REFERENCE_ROOT, 'mmedit', 'models', 'restorers')]
+        sys.modules['mmedit.models.restorers'] = r
+    basicvsr = importlib.import_module('mmedit.models.restorers.basicvsr')
+    return metrics.psnr, misc.tensor2img, basicvsr.BasicVSR
+
+
 def available():
     return os.path.isdir(os.path.join(REFERENCE_ROOT, 'mmedit'))

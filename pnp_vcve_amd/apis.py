@@ -108,7 +108,9 @@ def multi_gpu_test(model, dataset, save_image=False, save_path=None, device='cud
     clips_in_flight = 2: two clips of equal shape are enhanced by ONE generator call (a batch of two), which the generator runs
     interleaved on two streams -- each clip's conv launches fill the partial last round of tiles and the dispatch gaps of the
     other's (+5 % at 720p, bit-identical to one clip at a time); metrics and image saving stay clip by
-    clip (the reference evaluates with samples_per_gpu=1, mmedit/apis/test.py:100-119).  Costs a second workspace."""
+    clip (the reference evaluates with samples_per_gpu=1, mmedit/apis/test.py:100-119).  Costs a second workspace.
+    `frames_per_s` of a PAIRED clip is the pair's throughput (frames of both clips over the pair's wall time), not the clip's own
+    forward time; an unpaired leftover clip (odd count, shape change, sparse_val model) reports its own."""
     import time
     model.eval()
     rank, world = get_dist_info()
@@ -116,6 +118,9 @@ def multi_gpu_test(model, dataset, save_image=False, save_path=None, device='cud
     local = []
     dev = torch.device(device)
     pairs = int(clips_in_flight) >= 2 and dev.type == 'cuda' and hasattr(model, 'generator') and not getattr(model, 'psnr_only', False)
+    # a sparse_val generator evaluates one sample per call in eval mode (the reference indexes feature[0, ...],
+    # sr_backbone_utils.py:262-275; generator.py refuses n != 1): such a model keeps the clip-by-clip loop
+    pairs = pairs and not getattr(model.generator, 'sparse_val', False)
 
     def finish(data, out=None, fps=None):
         with torch.no_grad():

@@ -6,7 +6,7 @@
 // Here: one pass over the two frames in HBM, rounding exactly as numpy does (half to even), the
 // squared differences summed as 64-bit INTEGERS (exact, order-independent, deterministic), so the
 // host only sees 8 bytes per frame instead of 2 x 3*H*W*4.  HBM-bound: 8 B per element.
-#include "common.h"
+#include "prep.h"
 #include <cmath>
 
 namespace {
@@ -162,8 +162,8 @@ extern "C" int pnp_psnr_sse_f32(const float* a, const float* b, unsigned long lo
     if (frames < 1 || c < 1 || h < 1 || w < 1 || crop_border < 0 || 2 * crop_border >= h || 2 * crop_border >= w)
         return PNP_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sse, 0, sizeof(unsigned long long) * frames, st);
-    if (e != hipSuccess) return (int)e;
+    const int ze = launch_zero_words(sse, 2L * frames, st);      // a kernel, not a memset node (prep.h)
+    if (ze != PNP_OK) return ze;
     const long per = (long)c * h * w;
     long bx = (per / 4 + 255) / 256;
     if (bx > 1024) bx = 1024;

@@ -2,6 +2,10 @@
 #pragma once
 #include "common.h"
 
+// dst[0 .. n_words) = 0 (32-bit words; dst 4-byte aligned) by a KERNEL.  Used instead of hipMemsetAsync wherever the call could end up
+// inside a captured graph: on ROCm 7.2 a memset NODE replays pointer-like garbage from the second hipGraphLaunch on
+// (tools/repro/graph_memset_node.py, profiles/r04_graph_memset_node_report.txt).
+int launch_zero_words(void* dst, long n_words, hipStream_t stream);
 // (T,3,H,W) NCHW frames -> (T,H,W,4) pixel-major, 4th channel zero
 int launch_pack_lr(const float* lrs, float* lr4, int T, int H, int W, hipStream_t stream);
 // (T,3,H,W) partition maps -> the dense equivalent of the reference's sparse_val evaluation (prep.hip)

@@ -218,3 +218,18 @@ int launch_caa_predict(const CaaArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(caa_predict_kernel, dim3(a.count), dim3(64), 0, stream, a);
     return (int)hipGetLastError();
 }
+
+namespace {
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = 0u;
+}
+}  // namespace
+
+int launch_zero_words(void* dst, long n_words, hipStream_t stream) {
+    if (n_words <= 0) return PNP_OK;
+    long blocks = (n_words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<unsigned*>(dst), n_words);
+    return (int)hipGetLastError();
+}

@@ -15,7 +15,7 @@
 //   2. resolve: one thread per pixel reads its winners and writes the four motion planes.
 // Python slice semantics of the reference are kept exactly (a negative start index wraps around,
 // the far side is clipped) -- see py_slice().  HBM-bound, 8 (winners) + 28 (maps) bytes per pixel.
-#include "common.h"
+#include "prep.h"
 
 namespace {
 
@@ -110,10 +110,10 @@ extern "C" int pnp_rasterise_side_info_f32(const float* records, const int* rec_
         p_offset = is_b ? (p_offset < 0 ? -1 : p_offset + 1) : 1;
     }
     const long hw = (long)h * w;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int) * 2 * hw * t, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(par, 0, sizeof(float) * 3 * hw * t, st);
-    if (e != hipSuccess) return (int)e;
+    int ze = launch_zero_words(scratch, 2 * hw * t, st);          // kernels, not memset nodes (prep.h)
+    if (ze != PNP_OK) return ze;
+    ze = launch_zero_words(par, 3 * hw * t, st);
+    if (ze != PNP_OK) return ze;
     if (num_records > 0)
         hipLaunchKernelGGL(raster_mark_kernel, dim3((unsigned)num_records), dim3(256), 0, st, records, rec_frame,
                            num_records, fi, h, w, scratch, par);

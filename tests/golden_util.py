@@ -215,3 +215,32 @@ def raster_case_inputs(case):
             rows.append([float(dr[i]), bw, bh, xw, yw, x, y, float(mx[i]), float(my[i]), 4.0])
             frames.append(f)
     return np.array(rows, np.float32), np.array(frames, np.int32), slices, h, w
+
+
+# ---------------------------------------------------------------- PSNR / tensor2img / BasicVSR.evaluate
+METRIC_CASES = [
+    dict(name='metrics_psnr_40x56', seed=501, t=6, h=40, w=56),
+]
+
+
+def metric_case_inputs(case):
+    """(output, gt) float32 (1, T, 3, h, w) clips for the reference's tensor2img + psnr:
+    frame 0: plain values in [0, 1]; frame 1: output leaves [0, 1] on both sides (the clamp); frame 2: every output value
+    an exact (k + 0.5) / 255 rounding tie, gt exact k / 255; frame 3: output == gt (PSNR inf); frame 4: ties after the clamp
+    (-0.5 / 255, 255.5 / 255) mixed with values a hair off a tie; frame 5: a nearly constant pair (tiny MSE)."""
+    s, t, h, w = case['seed'], case['t'], case['h'], case['w']
+    gt = syn.uniform(s, 'gt', (1, t, 3, h, w), 0.0, 1.0)
+    out = gt + syn.uniform(s, 'noise', (1, t, 3, h, w), -0.06, 0.06)
+    out[0, 1] = gt[0, 1] * 1.5 - 0.25
+    k = np.floor(syn.uniform(s, 'k', (3, h, w), 0.0, 255.0)).astype(np.float32)
+    out[0, 2] = (k + np.float32(0.5)) / np.float32(255.0)
+    gt[0, 2] = k / np.float32(255.0)
+    out[0, 3] = gt[0, 3]
+    sel = syn.uniform(s, 'sel', (3, h, w), 0.0, 4.0)
+    out[0, 4] = np.where(sel < 1, np.float32(-0.5 / 255.0), np.where(sel < 2, np.float32(255.5 / 255.0),
+                         np.where(sel < 3, np.nextafter((k + np.float32(0.5)) / np.float32(255.0), np.float32(2)),
+                                  np.nextafter((k + np.float32(0.5)) / np.float32(255.0), np.float32(-1))))).astype(np.float32)
+    gt[0, 5] = np.float32(0.5)
+    out[0, 5] = np.float32(0.5)
+    out[0, 5, 1, 7, 9] = np.float32(0.5 + 1.5 / 255.0)
+    return np.ascontiguousarray(out.astype(np.float32)), np.ascontiguousarray(gt.astype(np.float32))

@@ -248,20 +248,37 @@ def test_conv_720p_scaling_linearity_and_crop_consistency():
     assert maxdiff(yc.permute(2, 0, 1).unsqueeze(0), ref) < TOL_CONV * 4
 
 
-@pytest.mark.parametrize('crop', [0, 3])
-def test_psnr_on_device_matches_reference_definition(crop):
+@pytest.mark.parametrize('case', gu.METRIC_CASES, ids=[c['name'] for c in gu.METRIC_CASES])
+def test_psnr_and_rgb8_on_device_match_the_reference_functions(case):
+    """pnp_psnr_sse_f32 / pnp_frames_to_rgb8 against what the reference's own tensor2img + psnr (+ BasicVSR.evaluate) returned for
+    the same frames (tests/golden/metrics_psnr_*.npz, oracle/gen_golden.py): values outside [0,1], exact .5 rounding ties, an
+    identical pair (inf), crop_border 0 and 3.  The comparator is the fixture -- not the package's host code."""
     from pnp_vcve_amd import ops
-    from pnp_vcve_amd.metrics import psnr, tensor2img
-    a = torch.rand(5, 3, 70, 90)
-    b = (a + 0.05 * torch.randn_like(a))          # exceeds [0,1] on purpose: exercises the clamp
-    b[4] = a[4]
-    got = ops.psnr_frames(a.to(dev()), b.to(dev()), crop)
-    for i in range(5):
-        ref = psnr(tensor2img(a[i]), tensor2img(b[i]), crop)
-        if ref == float('inf'):
-            assert got[i] == float('inf')
-        else:
-            assert abs(float(got[i]) - ref) < 1e-4, (i, float(got[i]), ref)
+    from pnp_vcve_amd.restorer import BasicVSR
+    out, gt = gu.metric_case_inputs(case)
+    g = gu.load_golden(case['name'])
+    o, t = G(out), G(gt)
+    rgb = ops.frames_to_rgb8(o[0]).cpu().numpy()                     # (T,h,w,3) RGB; the reference's images are BGR
+    assert np.array_equal(rgb[..., ::-1], g['img_out'])
+    assert np.array_equal(ops.frames_to_rgb8(t[0]).cpu().numpy()[..., ::-1], g['img_gt'])
+    for crop in (0, 3):
+        got = ops.psnr_frames(o[0], t[0], crop).numpy()
+        ref = g[f'psnr_crop{crop}']
+        for i in range(len(ref)):
+            if np.isinf(ref[i]):
+                assert np.isinf(got[i]) and got[i] > 0
+            else:
+                assert abs(got[i] - ref[i]) < 1e-4, (crop, i, got[i], ref[i])   # the reference's value is a float32
+        m = BasicVSR.__new__(BasicVSR)
+        m.test_cfg = dict(metrics=['PSNR'], crop_border=crop)
+        fin = [int(i) for i in g[f'finite_frames_crop{crop}']]
+        ev = BasicVSR.evaluate(m, o[:, fin], t[:, fin])['PSNR']        # CUDA tensors: the on-device statistic
+        assert abs(ev - float(g[f'evaluate_finite_crop{crop}'])) < 1e-4
+        assert BasicVSR.evaluate(m, o, t)['PSNR'] == float('inf') == float(g[f'evaluate_all_crop{crop}'])
+
+
+def test_psnr_on_device_exact_integer_statistic_at_720p():
+    from pnp_vcve_amd import ops
     # 720p frames, exact integer statistic vs the host
     x = torch.rand(2, 3, 720, 1280, device=dev())
     y = (x + 0.02 * torch.randn_like(x)).clamp(0, 1)

@@ -20,7 +20,7 @@ def T(a):
 def test_manifest_lists_every_case():
     with open(os.path.join(gu.GOLDEN_DIR, 'manifest.json')) as f:
         man = json.load(f)
-    names = [c['name'] for c in gu.GEN_CASES + gu.WARP_CASES + gu.BLOCK_CASES] + ['caa_predictors']
+    names = [c['name'] for c in gu.GEN_CASES + gu.WARP_CASES + gu.BLOCK_CASES + gu.METRIC_CASES] + ['caa_predictors']
     for n in names:
         assert n in man['cases'], n
         assert os.path.exists(os.path.join(gu.GOLDEN_DIR, n + '.npz')), n
@@ -87,6 +87,50 @@ def test_preconditions_match_reference_errors():
     with pytest.raises(ValueError):          # flow_warp.py:27-29 after spatial_padding of lrs only
         cpu_ref.generator_forward(sd, cfg, a['lq'][..., :, :66], a['QPs'], a['slices'], a['mvs'][..., :, :66],
                                   a['base_QPs'], a['partitions'][..., :, :66])
+
+
+@pytest.mark.parametrize('case', gu.METRIC_CASES, ids=[c['name'] for c in gu.METRIC_CASES])
+def test_psnr_and_tensor2img_match_reference(case):
+    """oracle vs the reference's OWN tensor2img / psnr / BasicVSR.evaluate outputs (core/misc.py:51-71,
+    core/evaluation/metrics.py:170-215, restorers/basicvsr.py:119-153): uint8 images bit-exact (clamp, .5 ties,
+    BGR order), PSNR to float32 resolution, inf for an identical pair, the clip mean."""
+    out, gt = gu.metric_case_inputs(case)
+    g = gu.load_golden(case['name'])
+    nt = out.shape[1]
+    for i in range(nt):
+        assert np.array_equal(cpu_ref.tensor2img_uint8(T(out[0, i])), g['img_out'][i])
+        assert np.array_equal(cpu_ref.tensor2img_uint8(T(gt[0, i])), g['img_gt'][i])
+    assert (g['img_out'][2].astype(int) - g['img_gt'][2].astype(int)).any()          # the tie frame is not trivially equal
+    for crop in (0, 3):
+        ref = g[f'psnr_crop{crop}']
+        assert np.isinf(ref[3]) and np.isfinite(np.delete(ref, 3)).all()
+        for i in range(nt):
+            v = cpu_ref.psnr_uint8(g['img_out'][i], g['img_gt'][i], crop)
+            assert v == ref[i] if np.isinf(ref[i]) else abs(v - ref[i]) < 1e-5, (crop, i, v, ref[i])
+        fin = list(g[f'finite_frames_crop{crop}'])
+        assert abs(cpu_ref.clip_psnr(T(out[:, fin]), T(gt[:, fin]), crop) - float(g[f'evaluate_finite_crop{crop}'])) < 1e-4
+        assert cpu_ref.clip_psnr(T(out), T(gt), crop) == float('inf') == float(g[f'evaluate_all_crop{crop}'])
+
+
+@pytest.mark.parametrize('case', gu.METRIC_CASES, ids=[c['name'] for c in gu.METRIC_CASES])
+def test_host_metrics_and_evaluate_match_reference(case):
+    """the package's host-side tensor2img / psnr and BasicVSR.evaluate (CPU tensors take the numpy path) against the same fixture"""
+    from pnp_vcve_amd import metrics
+    from pnp_vcve_amd.restorer import BasicVSR
+    out, gt = gu.metric_case_inputs(case)
+    g = gu.load_golden(case['name'])
+    for i in range(out.shape[1]):
+        assert np.array_equal(metrics.tensor2img(T(out[:, i])), g['img_out'][i])
+        for crop in (0, 3):
+            v, ref = metrics.psnr(g['img_out'][i], g['img_gt'][i], crop), g[f'psnr_crop{crop}'][i]
+            assert v == ref if np.isinf(ref) else abs(v - ref) < 1e-5
+    for crop in (0, 3):
+        m = BasicVSR.__new__(BasicVSR)
+        m.test_cfg = dict(metrics=['PSNR'], crop_border=crop)
+        m.allowed_metrics = metrics.ALLOWED_METRICS
+        fin = list(g[f'finite_frames_crop{crop}'])
+        got = BasicVSR.evaluate(m, T(out[:, fin]), T(gt[:, fin]))['PSNR']
+        assert abs(float(got) - float(g[f'evaluate_finite_crop{crop}'])) < 1e-4
 
 
 def test_psnr_definition():
