@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument('--f16-mirrors', type=int, default=None, choices=[0, 1, 2],
                     help='fp16 path A/B: 0 no fp16 mirrors (r02 schedule), 1 frame slots + aligned key frame (default), 2 also the '
                          'running map inside a branch (PNP_OPT_F16_CHAIN_MIRRORS)')
+    ap.add_argument('--winograd', type=int, default=None, choices=[0, 1, 2],
+                    help='PNP_OPT_WINOGRAD of the fp32 path: 0 direct kernels, 1 Winograd F(2x2,3x3) for the 64->64 convs on frames '
+                         'with >= 512 16x16 tiles, 2 on every frame size (default: the library default)')
     ap.add_argument('--tile-queue', type=int, default=None, choices=[0, 1],
                     help='split-fp16 path A/B: 0 = every block walks a static share of the tiles, 1 (default) = per-XCD tile queue '
                          '(PNP_OPT_TILE_QUEUE)')
@@ -269,6 +272,7 @@ def cpu_baseline_128(T, runs=5, thread_counts=(8, 16, 32)):
 
 F16_MIRRORS = None      # --f16-mirrors
 TILE_QUEUE = None       # --tile-queue
+WINOGRAD = None         # --winograd
 DTYPE_TEXT = {'fp32': 'f32',
               'fp16': 'f16 MFMA operands, f32 accumulate / feature maps (opt-in; whole-clip max-abs vs fp32 up to 2e-2, PSNR delta '
                       '< 1e-3 dB)',
@@ -288,6 +292,9 @@ def build_model(cfg, sd_np, dev, precision, graphs=False):
         from pnp_vcve_amd import _native
         m.set_option(_native.OPT_F16_MIRRORS, 1 if F16_MIRRORS >= 1 else 0)
         m.set_option(_native.OPT_F16_CHAIN_MIRRORS, 1 if F16_MIRRORS >= 2 else 0)
+    if WINOGRAD is not None:
+        from pnp_vcve_amd import _native
+        m.set_option(_native.OPT_WINOGRAD, WINOGRAD)
     if TILE_QUEUE is not None:
         from pnp_vcve_amd import _native
         m.set_option(_native.OPT_TILE_QUEUE, TILE_QUEUE)
@@ -535,7 +542,8 @@ def main(argv=None, measure_fn=None):
     """`measure_fn` replaces measure() in the CPU test of the rank path (tests/test_host_logic.py: 8 gloo ranks, no GPU); the
     script itself always runs the real one and refuses to start without a GPU."""
     args = parse_args(argv)
-    global F16_MIRRORS, TILE_QUEUE
+    global F16_MIRRORS, TILE_QUEUE, WINOGRAD
+    WINOGRAD = args.winograd
     F16_MIRRORS = args.f16_mirrors
     TILE_QUEUE = args.tile_queue
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

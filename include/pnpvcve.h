@@ -25,7 +25,7 @@ extern "C" {
 #define PNP_ERR_SIZE_ASSERT 1004 /* reference: AssertionError, h/w < 64 (iconvsr_ipb_par.py:51) */
 #define PNP_ERR_SIZE_VALUE 1005  /* reference: ValueError from flow_warp.py:27-29 (h/w % 4 != 0) */
 
-int pnp_abi_version(void); /* 4: pnp_generator_cfg grew num_group / flow_inter / blocktype (3: the never-implemented fused-block option / query of v2
+int pnp_abi_version(void); /* 5: PNP_OPT_WINOGRAD, pnp_wino_* / pnp_conv3x3_wino_f32.  4: pnp_generator_cfg grew num_group / flow_inter / blocktype (3: the never-implemented fused-block option / query of v2
                               removed, PNP_OPT_* renumbered, PNP_OPT_SPARSE_EVAL, PNP_OPT_F16_MIRRORS) */
 
 /* ------------------------------------------------------------------ generator (a1/a2)
@@ -105,7 +105,11 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     neutral at 720p -- the back half writes 128 B per pixel more for what the front half reads less) */
 #define PNP_OPT_TILE_QUEUE 8     /* PNP_PREC_F16X3: the split conv kernel's blocks draw their tiles from a per-XCD queue in the workspace instead of
                                     walking a static share (tiles differ in cost and the two blocks of a CU in speed); results identical */
-#define PNP_OPT_COUNT 9
+#define PNP_OPT_WINOGRAD 9       /* PNP_PREC_F32: the single-source 64 -> 64 convs (both halves of a BAE block, conv_hr) in Winograd F(2x2,3x3) form
+                                    (conv_wino.hip): 2.25x fewer matrix FLOPs, still fp32 products and sums, NOT bit-identical to the direct
+                                    kernels (summation order + the +-1 input transform: ~1e-6 per conv on unit-scale maps; whole-clip
+                                    gates in tests/test_gpu_wino.py).  0 off | 1 on frames with >= 512 16x16 tiles | 2 on every frame size */
+#define PNP_OPT_COUNT 10
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
 
@@ -208,6 +212,20 @@ int64_t pnp_packed_pixel_shuffle_floats(void);
 int pnp_pack_pixel_shuffle_f32(const float* w_dev, const float* b_dev, float* dst_dev, void* stream);
 int pnp_pixel_shuffle_conv_f32(const float* x_dev, const float* packed_dev, int act, float* out_dev, int h, int w,
                                void* stream);
+
+/* The single-source 64 -> 64 form of pnp_conv3x3_f32 as Winograd F(2x2,3x3) (sr_backbone_utils.py:304-333 block halves,
+ * iconvsr_ipb_par.py:144 conv_hr): act(gamma * (conv3x3(x; W) + bias) + Sum_j par_j * conv1x1_j(x)) + residual with
+ * x (h,w,64).  wino_w_dev = pnp_wino_image_from_packed_f32 of the packed direct-conv image WITH the same gamma (the gain
+ * lives in the transformed weights, the kernel scales the bias); wino_w1x1_dev = pnp_wino_par_image_from_packed_f32 of the
+ * packed 1x1 images or NULL (then par_dev / par_flags_dev are ignored); par_flags_dev as pnp_par_tile_flags_f32 writes
+ * them, or NULL.  fp32 arithmetic; differs from pnp_conv3x3_f32 by summation order (~1e-6 on unit-scale maps). */
+int64_t pnp_wino_image_floats(void);
+int64_t pnp_wino_par_image_floats(void);
+int pnp_wino_image_from_packed_f32(const float* packed_w_dev, const float* gamma_dev, float* dst_dev, void* stream);
+int pnp_wino_par_image_from_packed_f32(const float* packed_w1x1_dev, float* dst_dev, void* stream);
+int pnp_conv3x3_wino_f32(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
+                         const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
+                         const float* residual_dev, int act, float* out_dev, int h, int w, void* stream);
 
 /* Which of the three 1x1 partition branches (sr_backbone_utils.py:310-311, Sum_j par_j * conv1x1_j(x)) an 8x16 pixel tile
  * needs at all: par_dev (3,h,w) -> flags_dev[((w+15)/16) * ((h+7)/8)] ints, bit j set iff plane j is nonzero somewhere in

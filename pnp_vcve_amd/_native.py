@@ -78,6 +78,11 @@ SIGNATURES = {
     'pnp_conv3x3_f16': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'pnp_f16x3_image_from_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'pnp_wino_image_floats': (c_int64, []),
+    'pnp_wino_par_image_floats': (c_int64, []),
+    'pnp_wino_image_from_packed_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'pnp_wino_par_image_from_packed_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'pnp_conv3x3_wino_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_int, c_int, c_void_p]),
     'pnp_conv3x3_f16x3': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -106,7 +111,7 @@ DEBUG_SIGNATURES['pnp_mv_warp_nhwc_f16out'] = (c_int, [c_void_p, c_void_p, c_voi
 
 # pnp_generator_set_option ids (include/pnpvcve.h)
 (OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_SMALL_F16, OPT_SPARSE_EVAL, OPT_F16_MIRRORS, OPT_F16_CHAIN_MIRRORS,
- OPT_TILE_QUEUE) = range(9)
+ OPT_TILE_QUEUE, OPT_WINOGRAD) = range(10)
 CONV_AUTO, CONV_TILE, CONV_TILE_BIG = range(3)
 
 _lib = None

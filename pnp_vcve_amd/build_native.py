@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libpnpvcve_hip.so')
-SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_f16.hip', 'conv_f16x3.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
+SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_wino.hip', 'conv_f16.hip', 'conv_f16x3.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # per-source extras.  dcn.hip: hipcc's SLP vectoriser packs the scalar coordinate / weight arithmetic of the deformable gather into
 # v_pk_*_f32 pairs; every build with that packing gave wrong, run-to-run varying samples in the fp16 instantiation under some
@@ -16,7 +16,11 @@ EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize'],
                # conv_f16x3.hip (r04): an intermediate build of the general partition re-split (float-vector code inside a cut-up chunk)
                # showed the same signature; the committed structure is bit-stable with or without the flag
                # (tools/repro/f16x3_resplit_hazard.py) -- kept as the conservative form, scalar code + this flag
-               'conv_f16x3.hip': ['-fno-slp-vectorize']}
+               'conv_f16x3.hip': ['-fno-slp-vectorize'],
+               # conv_wino.hip (r05): the same signature a third time -- with v_pk_{add,mul}_f32 in the epilogue / the input transform, a few
+               # fixed (lane, register) slots of the output came out wrong, deterministically, and moved when unrelated code moved
+               # (tools/repro/wino_packed_f32_hazard.py; profiles/r05_wino_packed_f32_hazard.txt).  The kernel is built without packed fp32 VALU ops at all
+               'conv_wino.hip': ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']}
 
 
 def _stale(target, deps):

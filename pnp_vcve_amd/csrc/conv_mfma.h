@@ -9,6 +9,9 @@ struct ConvArgs {
     int src_c[4];           // 64 or 4
     int nsrc;
     const float* wpar;      // 3 chunks (conv16x16, conv16x8, conv8x8) or nullptr
+    const float* wwino;     // Winograd F(2x2,3x3) image of wsrc[0] (16 chunks of 4096 floats, gamma folded in: launch_wino_images), or nullptr:
+                            // with it a single-source 64 -> 64 conv (prec 0, out_mode 0) runs on conv_wino.hip
+    const float* wwino_par; // ... and of wpar (launch_wino_par_image; 12288 floats); required with wwino when wpar is set
     const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
     const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo
                             // interleaved, twice the halfs; conv_f16x3.hip launch_f16x3_image)
@@ -122,6 +125,18 @@ int launch_par_tile_flags(const float* par, long par_plane, int* flags, int fram
 int launch_pack_last_valu(const float* w_oihw, float* dst, hipStream_t stream);
 bool conv_last_valu_eligible(const ConvArgs& a, int cfg, int grid_y);
 int launch_conv_last_valu(const ConvArgs& a, hipStream_t stream);
+
+// Winograd F(2x2,3x3) variant of the single-source 64 -> 64 conv (conv_wino.hip): 2.25x fewer matrix FLOPs, fp32 arithmetic, results
+// within ~1e-6 (unit-scale data) of the direct kernels.  Weight images: src[i] = a packed direct-conv image (9 chunks), dst[i] = 16
+// chunks (65536 floats); gamma (64 floats or nullptr) is multiplied into every image (a dynamic conv's channel gain applies to
+// conv + bias but not to the partition branches, which share the accumulators here -- so it lives in the weights; the kernel
+// scales the bias).  n <= 16 images per launch.
+int launch_wino_images(const float* const* src, float* const* dst, int n, const float* gamma, hipStream_t stream);
+int launch_wino_par_image(const float* src_3chunks, float* dst_12288, hipStream_t stream);
+bool conv_wino_eligible(const ConvArgs& a, int cfg, int grid_y);
+int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream);
+#define PNP_WINO_IMG_FLOATS 65536
+#define PNP_WINO_PAR_FLOATS 12288
 
 // persistent single-source variant (conv_persist.hip)
 bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y);

@@ -1,0 +1,578 @@
+// Winograd F(2x2,3x3) form of the 64 -> 64 channel 3x3 convs (BAE block halves, conv_hr) on the fp32 matrix pipe of gfx950.
+//
+// Why: the direct implicit-GEMM kernels (conv_mfma.hip / conv_persist.hip) keep the chip inside fp32 MFMAs for > 99 % of a 720p clip
+// at 0.80 of the (power-limited) matrix peak -- the only lever left is fewer MFMAs per output pixel.  F(2x2,3x3) computes a 2x2
+// output tile from a 4x4 input patch with 16 channel contractions instead of 36: 2.25x fewer matrix FLOPs for
+//   conv3x3(x; g) = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A         (Lavin & Gray 2015; B, G, A below)
+// The arithmetic is still fp32 (exact products, fp32 accumulation); the result differs from the direct form by summation
+// order and by the cancellation of the +-1 input transform: 5e-7 abs on unit-scale data (tools/ubench/ub_winograd.hip), the gates are
+// in tests/test_gpu_wino.py.  Reference arithmetic restated: mmedit/models/common/sr_backbone_utils.py:304-333 (block),
+// basicvsr_net.py:506-519 (branch), iconvsr_ipb_par.py:144 (conv_hr).
+//
+// Structure (measured first as a micro-benchmark, profiles/r05_ub_winograd_*.txt):
+//   * block = 4 waves, ONE block per CU: all 256 accumulator registers of a lane hold 16 transform positions x 4 N tiles of
+//     v_mfma_f32_16x16x4_f32 (M = 16 Winograd tiles, N = 16 channels).  Block tile = 16x16 output pixels = 8x8 Winograd tiles;
+//     wave w owns tile rows 2w, 2w+1 and ALL 64 output channels, so the input transform is computed once per (tile, channel) and
+//     the output transform needs no exchange between waves.  Lane (m = lane & 15, kq = lane >> 4) = tile m, k-quarter kq.
+//   * K outermost: 4 steps of 16 input channels (lane: channels 16 s + 4 kq + j, j = the four MFMA k-steps).  Per step a lane reads
+//     its 4x4 patch (16 ds_read_b128), forms V = B^T d B with 32 float4 adds -- rolled over the step's chunks, row i of V being
+//     rewritten for step s+1 right after chunk i of step s has consumed it -- and issues 16 positions x 4 N tiles x 4 = 256 MFMAs.
+//     fp32 MFMAs execute on the vector ALUs: every VALU instruction costs ~7 matrix cycles, so addresses are buffer descriptors +
+//     scalar offsets + immediates, and accumulators start from an inline-constant zero C operand instead of being cleared.
+//   * transformed weights (256 KB per conv; gamma of a dynamic conv folded in per frame, see launch_wino_images) stream L2 -> registers
+//     -> a 4-slot LDS ring in 16 chunks of 16 KB (chunk = step s, position row i), requested three chunks ahead; B fragments are read
+//     one position ahead of the MFMAs, across chunk seams too (chunk c+1 is visible since the barrier at the top of chunk c).
+//   * the halo tile (18 x 18 pixels x 64 channels = 81 KB) lives in LDS as four 16-channel slabs; K-outer order frees slab s after
+//     step s-1's reads, so the NEXT tile's slab s replaces it during step s: no second halo buffer, no serial halo fill between tiles.
+//     Pixels of a halo row are stored even columns first: the 8 tiles of a row then read 8 consecutive 64-B pixels (2-way instead of
+//     8-way bank conflicts on the patch reads).
+//   * partition branches (front half): the three per-pixel-weighted 1x1 convs accumulate straight into the transform domain -- a value
+//     added to position (0,0) / -(0,3) / -(3,0) / (3,3) reaches exactly output pixel (0,0) / (0,1) / (1,0) / (1,1) through A^T . A --
+//     as a fifth chunk per step whose A operand is par_j(pixel) * x(centre pixel); branches whose plane is zero on the tile are skipped.
+//   * epilogue: Y = A^T M A in registers, + bias (* gamma), activation; one N tile at a time through 4 KiB of LDS per wave (the ring
+//     slot the tile's last chunk has just left) so that residual loads and stores move 16 B per lane (64-B channel runs per pixel).
+#include "conv_mfma.h"
+#include <type_traits>
+
+namespace {
+
+template <int N>
+using I = std::integral_constant<int, N>;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HP = 18, NPX = HP * HP;
+constexpr int SLAB_B = NPX * 64;              // bytes per 16-channel slab of the halo tile
+constexpr int RING_B = 4 * 16384;             // four 16-KiB weight chunks
+constexpr int PV_B = RING_B + 4 * SLAB_B;      // per thread 3 float4: the partition values of its tile's 4 pixels, signed (PAR)
+constexpr int BG_B = PV_B + 256 * 48;         // 64 floats: bias * gamma
+constexpr int WINO_LDS = BG_B + 256;          // 161024
+constexpr unsigned OOBW = 0xFFFFFFF0u;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+// LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the weight / halo requests kept in flight
+__device__ __forceinline__ void lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct WinoArgs {
+    const float* src;       // NHWC64
+    const float* U;         // 16 chunks x 4096 floats (launch_wino_images)
+    const float* Upar;      // PAR: 4 steps x 3 branches x 1024 floats (launch_wino_par_image)
+    const float* par;       // 3 planes
+    long par_plane;
+    const int* par_flags;   // per 8x16 tile (launch_par_tile_flags) or nullptr
+    const float *bias, *gamma, *residual;
+    float* out;
+    int H, W, act;
+    unsigned long long* dbg;
+};
+
+template <bool PAR, bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + 15) >> 4, ntiles = tiles_x * ((H + 15) >> 4);
+
+    // ---- strip of tiles: XCD x owns a contiguous band, dealt round-robin to its resident blocks (neighbouring halos share its L2)
+    int tile, tstep, tend;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int bq = ntiles >> 3, br = ntiles & 7;
+        const int xbeg = xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq;
+        tend = xbeg + bq + (xcd < br ? 1 : 0);
+        tile = xbeg + slot;
+        tstep = gridDim.x >> 3;
+    } else {
+        tile = blockIdx.x;
+        tstep = gridDim.x;
+        tend = ntiles;
+    }
+    if (tile >= tend) return;
+
+    const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
+    // halo pixel (ry, rx) of a tile at (y0, x0) is image pixel (y0 - 1 + ry, x0 - 1 + rx): the descriptor's base sits one row and one
+    // pixel before the map so that lane offsets stay non-negative; lanes outside the image carry the offset OOBW (-> zeros)
+    const __amdgpu_buffer_rsrc_t r_src = rsrc_of(reinterpret_cast<const char*>(a.src) - ((long)W + 1) * 256, OOBW);
+    const __amdgpu_buffer_rsrc_t r_u = rsrc_of(a.U, 16u * 16384u);
+    const __amdgpu_buffer_rsrc_t r_up = rsrc_of(PAR ? a.Upar : a.U, 4u * 12288u);
+    const __amdgpu_buffer_rsrc_t r_out = rsrc_of(a.out, map_bytes);
+    const __amdgpu_buffer_rsrc_t r_res = rsrc_of(RES ? a.residual : a.src, RES ? map_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t r_par = rsrc_of(a.par, PAR ? (unsigned)(3 * a.par_plane * 4) : 0u);
+
+    const unsigned t16 = (unsigned)t * 16u;
+    // patch base of this lane's tile (even-columns-first pixel order inside a halo row): tile (ty, tx) -> pixel row 2 ty, column pair tx
+    const int ty = 2 * wave + (m >> 3), tx = m & 7;
+    const unsigned dbase0 = RING_B + ((2 * ty) * HP + tx) * 64 + kq * 16, dbase1 = dbase0 + 2 * SLAB_B;
+    auto lds4 = [&](unsigned byte) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + byte); };
+    // d[r][c] of slab S: column c of the patch is halo column 2 tx + c = pair tx + (c >> 1) of parity c & 1
+    auto patch = [&](auto s_c, int r, int c) -> f32x4 {
+        constexpr int S = decltype(s_c)::value;
+        const unsigned off = (S & 1) * SLAB_B + (r * HP + (c & 1) * 9 + (c >> 1)) * 64;
+        return lds4((S < 2 ? dbase0 : dbase1) + off);
+    };
+
+    const float act_lo = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    // bias * gamma and the partition values live in LDS, not in registers: the K loop runs at the 256-VGPR limit, and a value
+    // spilled to scratch comes back behind an s_waitcnt vmcnt(0) that also waits for every weight / halo request in flight
+    if (t < 64) *reinterpret_cast<float*>(smem + BG_B + t * 4) = (a.bias ? a.bias[t] : 0.f) * (a.gamma ? a.gamma[t] : 1.f);
+    // (accumulator register r of N tile nt is tile 4 kq + r -- C/D layout of the 16x16 MFMA -- channel 16 nt + m;
+    //  tile (ty', tx') = (2 wave + (kq >> 1), 4 (kq & 1) + r), pixel (a, b) of it: see the epilogue)
+
+    f32x4 acc[16][4];
+    f32x4 V[16], d0[4], d1[4], d2[4], d3[4], bf[4], breg[4], hreg[3];
+    unsigned hoff[6];
+
+    auto row_tf = [&](int i) {
+        f32x4 tt[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tt[c] = i == 0 ? d0[c] - d2[c] : (i == 1 ? d1[c] + d2[c] : (i == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
+        V[4 * i + 0] = tt[0] - tt[2];
+        V[4 * i + 1] = tt[1] + tt[2];
+        V[4 * i + 2] = tt[2] - tt[1];
+        V[4 * i + 3] = tt[1] - tt[3];
+    };
+    // per-lane offsets of the six halo float4 this thread moves per slab (element e = t + 256 i of the slab's LDS image), for the tile at
+    // (y0, x0); recomputed per tile from the laundered thread id so that they do not stay live as 12 more registers
+    auto halo_offsets = [&](int tq, int y0, int x0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int e = tq + 256 * i;
+            e = e < NPX * 4 ? e : NPX * 4 - 1;
+            const int pl = e >> 2, quad = e & 3, ry = (pl * 3641) >> 16, col = pl - ry * HP;      // pl / 18 for pl < 324
+            const int rx = col < 9 ? 2 * col : 2 * col - 17;
+            const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+            const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            hoff[i] = inb ? (unsigned)(ry * W + rx) * 256u + (unsigned)quad * 16u : OOBW;
+        }
+    };
+    auto load_pv = [&](int tq_, int y0, int x0) {
+        if constexpr (PAR) {
+            const int mq = tq_ & 15, py = y0 + 2 * (2 * (tq_ >> 6) + (mq >> 3)), px = x0 + 2 * (mq & 7);
+            unsigned po[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gy = py + (q >> 1), gx = px + (q & 1);
+                po[q] = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOBW;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = bload1(r_par, po[q], (unsigned)(j * a.par_plane * 4));
+                v[1] = -v[1];                                     // positions (0,3) and (3,0) enter the output transform negated
+                v[2] = -v[2];
+                *reinterpret_cast<f32x4*>(smem + PV_B + tq_ * 48 + j * 16) = v;
+            }
+        }
+    };
+
+    int ty0 = (tile / tiles_x) * 16, tx0 = (tile % tiles_x) * 16;
+    // ---- prologue: whole halo of the first tile, chunks 0..2, first patch
+    {
+        halo_offsets(t, ty0, tx0);
+        const unsigned so = (unsigned)(ty0 * W + tx0) * 256u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 h[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) h[i] = bload4(r_src, hoff[i], so + s * 64);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int e = t + 256 * i;
+                e = e < NPX * 4 ? e : NPX * 4 - 1;
+                *reinterpret_cast<f32x4*>(smem + RING_B + s * SLAB_B + e * 16) = h[i];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool brc = PAR && (c % 5 == 0);
+#pragma unroll
+            for (int i = 0; i < (brc ? 3 : 4); ++i) {
+                const f32x4 v = brc ? bload4(r_up, t16, (c / 5) * 12288 + i * 4096)
+                                    : bload4(r_u, t16, (PAR ? (c / 5) * 4 + (c % 5) - 1 : c) * 16384 + i * 4096);
+                *reinterpret_cast<f32x4*>(smem + (c & 3) * 16384 + i * 4096 + t16) = v;
+            }
+        }
+        load_pv(t, ty0, tx0);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            d0[c] = patch(I<0>{}, 0, c);
+            d1[c] = patch(I<0>{}, 1, c);
+            d2[c] = patch(I<0>{}, 2, c);
+            d3[c] = patch(I<0>{}, 3, c);
+        }
+        row_tf(0);
+        row_tf(1);
+        row_tf(2);
+    }
+    // (the B fragment of lane l, N tile n, position column pj of a chunk in slot z sits at z * 16384 + (pj * 4 + n) * 1024 + l * 16)
+    const unsigned bl = (unsigned)lane * 16u;
+    if constexpr (!PAR) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bf[n] = lds4(bl + n * 1024);
+    }
+
+    float warm0 = 0.f, warm1 = 0.f;
+    unsigned long long dbg_t0 = 0;
+    if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memtime();
+    int dbg_n = 0;
+    int tq = t;
+    for (;;) {
+        asm volatile("" : "+v"(tq));
+        const int ntile = tile + tstep;
+        const bool has_next = ntile < tend;
+        const int nty0 = has_next ? (ntile / tiles_x) * 16 : ty0, ntx0 = has_next ? (ntile % tiles_x) * 16 : tx0;
+        const unsigned nso = (unsigned)(nty0 * W + ntx0) * 256u;
+        halo_offsets(tq, nty0, ntx0);
+        const unsigned tq16 = (unsigned)tq * 16u;
+        int need = 7;
+        if constexpr (PAR) {
+            if (a.par_flags) {
+                const int ftx = (W + 15) >> 4, f0 = (ty0 >> 3) * ftx + (tx0 >> 4);
+                need = a.par_flags[f0] & 7;
+                if (ty0 + 8 < H) need |= a.par_flags[f0 + ftx] & 7;
+            }
+            need = __builtin_amdgcn_readfirstlane(need);
+            // the four accumulators the branches add into start from zero (the others from an inline-constant zero C operand)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[0][n] = acc[3][n] = acc[12][n] = acc[15][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+        // one chunk of the K loop.  C = chunk index inside the tile (slot C & 3); KIND 0: position row PG of step S; KIND 1: the branch
+        // chunk of step S (PAR only)
+        auto chunk = [&](auto c_c, auto s_c, auto pg_c, auto kind_c) {
+            constexpr int C = decltype(c_c)::value, S = decltype(s_c)::value, PG = decltype(pg_c)::value, KIND = decltype(kind_c)::value;
+            constexpr int CPT = PAR ? 20 : 16;
+            constexpr int NC = (C + 3) % CPT;                        // the chunk requested now (three ahead)
+            constexpr bool NBR = PAR && (NC % 5 == 0);
+            constexpr int NSTEP = PAR ? NC / 5 : NC / 4, NPG = PAR ? NC % 5 - 1 : NC % 4;
+            lds_bar();
+#pragma unroll
+            for (int i = 0; i < (NBR ? 3 : 4); ++i)
+                breg[i] = NBR ? bload4(r_up, tq16, NSTEP * 12288 + i * 4096) : bload4(r_u, tq16, (NSTEP * 4 + NPG) * 16384 + i * 4096);
+            // next tile's slab S in two halves: requested in position chunks 0 / 1 of step S, written one chunk later
+            if (KIND == 0 && (PG == 1 || PG == 2)) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    int e = tq + 256 * (i + 3 * (PG - 1));
+                    e = e < NPX * 4 ? e : NPX * 4 - 1;
+                    *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[i];
+                }
+            }
+            if (KIND == 0 && (PG == 0 || PG == 1)) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) hreg[i] = bload4(r_src, hoff[i + 3 * PG], nso + S * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KIND == 1) {
+                // ---- partition branches of step S: A = par_j(pixel) * x(pixel), x = the patch centre (d rows 1, 2 x columns 1, 2 of step S)
+                // first the fragments of the following position chunk (visible since the previous barrier)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bf[n] = lds4(((C + 1) & 3) * 16384 + bl + n * 1024);
+                auto branch = [&](auto j_c) {
+                    constexpr int J = decltype(j_c)::value;
+                    f32x4 bb[4], ax[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bb[n] = lds4((C & 3) * 16384 + (J * 4 + n) * 1024 + bl);
+                    const f32x4 pv = lds4(PV_B + tq * 48 + J * 16);
+                    ax[0] = d1[1] * pv[0];
+                    ax[1] = d1[2] * pv[1];
+                    ax[2] = d2[1] * pv[2];
+                    ax[3] = d2[2] * pv[3];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) {
+                                f32x4& ac = q == 0 ? acc[0][n] : (q == 1 ? acc[3][n] : (q == 2 ? acc[12][n] : acc[15][n]));
+                                ac = mfma16(ax[q][k], bb[n][k], ac);
+                            }
+                };
+                if (need & 1) branch(I<0>{});
+                if (need & 2) branch(I<1>{});
+                if (need & 4) branch(I<2>{});
+            } else {
+                // ---- rolling input transform for step S + 1 (chunk 0 finishes row 3 of step S first)
+                using SN = I<(S + 1) & 3>;
+                if (RES && S == 3 && PG == 0 && !(ty0 + 16 > H || tx0 + 16 > W)) {
+                    // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (4 rows x
+                    // 16 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
+                    const unsigned wo = (unsigned)((4 * (tq >> 6) + ((tq >> 5) & 1)) * W) * 256u + (unsigned)(tq & 31) * 128u;
+                    warm0 = bload1(r_res, wo, (unsigned)(ty0 * W + tx0) * 256u);
+                    warm1 = bload1(r_res, wo + (unsigned)W * 512u, (unsigned)(ty0 * W + tx0) * 256u);
+                }
+                if (PG == 0) {
+                    row_tf(3);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        d0[c] = patch(SN{}, 0, c);
+                        d2[c] = patch(SN{}, 2, c);
+                    }
+                } else if (PG == 1) {
+                    row_tf(0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d1[c] = patch(SN{}, 1, c);
+                } else if (PG == 2) {
+                    row_tf(1);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d3[c] = patch(SN{}, 3, c);
+                } else {
+                    row_tf(2);
+                    if (S == 3) load_pv(tq, nty0, ntx0);   // this tile's last branch chunk is behind us
+                }
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj) {
+                    constexpr bool NEXT_IS_BR = PAR && PG == 3;      // the next chunk is a branch chunk: it reads its own fragments
+                    f32x4 bfn[4];
+                    if (pj < 3 || !NEXT_IS_BR) {
+                        const unsigned nb = pj < 3 ? (C & 3) * 16384 + (pj + 1) * 4096 : ((C + 1) & 3) * 16384;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) bfn[n] = lds4(nb + bl + n * 1024);
+                    }
+                    constexpr int P0 = PG * 4;
+                    const int p = P0 + pj;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            // step 0, first k-step: C operand = 0 (no accumulator clearing; the four positions the branches use excepted),
+                            // or the bias at position (1,1), which A^T . A carries to all four output pixels with weight 1
+                            const bool fresh = S == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
+                            float bgn = 0.f;
+                            if (S == 0 && k == 0 && p == 5) bgn = *reinterpret_cast<const float*>(smem + BG_B + n * 64 + (tq & 15) * 4);
+                            const f32x4 c0 = p == 5 ? f32x4{bgn, bgn, bgn, bgn} : f32x4{0.f, 0.f, 0.f, 0.f};
+                            acc[p][n] = mfma16(V[p][k], bf[n][k], fresh ? c0 : acc[p][n]);
+                        }
+                    if (pj < 3 || !NEXT_IS_BR) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) bf[n] = bfn[n];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < (NBR ? 3 : 4); ++i) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + i * 4096 + tq16) = breg[i];
+        };
+        auto step = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            if constexpr (PAR) {
+                chunk(I<5 * S>{}, s_c, I<0>{}, I<1>{});
+                chunk(I<5 * S + 1>{}, s_c, I<0>{}, I<0>{});
+                chunk(I<5 * S + 2>{}, s_c, I<1>{}, I<0>{});
+                chunk(I<5 * S + 3>{}, s_c, I<2>{}, I<0>{});
+                chunk(I<5 * S + 4>{}, s_c, I<3>{}, I<0>{});
+            } else {
+                chunk(I<4 * S>{}, s_c, I<0>{}, I<0>{});
+                chunk(I<4 * S + 1>{}, s_c, I<1>{}, I<0>{});
+                chunk(I<4 * S + 2>{}, s_c, I<2>{}, I<0>{});
+                chunk(I<4 * S + 3>{}, s_c, I<3>{}, I<0>{});
+            }
+        };
+        step(I<0>{});
+        step(I<1>{});
+        step(I<2>{});
+        step(I<3>{});
+
+        // ---- epilogue: Y = A^T M A per (tile, channel) in the accumulator layout (+ bias (* gamma), activation), then one N tile at a
+        //      time through LDS -- the wave's 4 x 16 pixel strip x 16 channels = 4 KiB of ring slot 3, free now: the next tile's chunks
+        //      0..2 sit in slots 0..2 -- so that residual loads and stores are 16 B per lane (64-B channel runs per pixel)
+        const unsigned so = (unsigned)(ty0 * W + tx0) * 256u;
+        const bool partial = ty0 + 16 > H || tx0 + 16 > W;
+        lds_bar();                       // every wave has read its last fragments out of slot 3
+        auto epilogue = [&](auto partial_c) {
+            constexpr bool PARTIAL = decltype(partial_c)::value;
+            const int lq = tq & 63, wq = tq >> 6, kqq = lq >> 4, mq = lq & 15;
+            char* tr = smem + 3 * 16384 + wq * 4096;
+            // write side: value (q = 2 a + b, r) of this lane is strip pixel (row 2 (kq >> 1) + a, column 8 (kq & 1) + 2 r + b), channel m
+            const unsigned wbase = (unsigned)(((2 * (kqq >> 1)) * 16 + 8 * (kqq & 1)) * 64 + mq * 4);
+            // read side: float4 j of this lane = strip pixel (row j, column lane >> 2), channels 4 (lane & 3) .. + 3 of the N tile
+            const unsigned rbase = (unsigned)((lq >> 2) * 64 + (lq & 3) * 16);
+            unsigned go[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                go[j] = (unsigned)((4 * wq + j) * W + (lq >> 2)) * 256u + (unsigned)(lq & 3) * 16u;
+                if (PARTIAL) go[j] = (ty0 + 4 * wq + j < H && tx0 + (lq >> 2) < W) ? go[j] : OOBW;
+            }
+            f32x4 rs[4];
+            if (RES) asm volatile("" ::"v"(warm0), "v"(warm1));       // (keeps the warm-up loads alive; they are long done)
+            if (RES) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rs[j] = bload4(r_res, go[j], so);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                f32x4 w0[4], w1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w0[i] = acc[i * 4 + 0][n] + acc[i * 4 + 1][n] + acc[i * 4 + 2][n];
+                    w1[i] = acc[i * 4 + 1][n] - acc[i * 4 + 2][n] - acc[i * 4 + 3][n];
+                }
+                f32x4 y[4];
+                y[0] = w0[0] + w0[1] + w0[2];
+                y[1] = w1[0] + w1[1] + w1[2];
+                y[2] = w0[1] - w0[2] - w0[3];
+                y[3] = w1[1] - w1[2] - w1[3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // (the bias came in through the accumulator of position (1,1))
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(tr + wbase + ((q >> 1) * 16 + 2 * r + (q & 1)) * 64) = y[q][r];
+                }
+                f32x4 o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const f32x4*>(tr + rbase + j * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = __builtin_elementwise_max(o[j], act_lo * o[j]);       // none: max(v, v) | relu: max(v, 0 v) | leaky-relu: max(v, 0.1 v)
+                    if (RES) {
+                        o[j] += rs[j];
+                        if (n < 3) rs[j] = bload4(r_res, go[j], so + (n + 1) * 64);       // requested one N tile ahead
+                    }
+                    bstore4(r_out, go[j], so + n * 64, o[j]);      // (the N tile's 64 B go into the scalar offset: go[j] may be the OOB marker)
+                }
+            }
+        };
+        if (partial) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        ++dbg_n;
+        if (!has_next) break;
+        tile = ntile;
+        ty0 = nty0;
+        tx0 = ntx0;
+    }
+    if (a.dbg && t == 0) {
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 16;
+        d[0] = dbg_t0;
+        d[3] = __builtin_amdgcn_s_memtime();
+        d[7] = dbg_n;
+    }
+}
+
+// ---- weight images ------------------------------------------------------------------------------------------------------------
+// U = G g G^T per (output channel, input channel), times gamma[co] when given (see launch_wino_images), from a packed direct-conv
+// B image (common.h: 9 chunks, chunk = tap; float index ((q * 2 + nt32) * 64 + h * 32 + n32) * 4 + j  <->  ci = 8 q + 4 h + j,
+// co = 32 nt32 + n32) into 16 chunks (chunk = 4 * (ci >> 4) + position row i; float index
+// ((pj * 4 + (co >> 4)) * 64 + ((ci >> 2) & 3) * 16 + (co & 15)) * 4 + (ci & 3)).  Computed in double, rounded once.
+struct WinoImgArgs {
+    const float* src[16];
+    float* dst[16];
+    const float* gamma;
+};
+__global__ __launch_bounds__(256) void wino_image_kernel(const WinoImgArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // [ci >> 4 | co >> 4 | (ci >> 2) & 3 | co & 15 | ci & 3]
+    const int ci = ((idx >> 10) & 3) * 16 + ((idx >> 6) & 3) * 4 + (idx & 3), co = ((idx >> 8) & 3) * 16 + ((idx >> 2) & 15);
+    const float* s = a.src[blockIdx.y];
+    float* d = a.dst[blockIdx.y];
+    double g[3][3];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        g[tap / 3][tap % 3] = s[tap * 4096 + (((ci >> 3) * 2 + (co >> 5)) * 64 + ((ci >> 2) & 1) * 32 + (co & 31)) * 4 + (ci & 3)];
+    const double gm = a.gamma ? (double)a.gamma[co] : 1.0;
+    double tmp[4][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        tmp[0][x] = g[0][x];
+        tmp[1][x] = 0.5 * (g[0][x] + g[1][x] + g[2][x]);
+        tmp[2][x] = 0.5 * (g[0][x] - g[1][x] + g[2][x]);
+        tmp[3][x] = g[2][x];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double u[4] = {tmp[i][0], 0.5 * (tmp[i][0] + tmp[i][1] + tmp[i][2]), 0.5 * (tmp[i][0] - tmp[i][1] + tmp[i][2]), tmp[i][2]};
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj)
+            d[((ci >> 4) * 4 + i) * 4096 + ((pj * 4 + (co >> 4)) * 64 + ((ci >> 2) & 3) * 16 + (co & 15)) * 4 + (ci & 3)] = (float)(u[pj] * gm);
+    }
+}
+
+// the three 1x1 branch images (PACK_1X1 chunks, same float index as above with tap = branch) -> [step s][branch][N tile][lane][j]
+__global__ __launch_bounds__(256) void wino_par_image_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // 3 * 4096
+    const int br = idx >> 12, e = idx & 4095;
+    const int ci = ((e >> 10) & 3) * 16 + ((e >> 6) & 3) * 4 + (e & 3), co = ((e >> 8) & 3) * 16 + ((e >> 2) & 15);
+    const float v = src[br * 4096 + (((ci >> 3) * 2 + (co >> 5)) * 64 + ((ci >> 2) & 1) * 32 + (co & 31)) * 4 + (ci & 3)];
+    dst[(((ci >> 4) * 3 + br) * 4 + (co >> 4)) * 256 + (((ci >> 2) & 3) * 16 + (co & 15)) * 4 + (ci & 3)] = v;
+}
+
+}  // namespace
+
+int launch_wino_images(const float* const* src, float* const* dst, int n, const float* gamma, hipStream_t stream) {
+    if (n < 1 || n > 16) return PNP_ERR_BAD_ARG;
+    WinoImgArgs a;
+    for (int i = 0; i < 16; ++i) {
+        a.src[i] = src[i < n ? i : 0];
+        a.dst[i] = dst[i < n ? i : 0];
+    }
+    a.gamma = gamma;
+    hipLaunchKernelGGL(wino_image_kernel, dim3(16, n), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+int launch_wino_par_image(const float* src, float* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(wino_par_image_kernel, dim3(48), dim3(256), 0, stream, src, dst);
+    return (int)hipGetLastError();
+}
+
+bool conv_wino_eligible(const ConvArgs& a, int cfg, int grid_y) {
+    if (!a.wwino || a.prec != 0 || cfg == CONV_CFG_RGB || grid_y != 1 || a.out_mode != 0) return false;
+    if (a.nsrc != 1 || a.src_c[0] != 64 || a.src_f16 || a.out_f16 || a.out16) return false;
+    if (a.wpar && (!a.wwino_par || !a.par)) return false;
+    return (long)a.H * a.W * 256 < ((long)1 << 32) - 65536;
+}
+
+int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
+    static PnpPerDevice once;
+    int cus = 256;
+    const hipError_t attr_err = once.run([](int dev, int& g) {
+        hipError_t e = hipSuccess;
+        const void* fns[4] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false>),
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true>),
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, false>),
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, true>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
+        g = 256;
+        (void)hipDeviceGetAttribute(&g, hipDeviceAttributeMultiprocessorCount, dev);
+        return e;
+    }, &cus);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    WinoArgs w;
+    w.src = a.src[0];
+    w.U = a.wwino;
+    w.Upar = a.wpar ? a.wwino_par : nullptr;
+    w.par = a.par;
+    w.par_plane = a.par_plane;
+    w.par_flags = a.par_flags;
+    w.bias = a.bias;
+    w.gamma = a.gamma;
+    w.residual = a.residual;
+    w.out = a.out;
+    w.H = a.H;
+    w.W = a.W;
+    w.act = a.act;
+    w.dbg = a.dbg;
+    const int ntiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
+    int grid = ntiles < cus ? ntiles : cus;                 // one resident block per CU
+    if (grid >= 8) grid -= grid % 8;
+    if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    return (int)hipGetLastError();
+}

@@ -45,6 +45,7 @@ struct BlockPk {
     int64_t conv2_bias = -1;      // flat
     int64_t w1x1 = -1;            // packed, 3 chunks + 3 chunks scaled by PNP_PAR_UNIT (split-fp16 fast path on binary partition maps)
     int dyn_conv2 = -1, dyn_conv1 = -1;
+    int64_t conv1_wino = -1, conv2_wino = -1, w1x1_wino = -1;   // packed: Winograd images of the static convs / the 1x1 branches (conv_wino.hip)
 };
 
 struct BranchPk {
@@ -68,7 +69,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
-    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1};   // pnp_generator_set_option (defaults: everything on but the chain mirrors)
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1, 0};   // pnp_generator_set_option (defaults: everything on but the chain mirrors and Winograd)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;
@@ -86,6 +87,7 @@ struct pnp_generator {
     int64_t dyn_w = 0, dyn_b = 0;     // flat offsets of the dynamic conv banks
     BranchPk br[2];                   // 0 backward, 1 forward
     int64_t hr_img = -1, hr_bias = -1, last_img = -1, last_bias = -1;       // last_bias packed (32)
+    int64_t hr_wino = -1;                                                   // packed: Winograd image of conv_hr
     int64_t ones2 = -1;                                                     // packed: {1, 1}
     int64_t last_valu = -1;                                                 // packed: conv_last weights [9][64][4]
     int64_t up_img[2] = {-1, -1}, up_bias[2] = {-1, -1};                    // packed
@@ -238,6 +240,15 @@ int build_layout(pnp_generator* g) {
             g->up_bias[u] = g->add_packed(256);
         }
     }
+    // Winograd images of the static 64 -> 64 convs and of the 1x1 branches (PNP_OPT_WINOGRAD; conv_wino.hip).  Appended last: no
+    // earlier offset moves.  The dynamic convs get theirs per frame in the workspace (their channel gain is folded in).
+    for (int b = 0; b < 2; ++b)
+        for (auto& K : g->br[b].blocks) {
+            if (K.conv1_img >= 0) K.conv1_wino = g->add_packed(PNP_WINO_IMG_FLOATS);
+            if (K.conv2_img >= 0) K.conv2_wino = g->add_packed(PNP_WINO_IMG_FLOATS);
+            K.w1x1_wino = g->add_packed(PNP_WINO_PAR_FLOATS);
+        }
+    g->hr_wino = g->add_packed(PNP_WINO_IMG_FLOATS);
     return PNP_OK;
 }
 
@@ -344,6 +355,9 @@ struct ConvCall {
         return *this;
     }
     ConvCall& residual(const float* r) { residual_ = r; return *this; }
+    // Winograd images of the (single) source's weights and of the branch weights; nullptr = the direct kernels
+    const float *wino_ = nullptr, *wino_par_ = nullptr;
+    ConvCall& wino(const float* u, const float* upar = nullptr) { wino_ = u; wino_par_ = upar; return *this; }
     ConvCall& act(int a) { act_ = a; return *this; }                      // 0 none, 1 relu, 2 leaky-relu(0.1)
     ConvCall& to(float* d) { dst = d; return *this; }
     // out_mode of conv_mfma.h with `gy` weight images `w_ystride` floats apart (pixel shuffle: 4, DCN offsets: 7)
@@ -373,6 +387,7 @@ struct Workspace {
     // the MV-aligned key frame is then fp16 only and lives in kw
     uint16_t *x16, *slots16;
     int* parflags;    // per frame, per 8x16 tile: which partition planes are nonzero there (ConvArgs::par_flags)
+    float* wino;      // PNP_PREC_F32: Winograd images of one branch's dynamic convs for the frame in flight (2 per block; gain folded in)
     int* queue;       // PNP_PREC_F16X3: the split kernel's tile queue (ConvArgs::tile_queue), 16 ints, zero between launches
     int64_t bytes;
 };
@@ -423,6 +438,8 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     W.mixw = take((int64_t)t * g->ndyn * IMG_WIDE);
     W.mixb = take((int64_t)t * g->ndyn * 64);
     W.mixh = g->prec != PNP_PREC_F32 ? take((int64_t)t * g->ndyn * IMG_WIDE / (g->prec == PNP_PREC_F16X3 ? 1 : 2)) : nullptr;
+    // (not the last region: the flags behind it are written by every forward, which is what the sanitizer harness's shrunken-workspace self-test trips over)
+    W.wino = (g->prec == PNP_PREC_F32 && g->ndyn > 0) ? take((int64_t)2 * g->cfg.num_blocks * PNP_WINO_IMG_FLOATS) : nullptr;
     const bool mir = g->prec == PNP_PREC_F16 && g->cfg.deform == 0;      // sized whether or not PNP_OPT_F16_MIRRORS is on
     W.x16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32)) : nullptr;
     W.slots16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32 * t)) : nullptr;
@@ -436,7 +453,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
 
 extern "C" {
 
-int pnp_abi_version(void) { return 4; }
+int pnp_abi_version(void) { return 5; }
 
 int pnp_generator_create(const pnp_generator_cfg* cfg, pnp_generator** out) {
     if (!cfg || !out) return PNP_ERR_BAD_ARG;
@@ -483,7 +500,7 @@ int pnp_generator_get_precision(const pnp_generator* g) { return g ? g->prec : -
 
 int pnp_generator_set_option(pnp_generator* g, int option, int value) {
     if (!g || option < 0 || option >= PNP_OPT_COUNT) return PNP_ERR_BAD_ARG;
-    g->opt[option] = value != 0;
+    g->opt[option] = option == PNP_OPT_WINOGRAD ? (value < 0 ? 0 : (value > 2 ? 2 : value)) : (value != 0);
     return PNP_OK;
 }
 int pnp_generator_get_option(const pnp_generator* g, int option) {
@@ -584,6 +601,24 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
                                packed + g->up_bias[u], 256, 256, 1);
         }
     }
+    if (g->prec == PNP_PREC_F32) {   // Winograd images (only the fp32 path has a Winograd kernel)
+        std::vector<const float*> ws;
+        std::vector<float*> wd;
+        for (int b = 0; b < 2; ++b)
+            for (const auto& K : g->br[b].blocks) {
+                if (K.conv1_wino >= 0) { ws.push_back(packed + K.conv1_img); wd.push_back(packed + K.conv1_wino); }
+                if (K.conv2_wino >= 0) { ws.push_back(packed + K.conv2_img); wd.push_back(packed + K.conv2_wino); }
+                rc = launch_wino_par_image(packed + K.w1x1, packed + K.w1x1_wino, st);
+                if (rc) return rc;
+            }
+        ws.push_back(packed + g->hr_img);
+        wd.push_back(packed + g->hr_wino);
+        for (size_t i = 0; i < ws.size(); i += 16) {
+            const int n = (int)(ws.size() - i < 16 ? ws.size() - i : 16);
+            rc = launch_wino_images(ws.data() + i, wd.data() + i, n, nullptr, st);
+            if (rc) return rc;
+        }
+    }
     if (g->prec == PNP_PREC_F16) {   // every region is whole 64-output-channel chunks (the others are never read as fp16)
         rc = launch_f16_image(packed, packed + g->packed_floats, (int)(g->packed_floats / IMG_CHUNK), 2, st);
         if (rc) return rc;
@@ -633,6 +668,9 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     };
     const bool f16_maps = g->prec == PNP_PREC_F16 && g->opt[PNP_OPT_F16_MAPS];
     const bool par_skip = g->opt[PNP_OPT_PAR_SKIP] != 0;
+    // Winograd form of the single-source 64 -> 64 convs (fp32 path only): 1 = frames that fill the chip with 16x16 tiles, 2 = always
+    const int wopt = g->prec == PNP_PREC_F32 ? g->opt[PNP_OPT_WINOGRAD] : 0;
+    auto wino_ok = [&](int hh, int ww) { return wopt == 2 || (wopt == 1 && (int64_t)((hh + 15) / 16) * ((ww + 15) / 16) >= 512); };
     // every 64-channel map that is only read as an MFMA A operand gets an fp16 copy from its producer
     const bool mirrors = f16_maps && g->opt[PNP_OPT_F16_MIRRORS] && c.deform == 0 && W.x16 != nullptr;
     // ... and, optionally, the running map x INSIDE a branch too (input conv and every block write x16 next to x, every front
@@ -651,6 +689,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             a.wsrc_h[s] = twin(q.w[s]);
         }
         a.wpar = q.wpar_;
+        a.wwino = q.wino_;
+        a.wwino_par = q.wino_par_;
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
@@ -852,6 +892,21 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0).also16(const_cast<void*>(x16)));
             if (r) return r;
             const float* x = W.tmp0;
+            const bool wino = wino_ok(h, w);
+            if (wino && g->ndyn > 0) {      // this frame's Winograd images of the branch's expert-mixed convs, its channel gain folded in
+                std::vector<const float*> ws;
+                std::vector<float*> wd;
+                for (int k = 0; k < c.num_blocks; ++k) {
+                    const BlockPk& K = B.blocks[k];
+                    if (K.dyn_conv2 >= 0) { ws.push_back(W.mixw + ((int64_t)u * g->ndyn + K.dyn_conv2) * IMG_WIDE); wd.push_back(W.wino + (int64_t)(2 * k) * PNP_WINO_IMG_FLOATS); }
+                    if (K.dyn_conv1 >= 0) { ws.push_back(W.mixw + ((int64_t)u * g->ndyn + K.dyn_conv1) * IMG_WIDE); wd.push_back(W.wino + (int64_t)(2 * k + 1) * PNP_WINO_IMG_FLOATS); }
+                }
+                for (size_t j = 0; j < ws.size(); j += 16) {
+                    const int n = (int)(ws.size() - j < 16 ? ws.size() - j : 16);
+                    r = launch_wino_images(ws.data() + j, wd.data() + j, n, gam, st);
+                    if (r) return r;
+                }
+            }
             for (int k = 0; k < c.num_blocks; ++k) {
                 const BlockPk& K = B.blocks[k];
                 float* dst = (k == c.num_blocks - 1) ? slot : W.tmp0;
@@ -866,20 +921,23 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 const float* b1 = c.one_layer ? flat + K.conv1_bias
                                               : W.mixb + ((int64_t)u * g->ndyn + K.dyn_conv1) * 64;
                 const float* g1 = c.one_layer ? nullptr : gam;
+                const float* u2 = !wino ? nullptr : (woqp ? packed + K.conv2_wino : W.wino + (int64_t)(2 * k) * PNP_WINO_IMG_FLOATS);
+                const float* u1 = !wino ? nullptr : (c.one_layer ? packed + K.conv1_wino : W.wino + (int64_t)(2 * k + 1) * PNP_WINO_IMG_FLOATS);
+                const float* up = !wino ? nullptr : packed + K.w1x1_wino;
                 // the map between the two halves is read only as an MFMA A operand: an fp16 map on the fp16 path
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
                     r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(g2)
-                                 .partition(packed + K.w1x1, parp, pflags).act(1).to(W.tmp1).f16_map(o16));
+                                 .partition(packed + K.w1x1, parp, pflags).wino(u2, up).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
-                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).residual(x).to(dst)
+                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).wino(u1).residual(x).to(dst)
                                      .f16_map(s16).also16(dst16));
                 } else {                 // sr_backbone_utils.py:314-327
-                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).mirror16(x16).bias(b1).gamma(g1).act(1).to(W.tmp1)
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).mirror16(x16).bias(b1).gamma(g1).wino(u1).act(1).to(W.tmp1)
                                  .f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(g2)
-                                     .partition(packed + K.w1x1, parp, pflags).residual(x).to(dst).f16_map(s16).also16(dst16));
+                                     .partition(packed + K.w1x1, parp, pflags).wino(u2, up).residual(x).to(dst).f16_map(s16).also16(dst16));
                 }
                 if (r) return r;
                 x = dst;
@@ -940,7 +998,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
             if (!c.vsr) {   // :144-146
                 rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->hr_img).mirror16(s16of(i)).bias(flat + g->hr_bias)
-                              .act(2).to(W.tmp1).f16_map(o16));
+                              .wino(wino_ok(h, w) ? packed + g->hr_wino : nullptr).act(2).to(W.tmp1).f16_map(o16));
                 if (!rc)
                     rc = conv(ConvCall(h, w, CONV_CFG_RGB).source(W.tmp1, 64, packed + g->last_img).bias(packed + g->last_bias)
                                   .mode(2).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));
@@ -955,7 +1013,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                                   .bias(packed + g->up_bias[1], 64).act(2).mode(1, 4, IMG_WIDE).to(W.u2).f16_map(o16 | s16));
                 if (!rc)
                     rc = conv(ConvCall(4 * h, 4 * w, conv_pick_cfg(4 * h, 4 * w)).source(W.u2, 64, packed + g->hr_img)
-                                  .bias(flat + g->hr_bias).act(2).to(W.u3).f16_map(o16 | s16));
+                                  .bias(flat + g->hr_bias).wino(wino_ok(4 * h, 4 * w) ? packed + g->hr_wino : nullptr).act(2).to(W.u3)
+                                  .f16_map(o16 | s16));
                 if (!rc)
                     rc = conv(ConvCall(4 * h, 4 * w, CONV_CFG_RGB).source(W.u3, 64, packed + g->last_img)
                                   .bias(packed + g->last_bias).mode(3).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));
@@ -1185,6 +1244,44 @@ int pnp_pack_conv3x3_f32(const float* w, const float* ew, int E, int cout, int c
 
 int pnp_pack_conv1x1_f32(const float* w, float* dst, void* st) {
     return launch_pack_weights(plain_pack(w, 64, 1, PACK_1X1, 0, 2, 64, dst), 1, (hipStream_t)st);
+}
+
+int64_t pnp_wino_image_floats(void) { return PNP_WINO_IMG_FLOATS; }
+int64_t pnp_wino_par_image_floats(void) { return PNP_WINO_PAR_FLOATS; }
+
+int pnp_wino_image_from_packed_f32(const float* packed_w, const float* gamma, float* dst, void* st) {
+    return launch_wino_images(&packed_w, &dst, 1, gamma, (hipStream_t)st);
+}
+
+int pnp_wino_par_image_from_packed_f32(const float* packed_w1x1, float* dst, void* st) {
+    return launch_wino_par_image(packed_w1x1, dst, (hipStream_t)st);
+}
+
+int pnp_conv3x3_wino_f32(const float* src, const float* wino_w, const float* bias, const float* gamma, const float* wino_w1x1,
+                         const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
+                         void* st) {
+    if (!src || !wino_w || !out || act < 0 || act > 2 || (wino_w1x1 && !par)) return PNP_ERR_BAD_ARG;
+    if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = 1;
+    a.src[0] = src;
+    a.src_c[0] = 64;
+    a.wwino = wino_w;
+    a.wwino_par = wino_w1x1;
+    a.wpar = wino_w1x1;              // "has branches"; the direct-form image itself is not read on this path
+    a.par = wino_w1x1 ? par : nullptr;
+    a.par_flags = wino_w1x1 ? par_flags : nullptr;
+    a.par_plane = (long)h * w;
+    a.bias = bias;
+    a.gamma = gamma;
+    a.residual = residual;
+    a.out = out;
+    a.H = h;
+    a.W = w;
+    a.act = act;
+    if (!conv_wino_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
+    return launch_conv3x3_wino(a, (hipStream_t)st);
 }
 
 int pnp_conv3x3_f32(int nsrc, const float* const* srcs, const int* src_channels, const float* const* packed_w,

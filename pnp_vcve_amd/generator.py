@@ -129,7 +129,9 @@ class IconVSR_restore_wo_refill_mv_ipb_fast_domain_dynamic_with_par(nn.Module):
 
     def set_option(self, option, value):
         """pnp_generator_set_option: A/B switches of the native scheduler (_native.OPT_*); per-generator state."""
-        _native.check(_native.lib().pnp_generator_set_option(self._handle, int(option), int(bool(value))),
+        # PNP_OPT_WINOGRAD takes 0 / 1 / 2 (off / large frames / every frame size); the others are booleans
+        v = int(value) if int(option) == _native.OPT_WINOGRAD else int(bool(value))
+        _native.check(_native.lib().pnp_generator_set_option(self._handle, int(option), v),
                       'pnp_generator_set_option')
         self._graphs = {}
 

@@ -331,6 +331,47 @@ def mv_warp_nhwc_f16(feat, flow_x, flow_y):
 
 
 @_on_device_of_first_tensor
+def wino_image(packed, gamma=None):
+    """Winograd F(2x2,3x3) image (65536 floats) of a packed 64 -> 64 direct-conv image (pack_conv3x3), times gamma[co] if given."""
+    packed = _chk(packed, 'packed')
+    if packed.numel() != 9 * 4096:
+        raise ValueError('packed must be a 9-chunk 64-channel image')
+    out = torch.empty(int(_native.lib().pnp_wino_image_floats()), device=packed.device, dtype=torch.float32)
+    _native.check(_native.lib().pnp_wino_image_from_packed_f32(_ptr(packed), _ptr(_chk(gamma, 'gamma')) if gamma is not None else None,
+                                                               _ptr(out), _stream()), 'pnp_wino_image_from_packed_f32')
+    return out
+
+
+@_on_device_of_first_tensor
+def wino_par_image(packed_w1x1):
+    packed_w1x1 = _chk(packed_w1x1, 'packed_w1x1')
+    out = torch.empty(int(_native.lib().pnp_wino_par_image_floats()), device=packed_w1x1.device, dtype=torch.float32)
+    _native.check(_native.lib().pnp_wino_par_image_from_packed_f32(_ptr(packed_w1x1), _ptr(out), _stream()),
+                  'pnp_wino_par_image_from_packed_f32')
+    return out
+
+
+@_on_device_of_first_tensor
+def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par_flags=None, residual=None, act=0):
+    """act(gamma * (conv3x3(x; W) + bias) + sum_j par_j * conv1x1_j(x)) + residual on conv_wino.hip; x (h,w,64) NHWC fp32,
+    wino_w = wino_image(packed W, gamma) -- the SAME gamma -- and wino_w1x1 = wino_par_image(packed 1x1 images)."""
+    x = _chk(x, 'x')
+    h, w, c = x.shape
+    if c != 64:
+        raise ValueError('x must be (h, w, 64)')
+    out = torch.empty_like(x)
+    opt = lambda t, n: _ptr(_chk(t, n)) if t is not None else None   # noqa: E731
+    if par_flags is not None and (par_flags.dtype != torch.int32 or not par_flags.is_cuda):
+        raise ValueError('par_flags must be a CUDA int32 tensor')
+    _native.check(_native.lib().pnp_conv3x3_wino_f32(_ptr(x), _ptr(_chk(wino_w, 'wino_w')), opt(bias, 'bias'), opt(gamma, 'gamma'),
+                                                     opt(wino_w1x1, 'wino_w1x1'), opt(par, 'par'),
+                                                     ctypes.c_void_p(par_flags.data_ptr()) if par_flags is not None else None,
+                                                     opt(residual, 'residual'), int(act), _ptr(out), h, w, _stream()),
+                  'pnp_conv3x3_wino_f32')
+    return out
+
+
+@_on_device_of_first_tensor
 def frames_to_rgb8(frames):
     """(n,3,h,w) fp32 CUDA frames -> (n,h,w,3) uint8 RGB CUDA tensor with tensor2img's arithmetic."""
     frames = _chk(frames, 'frames')

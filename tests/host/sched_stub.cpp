@@ -216,6 +216,10 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
         RD("the partition planes", a.par, (size_t)(2 * a.par_plane + hw) * 4);
         if (a.par_flags) RD("the partition tile flags", a.par_flags, (size_t)((a.W + 15) / 16) * ((a.H + 7) / 8) * 4);
     }
+    if (path == 0 && a.wwino && conv_wino_eligible(a, cfg, gy)) {      // the Winograd kernel reads these INSTEAD of wsrc / wpar (read above as well: harmless over-check)
+        RD("the Winograd weight image", a.wwino, (size_t)PNP_WINO_IMG_FLOATS * 4);
+        if (a.wpar) RD("the Winograd 1x1 weight image", a.wwino_par, (size_t)PNP_WINO_PAR_FLOATS * 4);
+    }
     if (a.bias) RD("the bias", a.bias, (size_t)((gy - 1) * a.bias_ystride + (rgb_head ? 3 : 64)) * 4);
     if (a.gamma) RD("the channel gain", a.gamma, 64 * 4);
     if (a.residual) RD("the residual map", a.residual, hw * 256);
@@ -278,6 +282,31 @@ int launch_f16_image(const float* src, void* dst, int nchunks, int ntb, hipStrea
     stub::WR("fp16 weight images", dst, n * 2);
     return 0;
 }
+bool conv_wino_eligible(const ConvArgs& a, int cfg, int grid_y) {       // conv_wino.hip's rule, restated
+    if (!a.wwino || a.prec != 0 || cfg == CONV_CFG_RGB || grid_y != 1 || a.out_mode != 0) return false;
+    if (a.nsrc != 1 || a.src_c[0] != 64 || a.src_f16 || a.out_f16 || a.out16) return false;
+    if (a.wpar && (!a.wwino_par || !a.par)) return false;
+    return (long)a.H * a.W * 256 < ((long)1 << 32) - 65536;
+}
+int launch_wino_images(const float* const* src, float* const* dst, int n, const float* gamma, hipStream_t s) {
+    stub::cur = "launch_wino_images";
+    stub::note_launch(s);
+    if (n < 1 || n > 16) return PNP_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i) {
+        stub::RD("a packed 3x3 weight image", src[i], 9 * 4096 * 4);
+        stub::WR("a Winograd weight image", dst[i], (size_t)PNP_WINO_IMG_FLOATS * 4);
+    }
+    if (gamma) stub::RD("the channel gain", gamma, 64 * 4);
+    return 0;
+}
+int launch_wino_par_image(const float* src, float* dst, hipStream_t s) {
+    stub::cur = "launch_wino_par_image";
+    stub::note_launch(s);
+    stub::RD("the packed 1x1 weight images", src, 3 * 4096 * 4);
+    stub::WR("the Winograd 1x1 weight image", dst, (size_t)PNP_WINO_PAR_FLOATS * 4);
+    return 0;
+}
+int launch_conv3x3_wino(const ConvArgs&, hipStream_t) { return PNP_ERR_UNSUPPORTED; }      // only reached through launch_conv3x3
 int launch_par_tile_flags(const float* par, long plane, int* flags, int frames, int H, int W, hipStream_t s) {
     stub::cur = "launch_par_tile_flags";
     stub::note_launch(s);
@@ -415,6 +444,7 @@ struct Scenario {
     int prec, n, t, h, w, contexts, forwards, profile;
     std::vector<float> slices, qps, bqs;        // n * t each
     int mirrors;                                // 0 none, 1 PNP_OPT_F16_MIRRORS (default), 2 + PNP_OPT_F16_CHAIN_MIRRORS
+    int wino = 0;                               // PNP_OPT_WINOGRAD
 };
 
 pnp_generator_cfg default_cfg() {
@@ -454,6 +484,7 @@ int run(const Scenario& sc) {
     pnp_generator_set_precision(g, sc.prec);
     pnp_generator_set_option(g, PNP_OPT_F16_MIRRORS, sc.mirrors >= 1);
     pnp_generator_set_option(g, PNP_OPT_F16_CHAIN_MIRRORS, sc.mirrors >= 2);
+    pnp_generator_set_option(g, PNP_OPT_WINOGRAD, sc.wino);
     const int64_t flat_n = pnp_generator_flat_floats(g), packed_n = pnp_generator_packed_floats(g);
     const int64_t ctx_bytes = pnp_generator_workspace_bytes(g, sc.t, sc.h, sc.w);
     const int64_t ws_bytes = ctx_bytes * sc.contexts;
@@ -534,12 +565,13 @@ int run(const Scenario& sc) {
     json_ints("warp_context", warp_ctx);
     json_ints("warp_f16", warp_f16);
     // expert mixtures: one per distinct routing value and context-sample; which one each partition-branch conv used
-    std::vector<int> mix_slot, block_frame, block_mix, conv_f16, conv_nsrc, conv_mask;
+    std::vector<int> mix_slot, block_frame, block_mix, conv_f16, conv_nsrc, conv_mask, conv_wino;
     const Workspace W0 = carve(g, ws, sc.t, sc.h, sc.w);
     for (const MixRec& m : mixes) mix_slot.push_back((int)(((const float*)m.dst - W0.mixw) % ((int64_t)ctx_bytes / 4) / ((int64_t)g->ndyn * IMG_WIDE)));
     for (const ConvRec& c : convs) {
         conv_f16.push_back(c.path);
         conv_nsrc.push_back(c.a.nsrc);
+        conv_wino.push_back((c.path == 0 && conv_wino_eligible(c.a, c.cfg, c.gy)) ? 1 : 0);
         conv_mask.push_back(c.a.src_f16 | (c.a.out_f16 ? 16 : 0) | (c.a.out16 ? 32 : 0));
         if (!(c.a.wpar || c.a.wpar_h)) continue;
         const size_t pl = (c.a.par - par) / (3 * hw);
@@ -564,6 +596,7 @@ int run(const Scenario& sc) {
     json_ints("par_conv_mixture", block_mix);
     json_ints("conv_f16_path", conv_f16);
     json_ints("conv_nsrc", conv_nsrc);
+    json_ints("conv_wino", conv_wino);
     json_ints("conv_map_mask", conv_mask);
     json_ints("launch_stream", launch_streams);
     std::vector<int> wait_stream, wait_on;
@@ -667,6 +700,19 @@ int main(int argc, char** argv) {
         add(p + "qp_routed_t6", qprouted, prec, 1, 6, 64, 64, 1, {"IBBBP"}, {25});
         add(p + "p720_t2", d, prec, 1, 2, 720, 1280, 1, {"IBBBP"}, {25});
     }
+    // PNP_OPT_WINOGRAD: 2 = every frame size, 1 = frames with >= 512 16x16 tiles only
+    add("f32_wino2_ibbbp_t7", d, 0, 1, 7, 64, 96, 1, {"IBBBP"}, {25});
+    all.back().wino = 2;
+    add("f32_wino2_channel_last_two_layer_t3", chlast, 0, 1, 3, 64, 64, 1, {"IBBBP"}, {25});
+    all.back().wino = 2;
+    add("f32_wino2_vsr_t2", vsr, 0, 1, 2, 64, 80, 1, {"IBBBP"}, {25});
+    all.back().wino = 2;
+    add("f32_wino1_p720_t2", d, 0, 1, 2, 720, 1280, 1, {"IBBBP"}, {25});
+    all.back().wino = 1;
+    add("f32_wino1_ibbbp_t7", d, 0, 1, 7, 64, 96, 1, {"IBBBP"}, {25});
+    all.back().wino = 1;
+    add("f16_wino2_ibbbp_t7", d, 1, 1, 7, 64, 96, 1, {"IBBBP"}, {25});
+    all.back().wino = 2;
     add("f16_nomirrors_ibbbp_t7", d, 1, 1, 7, 64, 96, 1, {"IBBBP"}, {25}, 1, 0, 0);
     add("f16_chainmirrors_ibbbp_t7", d, 1, 1, 7, 64, 96, 1, {"IBBBP"}, {25}, 1, 0, 2);
     add("f16_chainmirrors_channel_last_two_layer_t3", chlast, 1, 1, 3, 64, 64, 1, {"IBBBP"}, {25}, 1, 0, 2);

@@ -30,7 +30,7 @@ def maxdiff(a, b):
 
 def test_native_library_is_loaded():
     from pnp_vcve_amd import _native
-    assert _native.lib().pnp_abi_version() == 4
+    assert _native.lib().pnp_abi_version() == 5
 
 
 @pytest.mark.parametrize('case', gu.WARP_CASES, ids=[c['name'] for c in gu.WARP_CASES])

@@ -61,13 +61,13 @@ def test_scheduler_is_clean_under_asan_and_ubsan(stub_run):
     exe, r, docs, env = stub_run
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr and 'LeakSanitizer' not in r.stderr, r.stderr[-4000:]
-    assert len(docs) == 3 * len(EXPECT) + 4
+    assert len(docs) == 3 * len(EXPECT) + 4 + 6
     for name, d in docs.items():
         assert d['pack_rc'] == 0 and d['forward_rc'] == 0 and d['errors'] == [], (name, d['errors'])
         # no event or stream outlives its generator; the workspace handed over is exactly contexts x the advertised size
         assert d['live_events_after_destroy'] == 0 and d['live_streams_after_destroy'] == 0, name
         base = name.split('_', 1)[1]
-        for pre in ('nomirrors_', 'chainmirrors_'):
+        for pre in ('nomirrors_', 'chainmirrors_', 'wino1_', 'wino2_'):
             base = base[len(pre):] if base.startswith(pre) else base
         assert d['workspace_bytes'] == EXPECT[base][2] * d['context_bytes'] and d['context_bytes'] % 256 == 0
 
@@ -173,6 +173,29 @@ def test_fp16_mirrors_are_scheduled_consistently(stub_run):
         assert docs[nm]['errors'] == [] and docs[nm]['forward_rc'] == 0
     assert set(docs['f32_ibbbp_t7']['conv_map_mask']) == {0} and set(docs['f32_ibbbp_t7']['conv_f16_path']) == {0}
     assert set(docs['f16_basic_t3']['warp_f16']) == {0}                              # DCN aligners keep the r02 schedule
+
+
+def test_winograd_option_routes_the_single_source_64_channel_convs(stub_run):
+    """PNP_OPT_WINOGRAD (fp32 only): both halves of every BAE block and conv_hr carry a Winograd image and take conv_wino.hip; input
+    convs and the RGB / pixel-shuffle heads never do; option 1 applies from 512 16x16 tiles on, option 2 everywhere; the stub's
+    range bookkeeping (errors == []) proved that every image -- the per-frame ones of the expert-mixed convs included -- was written
+    before it was read, in the workspace the scheduler advertised."""
+    _, _, docs, _ = stub_run
+    d, ref = docs['f32_wino2_ibbbp_t7'], docs['f32_ibbbp_t7']
+    assert d['errors'] == [] and d['conv_nsrc'] == ref['conv_nsrc'] and set(ref['conv_wino']) == {0}
+    # t = 7, 8 blocks: 2 sweeps x 7 frames x 16 block halves + 7 conv_hr
+    assert sum(d['conv_wino']) == 2 * 7 * 16 + 7
+    assert all(w == 0 for w, ns in zip(d['conv_wino'], d['conv_nsrc']) if ns > 1)
+    # one launch per branch and frame makes the 8 images of the expert-mixed convs: 14 more launches than the direct schedule
+    assert d['launches_first_forward'] == ref['launches_first_forward'] + 14
+    assert set(docs['f32_wino1_ibbbp_t7']['conv_wino']) == {0}                   # 24 tiles: below the threshold
+    p = docs['f32_wino1_p720_t2']
+    assert p['errors'] == [] and sum(p['conv_wino']) == 2 * 2 * 16 + 2
+    assert set(docs['f16_wino2_ibbbp_t7']['conv_wino']) == {0}                   # the option is an fp32-path switch
+    c = docs['f32_wino2_channel_last_two_layer_t3']                             # both convs of a block expert-mixed, branches + residual in one launch
+    assert c['errors'] == [] and sum(c['conv_wino']) == 2 * 3 * 16 + 3
+    v = docs['f32_wino2_vsr_t2']                                                  # x4 head: conv_hr at 4h x 4w takes it, the pixel-shuffle convs do not
+    assert v['errors'] == [] and sum(v['conv_wino']) == 2 * 2 * 16 + 2
 
 
 def test_split_fp16_schedule_uses_the_split_kernel_where_it_applies(stub_run):

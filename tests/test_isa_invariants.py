@@ -61,3 +61,20 @@ def test_f16x3_counted_chunk_barrier_still_covers_the_ring_write(tmp_path):
     slack = _counted_barrier_slack('conv_f16x3.hip', tmp_path, r'_Z\w*conv3x3_f16x3_kernel\w*:', 17)      # one site per chunk but the last
     assert len(slack) >= 8                                     # {PAR, plain, MS} x {8x16, 4x16} x {trace}
     assert all(min(v) == 0 for v in slack.values())
+
+
+def test_winograd_kernel_is_built_without_packed_fp32_valu_ops(tmp_path):
+    """csrc/conv_wino.hip with v_pk_{add,mul}_f32 in its code object gave wrong values in fixed (lane, register) slots that moved with
+    unrelated code motion (profiles/r05_wino_packed_f32_hazard.txt) -- the third appearance of that signature (DCN r03, split-fp16
+    r04).  The file is compiled with the packed-fp32 target feature off; this fails if the flag is dropped or stops working."""
+    assert '-packed-fp32-ops' in build_native.EXTRA_FLAGS['conv_wino.hip']
+    asm = tmp_path / 'conv_wino.s'
+    flags = build_native.FLAGS + build_native.EXTRA_FLAGS['conv_wino.hip']
+    subprocess.check_call([HIPCC] + [f for f in flags if f != '-Wall'] + ['-S', '--cuda-device-only', '-o', str(asm),
+                          os.path.join(ROOT, 'pnp_vcve_amd', 'csrc', 'conv_wino.hip')], stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    kernels = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_kernel' in fn.split('\n')[0]]
+    assert len(kernels) == 4
+    for fn in kernels:
+        assert fn.count('v_mfma_f32_16x16x4_f32') >= 1024                           # the K loop is there ...
+        assert not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn), fn.split('\n')[0]    # ... and no packed fp32 arithmetic beside it

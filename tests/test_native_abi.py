@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert debug == set(_native.DEBUG_SIGNATURES), debug ^ set(_native.DEBUG_SIGNATURES)
     for name in declared | debug:
         assert hasattr(lib, name), name
-    assert lib.pnp_abi_version() == 4
+    assert lib.pnp_abi_version() == 5
 
 
 def test_no_undeclared_pnp_symbol_is_exported(lib):
@@ -133,7 +133,13 @@ def test_c_abi_error_codes_without_a_gpu(lib):
     for opt in range(9):                                                 # per-handle switches, default on (the chain mirrors off)
         assert lib.pnp_generator_get_option(h, opt) == (0 if opt == 7 else 1)
     assert lib.pnp_generator_set_option(h, 3, 0) == 0 and lib.pnp_generator_get_option(h, 3) == 0
-    assert lib.pnp_generator_set_option(h, 9, 0) == 1001 and lib.pnp_generator_get_option(h, 9) == -1
+    # r05 (ABI 5): PNP_OPT_WINOGRAD, default off, three-valued (off / large frames / every frame size)
+    assert lib.pnp_generator_get_option(h, 9) == 0
+    assert lib.pnp_generator_set_option(h, 9, 2) == 0 and lib.pnp_generator_get_option(h, 9) == 2
+    assert lib.pnp_generator_set_option(h, 9, 7) == 0 and lib.pnp_generator_get_option(h, 9) == 2          # clamped
+    assert lib.pnp_generator_set_option(h, 9, 1) == 0 and lib.pnp_generator_get_option(h, 9) == 1
+    assert lib.pnp_generator_set_option(h, 10, 0) == 1001 and lib.pnp_generator_get_option(h, 10) == -1
+    assert lib.pnp_wino_image_floats() == 65536 and lib.pnp_wino_par_image_floats() == 12288
     assert n32 % 4096 == 0 and ctx % 256 == 0
     lib.pnp_generator_destroy(h)
 
