@@ -25,6 +25,12 @@ int pnp_conv3x3_f32_ex(int nsrc, const float* const* srcs_dev, const int* src_ch
                        int act, float* out_dev, int h, int w, int variant, const int* par_flags_dev,
                        void* trace_dev, void* stream);
 
+/* pnp_conv3x3_wino_f32 of pnpvcve.h with a timeline buffer (16 u64 per block: [0] start tick, [1] K-loop ticks, [2] epilogue ticks,
+ * [3] end tick, [7] tiles walked, [13] / [14] the 100 MHz counter at start / end; NULL = none). */
+int pnp_conv3x3_wino_f32_ex(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
+                            const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
+                            const float* residual_dev, int act, float* out_dev, int h, int w, void* trace_dev, void* stream);
+
 /* The fp16-operand conv of pnpvcve.h with an optional timeline buffer (16 u64 per 4-wave group). */
 int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs_dev, const int* src_channels,
                        const void* const* packed_w_f16_dev, const float* bias_dev, const float* gamma_dev,

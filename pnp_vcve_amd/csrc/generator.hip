@@ -1260,6 +1260,12 @@ int pnp_wino_par_image_from_packed_f32(const float* packed_w1x1, float* dst, voi
 int pnp_conv3x3_wino_f32(const float* src, const float* wino_w, const float* bias, const float* gamma, const float* wino_w1x1,
                          const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
                          void* st) {
+    return pnp_conv3x3_wino_f32_ex(src, wino_w, bias, gamma, wino_w1x1, par, par_flags, residual, act, out, h, w, nullptr, st);
+}
+
+int pnp_conv3x3_wino_f32_ex(const float* src, const float* wino_w, const float* bias, const float* gamma, const float* wino_w1x1,
+                            const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
+                            void* trace, void* st) {
     if (!src || !wino_w || !out || act < 0 || act > 2 || (wino_w1x1 && !par)) return PNP_ERR_BAD_ARG;
     if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;
     ConvArgs a;
@@ -1280,6 +1286,7 @@ int pnp_conv3x3_wino_f32(const float* src, const float* wino_w, const float* bia
     a.H = h;
     a.W = w;
     a.act = act;
+    a.dbg = (unsigned long long*)trace;
     if (!conv_wino_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_wino(a, (hipStream_t)st);
 }

@@ -352,7 +352,7 @@ def wino_par_image(packed_w1x1):
 
 
 @_on_device_of_first_tensor
-def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par_flags=None, residual=None, act=0):
+def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par_flags=None, residual=None, act=0, trace=None):
     """act(gamma * (conv3x3(x; W) + bias) + sum_j par_j * conv1x1_j(x)) + residual on conv_wino.hip; x (h,w,64) NHWC fp32,
     wino_w = wino_image(packed W, gamma) -- the SAME gamma -- and wino_w1x1 = wino_par_image(packed 1x1 images)."""
     x = _chk(x, 'x')
@@ -363,11 +363,12 @@ def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par
     opt = lambda t, n: _ptr(_chk(t, n)) if t is not None else None   # noqa: E731
     if par_flags is not None and (par_flags.dtype != torch.int32 or not par_flags.is_cuda):
         raise ValueError('par_flags must be a CUDA int32 tensor')
-    _native.check(_native.lib().pnp_conv3x3_wino_f32(_ptr(x), _ptr(_chk(wino_w, 'wino_w')), opt(bias, 'bias'), opt(gamma, 'gamma'),
-                                                     opt(wino_w1x1, 'wino_w1x1'), opt(par, 'par'),
-                                                     ctypes.c_void_p(par_flags.data_ptr()) if par_flags is not None else None,
-                                                     opt(residual, 'residual'), int(act), _ptr(out), h, w, _stream()),
-                  'pnp_conv3x3_wino_f32')
+    args = (_ptr(x), _ptr(_chk(wino_w, 'wino_w')), opt(bias, 'bias'), opt(gamma, 'gamma'), opt(wino_w1x1, 'wino_w1x1'), opt(par, 'par'),
+            ctypes.c_void_p(par_flags.data_ptr()) if par_flags is not None else None, opt(residual, 'residual'), int(act), _ptr(out), h, w)
+    if trace is None:
+        _native.check(_native.lib().pnp_conv3x3_wino_f32(*args, _stream()), 'pnp_conv3x3_wino_f32')
+    else:       # include/pnpvcve_debug.h: 16 uint64 per block
+        _native.check(_native.lib().pnp_conv3x3_wino_f32_ex(*args, ctypes.c_void_p(trace.data_ptr()), _stream()), 'pnp_conv3x3_wino_f32_ex')
     return out
 
 
