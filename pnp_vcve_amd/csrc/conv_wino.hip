@@ -12,8 +12,8 @@
 // Structure (measured first as a micro-benchmark, profiles/r05_ub_winograd_*.txt):
 //   * block = 4 waves, ONE block per CU: all 256 accumulator registers of a lane hold 16 transform positions x 4 N tiles of
 //     v_mfma_f32_16x16x4_f32 (M = 16 Winograd tiles, N = 16 channels).  Block tile = 16x16 output pixels = 8x8 Winograd tiles;
-//     wave w owns tile rows 2w, 2w+1 and ALL 64 output channels, so the input transform is computed once per (tile, channel) and
-//     the output transform needs no exchange between waves.  Lane (m = lane & 15, kq = lane >> 4) = tile m, k-quarter kq.
+//     wave w owns the 8x8-pixel quadrant (4x4 tiles) w of it and ALL 64 output channels, so the input transform is computed once per
+//     (tile, channel) and the output transform needs no exchange between waves.  Lane (m = lane & 15, kq = lane >> 4) = tile m, k-quarter kq.
 //   * K outermost: 4 steps of 16 input channels (lane: channels 16 s + 4 kq + j, j = the four MFMA k-steps).  Per step a lane reads
 //     its 4x4 patch (16 ds_read_b128), forms V = B^T d B with 32 float4 adds -- rolled over the step's chunks, row i of V being
 //     rewritten for step s+1 right after chunk i of step s has consumed it -- and issues 16 positions x 4 N tiles x 4 = 256 MFMAs.
@@ -28,7 +28,8 @@
 //     8-way bank conflicts on the patch reads).
 //   * partition branches (front half): the three per-pixel-weighted 1x1 convs accumulate straight into the transform domain -- a value
 //     added to position (0,0) / -(0,3) / -(3,0) / (3,3) reaches exactly output pixel (0,0) / (0,1) / (1,0) / (1,1) through A^T . A --
-//     as a fifth chunk per step whose A operand is par_j(pixel) * x(centre pixel); branches whose plane is zero on the tile are skipped.
+//     as a fifth chunk per step whose A operand is par_j(pixel) * x(centre pixel).  A wave's quadrant is one 8x8 codec block, so on a one-hot
+//     map each wave runs ONE branch: which, it decides itself from the values it loaded (a zero plane adds exact zeros).
 //   * epilogue: Y = A^T M A in registers, + bias (* gamma), activation; one N tile at a time through 4 KiB of LDS per wave (the ring
 //     slot the tile's last chunk has just left) so that residual loads and stores move 16 B per lane (64-B channel runs per pixel).
 #include "conv_mfma.h"
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 
     const unsigned t16 = (unsigned)t * 16u;
     // patch base of this lane's tile (even-columns-first pixel order inside a halo row): tile (ty, tx) -> pixel row 2 ty, column pair tx
-    const int ty = 2 * wave + (m >> 3), tx = m & 7;
+    // wave w owns the 8x8-pixel quadrant (w >> 1, w & 1) of the block tile = 4x4 Winograd tiles: one codec partition block, so a one-hot
+    // partition map needs ONE of the three branches per wave (decided per wave, below)
+    const int ty = 4 * (wave >> 1) + (m >> 2), tx = 4 * (wave & 1) + (m & 3);
     const unsigned dbase0 = RING_B + ((2 * ty) * HP + tx) * 64 + kq * 16, dbase1 = dbase0 + 2 * SLAB_B;
     auto lds4 = [&](unsigned byte) -> f32x4 { return *reinterpret_cast<const f32x4*>(smem + byte); };
     // d[r][c] of slab S: column c of the patch is halo column 2 tx + c = pair tx + (c >> 1) of parity c & 1
@@ -160,9 +163,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             hoff[i] = inb ? (unsigned)(ry * W + rx) * 256u + (unsigned)quad * 16u : OOBW;
         }
     };
+    int need_next = 0;
     auto load_pv = [&](int tq_, int y0, int x0) {
         if constexpr (PAR) {
-            const int mq = tq_ & 15, py = y0 + 2 * (2 * (tq_ >> 6) + (mq >> 3)), px = x0 + 2 * (mq & 7);
+            need_next = 0;
+            const int mq = tq_ & 15, wq_ = tq_ >> 6;
+            const int py = y0 + 2 * (4 * (wq_ >> 1) + (mq >> 2)), px = x0 + 2 * (4 * (wq_ & 1) + (mq & 3));
             unsigned po[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -174,6 +180,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = bload1(r_par, po[q], (unsigned)(j * a.par_plane * 4));
+                // which branches this WAVE needs: a plane that is zero on all of its 8x8 pixels contributes exact zeros
+                const bool nz = v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f;
+                if (__builtin_amdgcn_ballot_w64(nz) != 0) need_next |= 1 << j;
                 v[1] = -v[1];                                     // positions (0,3) and (3,0) enter the output transform negated
                 v[2] = -v[2];
                 *reinterpret_cast<f32x4*>(smem + PV_B + tq_ * 48 + j * 16) = v;
@@ -186,27 +195,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     {
         halo_offsets(t, ty0, tx0);
         const unsigned so = (unsigned)(ty0 * W + tx0) * 256u;
+        // every request first (24 halo + 12 weight float4 per thread: the registers are free here), then the LDS writes: one
+        // memory latency for the whole prologue instead of seven in a row
+        f32x4 hh[4][6], rg[3][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f32x4 h[6];
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) h[i] = bload4(r_src, hoff[i], so + s * 64);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                int e = t + 256 * i;
-                e = e < NPX * 4 ? e : NPX * 4 - 1;
-                *reinterpret_cast<f32x4*>(smem + RING_B + s * SLAB_B + e * 16) = h[i];
-            }
-        }
+            for (int i = 0; i < 6; ++i) hh[s][i] = bload4(r_src, hoff[i], so + s * 64);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const bool brc = PAR && (c % 5 == 0);
 #pragma unroll
-            for (int i = 0; i < (brc ? 3 : 4); ++i) {
-                const f32x4 v = brc ? bload4(r_up, t16, (c / 5) * 12288 + i * 4096)
-                                    : bload4(r_u, t16, (PAR ? (c / 5) * 4 + (c % 5) - 1 : c) * 16384 + i * 4096);
-                *reinterpret_cast<f32x4*>(smem + (c & 3) * 16384 + i * 4096 + t16) = v;
+            for (int i = 0; i < (brc ? 3 : 4); ++i)
+                rg[c][i] = brc ? bload4(r_up, t16, (c / 5) * 12288 + i * 4096)
+                               : bload4(r_u, t16, (PAR ? (c / 5) * 4 + (c % 5) - 1 : c) * 16384 + i * 4096);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int e = t + 256 * i;
+                e = e < NPX * 4 ? e : NPX * 4 - 1;
+                *reinterpret_cast<f32x4*>(smem + RING_B + s * SLAB_B + e * 16) = hh[s][i];
             }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool brc = PAR && (c % 5 == 0);
+#pragma unroll
+            for (int i = 0; i < (brc ? 3 : 4); ++i) *reinterpret_cast<f32x4*>(smem + (c & 3) * 16384 + i * 4096 + t16) = rg[c][i];
         }
         load_pv(t, ty0, tx0);
         __syncthreads();
@@ -229,8 +245,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     }
 
     float warm0 = 0.f, warm1 = 0.f;
-    unsigned long long dbg_t0 = 0;
-    if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dbg_t0 = 0, dbg_r0 = 0, dbg_k = 0, dbg_e = 0;
+    if (a.dbg) {
+        dbg_t0 = __builtin_amdgcn_s_memtime();
+        dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     int dbg_n = 0;
     int tq = t;
     for (;;) {
@@ -243,12 +262,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         const unsigned tq16 = (unsigned)tq * 16u;
         int need = 7;
         if constexpr (PAR) {
-            if (a.par_flags) {
-                const int ftx = (W + 15) >> 4, f0 = (ty0 >> 3) * ftx + (tx0 >> 4);
-                need = a.par_flags[f0] & 7;
-                if (ty0 + 8 < H) need |= a.par_flags[f0 + ftx] & 7;
-            }
-            need = __builtin_amdgcn_readfirstlane(need);
+            // par_flags != nullptr only ENABLES branch skipping here (the caller's PNP_OPT_PAR_SKIP switch): the decision is per wave,
+            // taken from the values themselves when they were loaded (load_pv), not per 8x16 tile
+            if (a.par_flags) need = __builtin_amdgcn_readfirstlane(need_next);
             // the four accumulators the branches add into start from zero (the others from an inline-constant zero C operand)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[0][n] = acc[3][n] = acc[12][n] = acc[15][n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -312,11 +328,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 // ---- rolling input transform for step S + 1 (chunk 0 finishes row 3 of step S first)
                 using SN = I<(S + 1) & 3>;
                 if (RES && S == 3 && PG == 0 && !(ty0 + 16 > H || tx0 + 16 > W)) {
-                    // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (4 rows x
-                    // 16 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
-                    const unsigned wo = (unsigned)((4 * (tq >> 6) + ((tq >> 5) & 1)) * W) * 256u + (unsigned)(tq & 31) * 128u;
+                    // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (8 rows x
+                    // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
+                    const unsigned wo = (unsigned)((8 * (tq >> 7) + ((tq >> 4) & 3)) * W + 8 * ((tq >> 6) & 1)) * 256u + (unsigned)(tq & 15) * 128u;
                     warm0 = bload1(r_res, wo, (unsigned)(ty0 * W + tx0) * 256u);
-                    warm1 = bload1(r_res, wo + (unsigned)W * 512u, (unsigned)(ty0 * W + tx0) * 256u);
+                    warm1 = bload1(r_res, wo + (unsigned)W * 1024u, (unsigned)(ty0 * W + tx0) * 256u);
                 }
                 if (PG == 0) {
                     row_tf(3);
@@ -385,10 +401,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 chunk(I<4 * S + 3>{}, s_c, I<3>{}, I<0>{});
             }
         };
+        unsigned long long dbg_a = 0, dbg_b = 0;
+        if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
         step(I<0>{});
         step(I<1>{});
         step(I<2>{});
         step(I<3>{});
+        if (a.dbg) {
+            dbg_b = __builtin_amdgcn_s_memtime();
+            dbg_k += dbg_b - dbg_a;
+        }
 
         // ---- epilogue: Y = A^T M A per (tile, channel) in the accumulator layout (+ bias (* gamma), activation), then one N tile at a
         //      time through LDS -- the wave's 4 x 16 pixel strip x 16 channels = 4 KiB of ring slot 3, free now: the next tile's chunks
@@ -400,15 +422,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             constexpr bool PARTIAL = decltype(partial_c)::value;
             const int lq = tq & 63, wq = tq >> 6, kqq = lq >> 4, mq = lq & 15;
             char* tr = smem + 3 * 16384 + wq * 4096;
-            // write side: value (q = 2 a + b, r) of this lane is strip pixel (row 2 (kq >> 1) + a, column 8 (kq & 1) + 2 r + b), channel m
-            const unsigned wbase = (unsigned)(((2 * (kqq >> 1)) * 16 + 8 * (kqq & 1)) * 64 + mq * 4);
-            // read side: float4 j of this lane = strip pixel (row j, column lane >> 2), channels 4 (lane & 3) .. + 3 of the N tile
+            // write side: accumulator register r of this lane is tile (row kq, column r) of the wave's 4x4 tiles; value (q = 2 a + b, r)
+            // is pixel (row 2 kq + a, column 2 r + b) of its 8x8 block, channel m
+            const unsigned wbase = (unsigned)((2 * kqq) * 8 * 64 + mq * 4);
+            // read side: float4 j of this lane = block pixel lp = 16 j + (lane >> 2) (row lp >> 3, column lp & 7), channels 4 (lane & 3) .. + 3
             const unsigned rbase = (unsigned)((lq >> 2) * 64 + (lq & 3) * 16);
             unsigned go[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                go[j] = (unsigned)((4 * wq + j) * W + (lq >> 2)) * 256u + (unsigned)(lq & 3) * 16u;
-                if (PARTIAL) go[j] = (ty0 + 4 * wq + j < H && tx0 + (lq >> 2) < W) ? go[j] : OOBW;
+                const int row = 8 * (wq >> 1) + 2 * j + (lq >> 5), col = 8 * (wq & 1) + ((lq >> 2) & 7);
+                go[j] = (unsigned)(row * W + col) * 256u + (unsigned)(lq & 3) * 16u;
+                if (PARTIAL) go[j] = (ty0 + row < H && tx0 + col < W) ? go[j] : OOBW;
             }
             f32x4 rs[4];
             if (RES) asm volatile("" ::"v"(warm0), "v"(warm1));       // (keeps the warm-up loads alive; they are long done)
@@ -433,14 +457,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 for (int q = 0; q < 4; ++q) {
                     // (the bias came in through the accumulator of position (1,1))
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(tr + wbase + ((q >> 1) * 16 + 2 * r + (q & 1)) * 64) = y[q][r];
+                    for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(tr + wbase + ((q >> 1) * 8 + 2 * r + (q & 1)) * 64) = y[q][r];
                 }
                 f32x4 o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const f32x4*>(tr + rbase + j * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = __builtin_elementwise_max(o[j], act_lo * o[j]);       // none: max(v, v) | relu: max(v, 0 v) | leaky-relu: max(v, 0.1 v)
+                    o[j] = __builtin_elementwise_max(o[j], act_lo * o[j]);       // none: max(v, 1 v) | relu: max(v, 0 v) | leaky-relu: max(v, 0.1 v)
                     if (RES) {
                         o[j] += rs[j];
                         if (n < 3) rs[j] = bload4(r_res, go[j], so + (n + 1) * 64);       // requested one N tile ahead
@@ -452,6 +476,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         if (partial) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         ++dbg_n;
+        if (a.dbg) dbg_e += __builtin_amdgcn_s_memtime() - dbg_b;
         if (!has_next) break;
         tile = ntile;
         ty0 = nty0;
@@ -460,8 +485,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     if (a.dbg && t == 0) {
         unsigned long long* d = a.dbg + (size_t)blockIdx.x * 16;
         d[0] = dbg_t0;
+        d[1] = dbg_k;
+        d[2] = dbg_e;
         d[3] = __builtin_amdgcn_s_memtime();
         d[7] = dbg_n;
+        d[13] = dbg_r0;
+        d[14] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
