@@ -132,12 +132,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const float act_lo = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
     // bias * gamma and the partition values live in LDS, not in registers: the K loop runs at the 256-VGPR limit, and a value
     // spilled to scratch comes back behind an s_waitcnt vmcnt(0) that also waits for every weight / halo request in flight
-    if (t < 64) *reinterpret_cast<float*>(smem + BG_B + t * 4) = (a.bias ? a.bias[t] : 0.f) * (a.gamma ? a.gamma[t] : 1.f);
+    // (channel t = 16 n + m at float index 4 m + n: lane m reads its four N tiles' values as one float4)
+    if (t < 64) *reinterpret_cast<float*>(smem + BG_B + ((t & 15) * 4 + (t >> 4)) * 4) = (a.bias ? a.bias[t] : 0.f) * (a.gamma ? a.gamma[t] : 1.f);
     // (accumulator register r of N tile nt is tile 4 kq + r -- C/D layout of the 16x16 MFMA -- channel 16 nt + m;
     //  tile (ty', tx') = (2 wave + (kq >> 1), 4 (kq & 1) + r), pixel (a, b) of it: see the epilogue)
 
     f32x4 acc[16][4];
-    f32x4 V[16], d0[4], d1[4], d2[4], d3[4], bf[4], breg[4], hreg[3];
+    f32x4 V[16], d0[4], d1[4], d2[4], d3[4], bf[2][4], breg[4], hreg[3], tt[4];
     unsigned hoff[6];
 
     auto row_tf = [&](int i) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const unsigned bl = (unsigned)lane * 16u;
     if constexpr (!PAR) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bf[n] = lds4(bl + n * 1024);
+        for (int n = 0; n < 4; ++n) bf[0][n] = lds4(bl + n * 1024);
     }
 
     float warm0 = 0.f, warm1 = 0.f;
@@ -279,112 +280,113 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             constexpr bool NBR = PAR && (NC % 5 == 0);
             constexpr int NSTEP = PAR ? NC / 5 : NC / 4, NPG = PAR ? NC % 5 - 1 : NC % 4;
             lds_bar();
+            if (KIND == 1) {
 #pragma unroll
-            for (int i = 0; i < (NBR ? 3 : 4); ++i)
-                breg[i] = NBR ? bload4(r_up, tq16, NSTEP * 12288 + i * 4096) : bload4(r_u, tq16, (NSTEP * 4 + NPG) * 16384 + i * 4096);
-            // next tile's slab S in two halves: requested in position chunks 0 / 1 of step S, written one chunk later
-            if (KIND == 0 && (PG == 1 || PG == 2)) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    int e = tq + 256 * (i + 3 * (PG - 1));
-                    e = e < NPX * 4 ? e : NPX * 4 - 1;
-                    *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[i];
-                }
+                for (int i = 0; i < (NBR ? 3 : 4); ++i)
+                    breg[i] = NBR ? bload4(r_up, tq16, NSTEP * 12288 + i * 4096) : bload4(r_u, tq16, (NSTEP * 4 + NPG) * 16384 + i * 4096);
             }
-            if (KIND == 0 && (PG == 0 || PG == 1)) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) hreg[i] = bload4(r_src, hoff[i + 3 * PG], nso + S * 64);
-            }
+            // (the next tile's slab S travels in two halves: requested in position chunks 0 / 1 of step S, written one chunk later)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (KIND == 1) {
                 // ---- partition branches of step S: A = par_j(pixel) * x(pixel), x = the patch centre (d rows 1, 2 x columns 1, 2 of step S)
                 // first the fragments of the following position chunk (visible since the previous barrier)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) bf[n] = lds4(((C + 1) & 3) * 16384 + bl + n * 1024);
+                for (int n = 0; n < 4; ++n) bf[0][n] = lds4(((C + 1) & 3) * 16384 + bl + n * 1024);
                 auto branch = [&](auto j_c) {
                     constexpr int J = decltype(j_c)::value;
-                    f32x4 bb[4], ax[4];
+                    // (the branch's B fragments go where position 3 of the chunk in front kept its own: bf[1] is free, bf[0] holds
+                    //  the first fragments of the chunk behind)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) bb[n] = lds4((C & 3) * 16384 + (J * 4 + n) * 1024 + bl);
+                    for (int n = 0; n < 4; ++n) bf[1][n] = lds4((C & 3) * 16384 + (J * 4 + n) * 1024 + bl);
                     const f32x4 pv = lds4(PV_B + tq * 48 + J * 16);
-                    ax[0] = d1[1] * pv[0];
-                    ax[1] = d1[2] * pv[1];
-                    ax[2] = d2[1] * pv[2];
-                    ax[3] = d2[2] * pv[3];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 ax = (q == 0 ? d1[1] : (q == 1 ? d1[2] : (q == 2 ? d2[1] : d2[2]))) * pv[q];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
 #pragma unroll
                             for (int n = 0; n < 4; ++n) {
                                 f32x4& ac = q == 0 ? acc[0][n] : (q == 1 ? acc[3][n] : (q == 2 ? acc[12][n] : acc[15][n]));
-                                ac = mfma16(ax[q][k], bb[n][k], ac);
+                                ac = mfma16(ax[k], bf[1][n][k], ac);
                             }
+                    }
                 };
                 if (need & 1) branch(I<0>{});
                 if (need & 2) branch(I<1>{});
                 if (need & 4) branch(I<2>{});
-            } else {
-                // ---- rolling input transform for step S + 1 (chunk 0 finishes row 3 of step S first)
+            }
+            if constexpr (KIND == 0) {
+                // ---- position row PG of step S: 64 MFMAs, and between them -- ONE thing per MFMA gap, in this order, pinned with a
+                //      scheduling barrier per gap (a 16x16x4 fp32 MFMA issues in a few cycles and executes for 32; left to itself hipcc
+                //      clusters the loads, the LDS traffic and the transform in front of and behind the MFMAs) --
+                //        gaps 0-3 of every position: the B fragments of the next position (across the chunk seam too)
+                //        gaps 4-7: the weight requests;  8-10: halo pieces requested a chunk ago -> LDS;  11-13: halo requests
+                //        gaps 20-27: patch rows of step S + 1;  36-43: the rolling input transform (one float4 add each)
+                //        gaps 52-55: the weight chunk requested at the top -> ring
                 using SN = I<(S + 1) & 3>;
-                if (RES && S == 3 && PG == 0 && !(ty0 + 16 > H || tx0 + 16 > W)) {
-                    // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (8 rows x
-                    // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
-                    const unsigned wo = (unsigned)((8 * (tq >> 7) + ((tq >> 4) & 3)) * W + 8 * ((tq >> 6) & 1)) * 256u + (unsigned)(tq & 15) * 128u;
-                    warm0 = bload1(r_res, wo, (unsigned)(ty0 * W + tx0) * 256u);
-                    warm1 = bload1(r_res, wo + (unsigned)W * 1024u, (unsigned)(ty0 * W + tx0) * 256u);
-                }
-                if (PG == 0) {
-                    row_tf(3);
+                constexpr int NRING = NBR ? 3 : 4;
+                constexpr bool NEXT_IS_BR = PAR && PG == 3;      // the next chunk is a branch chunk: it reads its own fragments
+                constexpr int TR = PG == 0 ? 3 : PG - 1;         // the V row rewritten in this chunk (row 3 of step S, or row PG - 1 of S + 1)
+                f32x4 bgv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        d0[c] = patch(SN{}, 0, c);
-                        d2[c] = patch(SN{}, 2, c);
+                for (int g = 0; g < 64; ++g) {
+                    const int pj = g >> 4, k = (g >> 2) & 3, n = g & 3, p = PG * 4 + pj;
+                    // step 0, first k-step: C operand = 0 (no accumulator clearing; the four positions the branches use excepted),
+                    // or the bias at position (1,1), which A^T . A carries to all four output pixels with weight 1
+                    const bool fresh = S == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
+                    const f32x4 c0 = p == 5 ? f32x4{bgv[n], bgv[n], bgv[n], bgv[n]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[p][n] = mfma16(V[p][k], bf[pj & 1][n][k], fresh ? c0 : acc[p][n]);
+                    // ---- the gap behind it
+                    if (PAR && PG == 0 && g < 4) {
+                        // the weight chunk the branch chunk in front of this one requested: a branch chunk may hold no MFMA at all (no
+                        // partition record on the wave's pixels), so it does not wait for its requests -- they land in the ring here
+                        constexpr int NCB = (C - 1 + 3) % CPT;
+                        *reinterpret_cast<f32x4*>(smem + (NCB & 3) * 16384 + g * 4096 + tq16) = breg[g];
                     }
-                } else if (PG == 1) {
-                    row_tf(0);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) d1[c] = patch(SN{}, 1, c);
-                } else if (PG == 2) {
-                    row_tf(1);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) d3[c] = patch(SN{}, 3, c);
-                } else {
-                    row_tf(2);
-                    if (S == 3) load_pv(tq, nty0, ntx0);   // this tile's last branch chunk is behind us
-                }
-#pragma unroll
-                for (int pj = 0; pj < 4; ++pj) {
-                    constexpr bool NEXT_IS_BR = PAR && PG == 3;      // the next chunk is a branch chunk: it reads its own fragments
-                    f32x4 bfn[4];
-                    if (pj < 3 || !NEXT_IS_BR) {
+                    if ((g & 15) < 4 && !(pj == 3 && NEXT_IS_BR)) {
                         const unsigned nb = pj < 3 ? (C & 3) * 16384 + (pj + 1) * 4096 : ((C + 1) & 3) * 16384;
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) bfn[n] = lds4(nb + bl + n * 1024);
+                        bf[(pj + 1) & 1][g & 3] = lds4(nb + bl + (g & 3) * 1024);
                     }
-                    constexpr int P0 = PG * 4;
-                    const int p = P0 + pj;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            // step 0, first k-step: C operand = 0 (no accumulator clearing; the four positions the branches use excepted),
-                            // or the bias at position (1,1), which A^T . A carries to all four output pixels with weight 1
-                            const bool fresh = S == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
-                            float bgn = 0.f;
-                            if (S == 0 && k == 0 && p == 5) bgn = *reinterpret_cast<const float*>(smem + BG_B + n * 64 + (tq & 15) * 4);
-                            const f32x4 c0 = p == 5 ? f32x4{bgn, bgn, bgn, bgn} : f32x4{0.f, 0.f, 0.f, 0.f};
-                            acc[p][n] = mfma16(V[p][k], bf[n][k], fresh ? c0 : acc[p][n]);
-                        }
-                    if (pj < 3 || !NEXT_IS_BR) {
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) bf[n] = bfn[n];
+                    if (g >= 4 && g < 4 + NRING)
+                        breg[g - 4] = NBR ? bload4(r_up, tq16, NSTEP * 12288 + (g - 4) * 4096) : bload4(r_u, tq16, (NSTEP * 4 + NPG) * 16384 + (g - 4) * 4096);
+                    if (S == 0 && PG == 1 && g == 7) bgv = *reinterpret_cast<const f32x4*>(smem + BG_B + (tq & 15) * 16);
+                    if ((PG == 1 || PG == 2) && g >= 8 && g < 11) {        // (before this chunk's own halo requests reuse the registers)
+                        int e = tq + 256 * (g - 8 + 3 * (PG - 1));
+                        e = e < NPX * 4 ? e : NPX * 4 - 1;
+                        *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[g - 8];
                     }
+                    if ((PG == 0 || PG == 1) && g >= 11 && g < 14) hreg[g - 11] = bload4(r_src, hoff[g - 11 + 3 * PG], nso + S * 64);
+                    if (RES && S == 3 && PG == 0 && g == 16 && !(ty0 + 16 > H || tx0 + 16 > W)) {
+                        // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (8 rows x
+                        // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
+                        const unsigned wo = (unsigned)((8 * (tq >> 7) + ((tq >> 4) & 3)) * W + 8 * ((tq >> 6) & 1)) * 256u + (unsigned)(tq & 15) * 128u;
+                        warm0 = bload1(r_res, wo, (unsigned)(ty0 * W + tx0) * 256u);
+                        warm1 = bload1(r_res, wo + (unsigned)W * 1024u, (unsigned)(ty0 * W + tx0) * 256u);
+                    }
+                    if (g >= 20 && g < 28) {                     // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
+                        const int c = (g - 20) & 3;
+                        if (PG == 0 && g < 24) d0[c] = patch(SN{}, 0, c);
+                        if (PG == 0 && g >= 24) d2[c] = patch(SN{}, 2, c);
+                        if (PG == 1 && g < 24) d1[c] = patch(SN{}, 1, c);
+                        if (PG == 2 && g < 24) d3[c] = patch(SN{}, 3, c);
+                    }
+                    if (g >= 36 && g < 40) {                     // rolling transform, row TR: first the row combination ...
+                        const int c = g - 36;
+                        tt[c] = TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
+                    }
+                    if (g >= 40 && g < 44) {                     // ... then the column combination
+                        const int c = g - 40;
+                        V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
+                    }
+                    if (PAR && S == 3 && PG == 3 && g == 44) load_pv(tq, nty0, ntx0);      // this tile's last branch chunk is behind us
+                    if (g >= 52 && g < 52 + NRING) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < (NBR ? 3 : 4); ++i) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + i * 4096 + tq16) = breg[i];
+            if constexpr (KIND == 1) {
+                static_assert(!NBR, "a branch chunk requests a position chunk (four pieces), written by the position chunk behind it");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         auto step = [&](auto s_c) {
             constexpr int S = decltype(s_c)::value;

@@ -37,6 +37,8 @@ def main():
         'back': lambda tr: ops.conv3x3_wino(x, u, bias=b, residual=res, trace=tr),
         'front': lambda tr: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, par_flags=flags, act=1, trace=tr),
         'front_dense': lambda tr: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, act=1, trace=tr),
+        # no partition record anywhere (an I frame): the branch chunks hold no MFMA -- what the PAR structure costs by itself
+        'front_zero': lambda tr: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par * 0, par_flags=flags, act=1, trace=tr),
     }
     for name, fn in kinds.items():
         if args.kind not in ('all', name):
