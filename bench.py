@@ -152,7 +152,8 @@ def strict(obj, digits=6):
 
 # what the single stdout line keeps of a roofline object (the full objects, with their prose, go to bench_secondary.json)
 ROOFLINE_KEEP = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_us', 'frac_wall',
-                 'algorithmic_frac', 'frac_dense_par', 'hbm_frac', 'algorithmic_bytes_per_launch', 'traffic_source')
+                 'algorithmic_frac', 'algorithmic_TFLOPs', 'winograd', 'frac_dense_par', 'hbm_frac', 'algorithmic_bytes_per_launch',
+                 'traffic_source')
 
 
 def bounded_line(res):
@@ -335,16 +336,35 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         executed = ach * (1 - skipped_frac)
         kern = ('conv3x3_persist_kernel<PAR> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, persistent strips)'
                 if big else 'conv3x3_mfma_kernel<2,2,1,2> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, 4x16 tiles)')
+        wopt = m.get_option(9)             # PNP_OPT_WINOGRAD
+        wino = wopt == 2 or (wopt == 1 and ((h + 15) // 16) * ((w + 15) // 16) >= 512)
+        if wino:
+            # Winograd F(2x2,3x3) (csrc/conv_wino.hip): 16 transform positions per 2x2 output pixels instead of 36 taps -> the 3x3 part
+            # executes 256/576 of the direct form's matrix FLOPs; the 1x1 branches run per 8x8-pixel quadrant (one wave), each wave
+            # only the planes that are nonzero on its pixels
+            par = a['partitions'][0]                                    # (T,3,h,w)
+            blk = torch.nn.functional.max_pool2d((par != 0).float(), 8, ceil_mode=True)     # (T,3,h/8,w/8): plane live on the block
+            run = blk.sum(1).mean().item()                              # branches run per wave quadrant (no dummy chunk)
+            branches = run
+            skipped_frac = 1 - (nb * (2 * 256 + 64 * run) + 256) / dense
+            executed = ach * (1 - skipped_frac)
+            kern = ('conv3x3_wino_kernel<PAR,RES> (the 64->64 BAE-block convs + conv_hr as Winograd F(2x2,3x3): fp32 MFMA 16x16x4, 16x16-pixel '
+                    'block tiles on 256 persistent blocks, K-outer with in-place halo refill)')
         # roofline.achieved / frac price the FLOPs the kernel EXECUTES (what the matrix pipe really did per second);
         # algorithmic_* is the reference's dense count over the same time (what a user gets per second)
         r = {'kernel': kern, 'bound': 'mfma', 'achieved': executed, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
              'frac': executed / PEAK_F32_MFMA_TFLOPS, 'algorithmic_TFLOPs': ach,
              'algorithmic_frac': ach / PEAK_F32_MFMA_TFLOPS,
-             'definition': 'achieved = executed FLOPs (dense reference count minus the 64-deep 1x1 branch chunks skipped on tiles '
-                           'whose partition plane is all zero; = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) / HIP-event launch time; '
-                           'algorithmic_* = the dense reference count 2*K*64*H*W over the same time',
+             'definition': ('achieved = matrix FLOPs the kernel EXECUTES (Winograd F(2x2,3x3): 16 position products per 2x2 pixels instead of 36 '
+                            'tap products, + the 1x1 branches each wave really runs; = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) / HIP-event launch '
+                            'time -- the matrix pipe\'s utilisation; algorithmic_* = the reference\'s direct-conv count 2*K*64*H*W over the same '
+                            'time (what a user gets per second: it may exceed the peak, the algorithm does fewer multiplies)') if wino else
+                           ('achieved = executed FLOPs (dense reference count minus the 64-deep 1x1 branch chunks skipped on tiles '
+                            'whose partition plane is all zero; = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) / HIP-event launch time; '
+                            'algorithmic_* = the dense reference count 2*K*64*H*W over the same time'),
+             'winograd': bool(wino),
              'partition_branches_needed_per_tile': branches, 'partition_branch_chunks_run_per_tile': run,
-             'traffic': _launch_weighted_traffic(pmc, 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>'),
+             'traffic': _launch_weighted_traffic(pmc, 'conv3x3_wino_kernel' if wino else 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>'),
              'traffic_source': pmc_src,
              'launches': cb['launches'], 'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
              'all_convs_TFLOPs': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
@@ -864,17 +884,31 @@ def secondary_workloads(dev, T, no_cpu_baseline=False):
         dict(name='7x3x720x1280 split-fp16 convs, 2 clips per step interleaved on two streams (as above; each context has its own tile '
                   'queue)', workload='720p', precision='f16x3', vsr=False, clips=2, steps=3, warmup=1),
     ]
+    specs += [
+        dict(name='100x3x720x1280 fp32, one clip: the reference configs\' real clip length (configs/HR_davis_LR_128x128.py:202 '
+                  'num_input_frames=100; 24.5 GB workspace, 100 live frame slots)', workload='720p', precision='fp32', vsr=False, clips=1,
+             steps=2, warmup=1, frames=100),
+        dict(name='7x3x720x1280 fp32 with PNP_OPT_WINOGRAD = 0: the direct implicit-GEMM kernels of rounds 1-4 (exact fp32 MFMA 32x32x2), '
+                  'same session as the headline', workload='720p', precision='fp32', vsr=False, clips=1, steps=3, warmup=1, winograd=0),
+    ]
     cpu128 = None if no_cpu_baseline else cpu_baseline_128(T)
     for sp in specs:
         cfg = dict(syn.DEFAULT_GENERATOR_CFG)
         cfg['vsr'] = sp['vsr']
         sd_np = syn.make_state_dict(cfg, seed=2025)
         h, w = WORKLOADS[sp['workload']]
-        r, m, a = measure(dev, sd_np, cfg, workload=sp['workload'], precision=sp['precision'], vsr=sp['vsr'],
-                          clips=sp['clips'], graphs=sp.get('graphs', False), steps=sp['steps'], warmup=sp['warmup'], T=T,
-                          crfs=sp.get('crfs'), kernel_events=sp.get('kernel_events', True))
+        global WINOGRAD
+        keep_w, Tsp = WINOGRAD, sp.get('frames', T)
+        if 'winograd' in sp:
+            WINOGRAD = sp['winograd']
+        try:
+            r, m, a = measure(dev, sd_np, cfg, workload=sp['workload'], precision=sp['precision'], vsr=sp['vsr'],
+                              clips=sp['clips'], graphs=sp.get('graphs', False), steps=sp['steps'], warmup=sp['warmup'], T=Tsp,
+                              crfs=sp.get('crfs'), kernel_events=sp.get('kernel_events', True))
+        finally:
+            WINOGRAD = keep_w
         e = {'name': sp['name'], 'workload': sp['workload'], 'precision': sp['precision'],
-             'metric': f'enhanced frames/sec ({w}x{h}, {T}-frame window)', 'value': r['value'],
+             'metric': f'enhanced frames/sec ({w}x{h}, {Tsp}-frame window)', 'value': r['value'], 'frames_per_clip': Tsp,
              'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': sp['steps'], 'warmup': sp['warmup'],
              'dtype': DTYPE_TEXT[sp['precision']],
              'clips_per_step': sp['clips'], 'vsr_x4_heads': sp['vsr'], 'hip_graphs': sp.get('graphs', False),

@@ -87,7 +87,7 @@ int pnp_generator_set_precision(pnp_generator* g, int precision);
 int pnp_generator_get_precision(const pnp_generator* g);
 
 /* Per-generator execution switches (A/B and diagnostic; results are bit-identical either way unless stated).
- * value 0/1; all default to 1 except PNP_OPT_F16_CHAIN_MIRRORS.  State lives in the handle. */
+ * value 0/1 (PNP_OPT_WINOGRAD: 0/1/2); all default to 1 except PNP_OPT_F16_CHAIN_MIRRORS.  State lives in the handle. */
 #define PNP_OPT_F16_MAPS 0       /* PNP_PREC_F16: the map between the two halves of a BAE block / behind conv_hr is stored fp16 */
 #define PNP_OPT_PAR_SKIP 1       /* skip 1x1 partition branches whose plane is all zero on a tile (exact zeros) */
 #define PNP_OPT_CONV_LAST_VALU 2 /* conv_last on the vector ALUs (<= 2e-6 from the MFMA kernel: other summation order) */
@@ -108,7 +108,7 @@ int pnp_generator_get_precision(const pnp_generator* g);
 #define PNP_OPT_WINOGRAD 9       /* PNP_PREC_F32: the single-source 64 -> 64 convs (both halves of a BAE block, conv_hr) in Winograd F(2x2,3x3) form
                                     (conv_wino.hip): 2.25x fewer matrix FLOPs, still fp32 products and sums, NOT bit-identical to the direct
                                     kernels (summation order + the +-1 input transform: ~1e-6 per conv on unit-scale maps; whole-clip
-                                    gates in tests/test_gpu_wino.py).  0 off | 1 on frames with >= 512 16x16 tiles | 2 on every frame size */
+                                    gates in tests/test_gpu_wino.py).  0 off | 1 (default) on frames with >= 512 16x16 tiles | 2 on every frame size */
 #define PNP_OPT_COUNT 10
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);

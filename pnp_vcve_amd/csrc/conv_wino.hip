@@ -164,33 +164,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             hoff[i] = inb ? (unsigned)(ry * W + rx) * 256u + (unsigned)quad * 16u : OOBW;
         }
     };
+    // partition values of the wave's pixels for the tile at (y0, x0), plane J: global -> LDS (signed), and whether the WAVE needs the
+    // branch at all.  One plane per call: the next tile's values are fetched plane by plane in the last three position chunks of a
+    // tile (all twelve at once, with their offsets, were what tipped the K loop into scratch spills)
     int need_next = 0;
-    auto load_pv = [&](int tq_, int y0, int x0) {
+    auto load_pv_plane = [&](int tq_, int y0, int x0, int J) {
         if constexpr (PAR) {
-            need_next = 0;
             const int mq = tq_ & 15, wq_ = tq_ >> 6;
             const int py = y0 + 2 * (4 * (wq_ >> 1) + (mq >> 2)), px = x0 + 2 * (4 * (wq_ & 1) + (mq & 3));
-            unsigned po[4];
+            f32x4 v;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int gy = py + (q >> 1), gx = px + (q & 1);
-                po[q] = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOBW;
+                v[q] = bload1(r_par, (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOBW, (unsigned)(J * a.par_plane * 4));
             }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = bload1(r_par, po[q], (unsigned)(j * a.par_plane * 4));
-                // which branches this WAVE needs: a plane that is zero on all of its 8x8 pixels contributes exact zeros
-                const bool nz = v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f;
-                if (__builtin_amdgcn_ballot_w64(nz) != 0) need_next |= 1 << j;
-                v[1] = -v[1];                                     // positions (0,3) and (3,0) enter the output transform negated
-                v[2] = -v[2];
-                *reinterpret_cast<f32x4*>(smem + PV_B + tq_ * 48 + j * 16) = v;
-            }
+            // which branches this WAVE needs: a plane that is zero on all of its 8x8 pixels contributes exact zeros
+            const bool nz = v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f;
+            if (J == 0) need_next = 0;
+            if (__builtin_amdgcn_ballot_w64(nz) != 0) need_next |= 1 << J;
+            v[1] = -v[1];                                     // positions (0,3) and (3,0) enter the output transform negated
+            v[2] = -v[2];
+            *reinterpret_cast<f32x4*>(smem + PV_B + tq_ * 48 + J * 16) = v;
         }
     };
-
+    auto load_pv = [&](int tq_, int y0, int x0) {
+        load_pv_plane(tq_, y0, x0, 0);
+        load_pv_plane(tq_, y0, x0, 1);
+        load_pv_plane(tq_, y0, x0, 2);
+    };
     int ty0 = (tile / tiles_x) * 16, tx0 = (tile % tiles_x) * 16;
     // ---- prologue: whole halo of the first tile, chunks 0..2, first patch
     {
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         const int c = g - 40;
                         V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
                     }
-                    if (PAR && S == 3 && PG == 3 && g == 44) load_pv(tq, nty0, ntx0);      // this tile's last branch chunk is behind us
+                    if (PAR && S == 3 && PG >= 1 && g == 44) load_pv_plane(tq, nty0, ntx0, PG - 1);     // (this tile's last branch chunk is behind us)
                     if (g >= 52 && g < 52 + NRING) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
                     __builtin_amdgcn_sched_barrier(0);
                 }

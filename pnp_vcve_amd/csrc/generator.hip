@@ -69,7 +69,7 @@ struct ProfRec {
 struct pnp_generator {
     pnp_generator_cfg cfg;
     int prec = PNP_PREC_F32;          // pnp_generator_set_precision
-    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1, 0};   // pnp_generator_set_option (defaults: everything on but the chain mirrors and Winograd)
+    int opt[PNP_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 0, 1, 1};   // pnp_generator_set_option (defaults: everything on but the chain mirrors; Winograd on large frames)
     // optional per-launch HIP-event timing (pnp_generator_profile*): off by default
     mutable bool prof_on = false;
     mutable std::vector<hipEvent_t> prof_pool;

@@ -130,11 +130,11 @@ def test_c_abi_error_codes_without_a_gpu(lib):
     assert lib.pnp_generator_set_precision(h, 1) == 0 and lib.pnp_generator_get_precision(h) == 1
     assert lib.pnp_generator_packed_floats(h) == n32 + n32 // 2          # fp16 mirror of every image
     assert lib.pnp_generator_workspace_bytes(h, 7, 128, 128) > ctx       # + mirror of the mixed experts
-    for opt in range(9):                                                 # per-handle switches, default on (the chain mirrors off)
+    for opt in range(10):                                                # per-handle switches, default on (the chain mirrors off)
         assert lib.pnp_generator_get_option(h, opt) == (0 if opt == 7 else 1)
     assert lib.pnp_generator_set_option(h, 3, 0) == 0 and lib.pnp_generator_get_option(h, 3) == 0
     # r05 (ABI 5): PNP_OPT_WINOGRAD, default off, three-valued (off / large frames / every frame size)
-    assert lib.pnp_generator_get_option(h, 9) == 0
+    assert lib.pnp_generator_get_option(h, 9) == 1
     assert lib.pnp_generator_set_option(h, 9, 2) == 0 and lib.pnp_generator_get_option(h, 9) == 2
     assert lib.pnp_generator_set_option(h, 9, 7) == 0 and lib.pnp_generator_get_option(h, 9) == 2          # clamped
     assert lib.pnp_generator_set_option(h, 9, 1) == 0 and lib.pnp_generator_get_option(h, 9) == 1
