@@ -167,30 +167,39 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     // partition values of the wave's pixels for the tile at (y0, x0), plane J: global -> LDS (signed), and whether the WAVE needs the
     // branch at all.  One plane per call: the next tile's values are fetched plane by plane in the last three position chunks of a
     // tile (all twelve at once, with their offsets, were what tipped the K loop into scratch spills)
+    // partition values of the wave's pixels for the tile at (y0, x0): global -> registers (pv_request), then -> LDS, signed, with the
+    // decision whether the WAVE needs each branch at all (pv_finish).  The next tile's values are requested at the top of the epilogue and
+    // finished behind it: inside the K loop their twelve registers tipped the branch kernels into scratch spills, and a spill reload is
+    // an s_waitcnt vmcnt(0) -- it waits for every weight / halo request in flight
     int need_next = 0;
-    auto load_pv_plane = [&](int tq_, int y0, int x0, int J) {
+    f32x4 pvr[3];
+    auto pv_request = [&](int tq_, int y0, int x0) {
         if constexpr (PAR) {
             const int mq = tq_ & 15, wq_ = tq_ >> 6;
             const int py = y0 + 2 * (4 * (wq_ >> 1) + (mq >> 2)), px = x0 + 2 * (4 * (wq_ & 1) + (mq & 3));
-            f32x4 v;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int gy = py + (q >> 1), gx = px + (q & 1);
-                v[q] = bload1(r_par, (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOBW, (unsigned)(J * a.par_plane * 4));
+                const unsigned po = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOBW;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pvr[j][q] = bload1(r_par, po, (unsigned)(j * a.par_plane * 4));
             }
-            // which branches this WAVE needs: a plane that is zero on all of its 8x8 pixels contributes exact zeros
-            const bool nz = v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f;
-            if (J == 0) need_next = 0;
-            if (__builtin_amdgcn_ballot_w64(nz) != 0) need_next |= 1 << J;
-            v[1] = -v[1];                                     // positions (0,3) and (3,0) enter the output transform negated
-            v[2] = -v[2];
-            *reinterpret_cast<f32x4*>(smem + PV_B + tq_ * 48 + J * 16) = v;
         }
     };
-    auto load_pv = [&](int tq_, int y0, int x0) {
-        load_pv_plane(tq_, y0, x0, 0);
-        load_pv_plane(tq_, y0, x0, 1);
-        load_pv_plane(tq_, y0, x0, 2);
+    auto pv_finish = [&](int tq_) {
+        if constexpr (PAR) {
+            need_next = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 v = pvr[j];
+                // which branches this WAVE needs: a plane that is zero on all of its 8x8 pixels contributes exact zeros
+                const bool nz = v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f;
+                if (__builtin_amdgcn_ballot_w64(nz) != 0) need_next |= 1 << j;
+                v[1] = -v[1];                                     // positions (0,3) and (3,0) enter the output transform negated
+                v[2] = -v[2];
+                *reinterpret_cast<f32x4*>(smem + PV_B + tq_ * 48 + j * 16) = v;
+            }
+        }
     };
     int ty0 = (tile / tiles_x) * 16, tx0 = (tile % tiles_x) * 16;
     // ---- prologue: whole halo of the first tile, chunks 0..2, first patch
@@ -226,7 +235,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 #pragma unroll
             for (int i = 0; i < (brc ? 3 : 4); ++i) *reinterpret_cast<f32x4*>(smem + (c & 3) * 16384 + i * 4096 + t16) = rg[c][i];
         }
-        load_pv(t, ty0, tx0);
+        pv_request(t, ty0, tx0);
+        pv_finish(t);
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 //      clusters the loads, the LDS traffic and the transform in front of and behind the MFMAs) --
                 //        gaps 0-3 of every position: the B fragments of the next position (across the chunk seam too)
                 //        gaps 4-7: the weight requests;  8-10: halo pieces requested a chunk ago -> LDS;  11-13: halo requests
-                //        gaps 20-27: patch rows of step S + 1;  36-43: the rolling input transform (one float4 add each)
+                //        gaps 16-23: the rolling input transform (one float4 add each);  28-35: patch rows of step S + 1
                 //        gaps 52-55: the weight chunk requested at the top -> ring
                 using SN = I<(S + 1) & 3>;
                 constexpr int NRING = NBR ? 3 : 4;
@@ -364,22 +374,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         warm0 = bload1(r_res, wo, (unsigned)(ty0 * W + tx0) * 256u);
                         warm1 = bload1(r_res, wo + (unsigned)W * 1024u, (unsigned)(ty0 * W + tx0) * 256u);
                     }
-                    if (g >= 20 && g < 28) {                     // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
-                        const int c = (g - 20) & 3;
-                        if (PG == 0 && g < 24) d0[c] = patch(SN{}, 0, c);
-                        if (PG == 0 && g >= 24) d2[c] = patch(SN{}, 2, c);
-                        if (PG == 1 && g < 24) d1[c] = patch(SN{}, 1, c);
-                        if (PG == 2 && g < 24) d3[c] = patch(SN{}, 3, c);
+                    // rolling transform of row TR + the patch rows of step S + 1.  Branch kernels: the transform BEFORE this chunk's patch reads
+                    // -- the rows it frees (chunk 0: the old rows 1 and 3) are dead by the time new ones arrive, at most three patch rows live
+                    // instead of four; its results pinned where they are computed (with branch chunks in the way -- other basic blocks --
+                    // LLVM's IR-level sinking moves the adds next to their first use, into the join block behind the next step's branches,
+                    // where nothing overlaps them: 96 VALU instructions per branch chunk in the first PAR build).  Plain kernels: the
+                    // same source order makes hipcc keep `acc` and `V` in scratch MEMORY (private_seg_size 1616, ten times slower), and
+                    // the pin costs the back half 8 %: they keep reads first, transform second, unpinned.
+                    if constexpr (PAR) {
+                        if (g >= 16 && g < 20) tt[g - 16] = TR == 0 ? d0[g - 16] - d2[g - 16] : (TR == 1 ? d1[g - 16] + d2[g - 16] : (TR == 2 ? d2[g - 16] - d1[g - 16] : d1[g - 16] - d3[g - 16]));
+                        if (g >= 20 && g < 24) {
+                            const int c = g - 20;
+                            V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
+                            asm volatile("" : "+v"(V[4 * TR + c]));
+                        }
+                        if (g >= 28 && g < 36) {                 // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
+                            const int c = (g - 28) & 3;
+                            if (PG == 0 && g < 32) d0[c] = patch(SN{}, 0, c);
+                            if (PG == 0 && g >= 32) d2[c] = patch(SN{}, 2, c);
+                            if (PG == 1 && g < 32) d1[c] = patch(SN{}, 1, c);
+                            if (PG == 2 && g < 32) d3[c] = patch(SN{}, 3, c);
+                        }
+                    } else {
+                        if (g >= 20 && g < 28) {                 // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
+                            const int c = (g - 20) & 3;
+                            if (PG == 0 && g < 24) d0[c] = patch(SN{}, 0, c);
+                            if (PG == 0 && g >= 24) d2[c] = patch(SN{}, 2, c);
+                            if (PG == 1 && g < 24) d1[c] = patch(SN{}, 1, c);
+                            if (PG == 2 && g < 24) d3[c] = patch(SN{}, 3, c);
+                        }
+                        if (g >= 36 && g < 40) {                 // first the row combination ...
+                            const int c = g - 36;
+                            tt[c] = TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
+                        }
+                        if (g >= 40 && g < 44) {                 // ... then the column combination
+                            const int c = g - 40;
+                            V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
+                        }
                     }
-                    if (g >= 36 && g < 40) {                     // rolling transform, row TR: first the row combination ...
-                        const int c = g - 36;
-                        tt[c] = TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
-                    }
-                    if (g >= 40 && g < 44) {                     // ... then the column combination
-                        const int c = g - 40;
-                        V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
-                    }
-                    if (PAR && S == 3 && PG >= 1 && g == 44) load_pv_plane(tq, nty0, ntx0, PG - 1);     // (this tile's last branch chunk is behind us)
                     if (g >= 52 && g < 52 + NRING) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -421,6 +453,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         const unsigned so = (unsigned)(ty0 * W + tx0) * 256u;
         const bool partial = ty0 + 16 > H || tx0 + 16 > W;
         lds_bar();                       // every wave has read its last fragments out of slot 3
+        pv_request(tq, nty0, ntx0);
         auto epilogue = [&](auto partial_c) {
             constexpr bool PARTIAL = decltype(partial_c)::value;
             const int lq = tq & 63, wq = tq >> 6, kqq = lq >> 4, mq = lq & 15;
@@ -478,6 +511,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         };
         if (partial) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+        pv_finish(tq);
         ++dbg_n;
         if (a.dbg) dbg_e += __builtin_amdgcn_s_memtime() - dbg_b;
         if (!has_next) break;

@@ -53,7 +53,7 @@ def main():
         life = (d[:, 3] - d[:, 0]).astype(np.float64)
         clk = life / ((d[:, 14] - d[:, 13]).astype(np.float64) * 10e-9) / 1e9
         print(f'{name:12s} blocks {len(d)}  tiles/block {n.min():.0f}..{n.max():.0f}  K loop {np.median(d[:, 1] / n):8.0f} cycles/tile  '
-              f'epilogue {np.median(d[:, 2] / n):7.0f}  other {np.median((life - d[:, 1] - d[:, 2]) / n):6.0f}  '
+              f'epilogue {np.median(d[:, 2] / n):7.0f}  (branch chunks {np.median(d[:, 8] / n):6.0f})  other {np.median((life - d[:, 1] - d[:, 2]) / n):6.0f}  '
               f'lifetime median {np.median(life):9.0f} max {life.max():9.0f} cycles  clock {np.median(clk):.2f} GHz  '
               f'launch {(d[:, 14].max() - d[:, 13].min()) * 10e-3:.1f} us', flush=True)
 
