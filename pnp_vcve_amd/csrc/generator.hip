@@ -1467,6 +1467,9 @@ int pnp_conv3x3_f16x3_ex(int nsrc, const float* const* srcs, const int* src_chan
     a.par = par;
     a.par_flags = par_flags;
     a.tile_queue = tile_queue;
+    // A queue that is not all zero on entry ends the blocks' walk early (tiles left unwritten, no error): zero it here instead of
+    // trusting the caller -- a launch aborted in mid-clip would leave it dirty for this entry point
+    if (tile_queue) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, reinterpret_cast<float*>(tile_queue), 0.0f, 16);
     a.par_plane = (long)h * w;
     a.bias = bias;
     a.gamma = gamma;
