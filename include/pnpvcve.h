@@ -223,6 +223,14 @@ int64_t pnp_wino_image_floats(void);
 int64_t pnp_wino_par_image_floats(void);
 int pnp_wino_image_from_packed_f32(const float* packed_w_dev, const float* gamma_dev, float* dst_dev, void* stream);
 int pnp_wino_par_image_from_packed_f32(const float* packed_w1x1_dev, float* dst_dev, void* stream);
+/* The input conv (basicvsr_net.py:484 over the virtual concat of iconvsr_ipb_par.py:90,125) in the same form: srcs_dev[0] the frame
+ * as (h,w,4) RGB0, srcs_dev[1..nsrc-1] one to three (h,w,64) maps; wino_w_dev[0] = pnp_wino_rgb_image_from_packed_f32 of the frame's
+ * packed chunk (pnp_pack_conv3x3_f32 with csrc 3), wino_w_dev[s] = pnp_wino_image_from_packed_f32 (no gamma) of source s's image.
+ * The images of the 64-channel sources must lie within 4 GiB of each other.  out = act(sum_s conv3x3(src_s) + bias). */
+int64_t pnp_wino_rgb_image_floats(void);
+int pnp_wino_rgb_image_from_packed_f32(const float* packed_rgb_chunk_dev, float* dst_dev, void* stream);
+int pnp_conv3x3_wino_ms_f32(int nsrc, const float* const* srcs_dev, const float* const* wino_w_dev, const float* bias_dev,
+                            int act, float* out_dev, int h, int w, void* stream);
 int pnp_conv3x3_wino_f32(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
                          const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
                          const float* residual_dev, int act, float* out_dev, int h, int w, void* stream);

@@ -12,6 +12,8 @@ struct ConvArgs {
     const float* wwino;     // Winograd F(2x2,3x3) image of wsrc[0] (16 chunks of 4096 floats, gamma folded in: launch_wino_images), or nullptr:
                             // with it a single-source 64 -> 64 conv (prec 0, out_mode 0) runs on conv_wino.hip
     const float* wwino_par; // ... and of wpar (launch_wino_par_image; 12288 floats); required with wwino when wpar is set
+    const float* wwino_src[4]; // the input conv in Winograd form (source 0 the RGB frame, then 1..3 64-channel sources): the image of
+    const float* wwino_rgb;    // wsrc[s] for s >= 1 (launch_wino_images) and of the frame's chunk wsrc[0] (launch_wino_rgb_image)
     const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
     const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo
                             // interleaved, twice the halfs; conv_f16x3.hip launch_f16x3_image)
@@ -133,10 +135,13 @@ int launch_conv_last_valu(const ConvArgs& a, hipStream_t stream);
 // scales the bias).  n <= 16 images per launch.
 int launch_wino_images(const float* const* src, float* const* dst, int n, const float* gamma, hipStream_t stream);
 int launch_wino_par_image(const float* src_3chunks, float* dst_12288, hipStream_t stream);
+int launch_wino_rgb_image(const float* src_chunk, float* dst_4096, hipStream_t stream);
 bool conv_wino_eligible(const ConvArgs& a, int cfg, int grid_y);
+bool conv_wino_ms_eligible(const ConvArgs& a, int cfg, int grid_y);
 int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream);
 #define PNP_WINO_IMG_FLOATS 65536
 #define PNP_WINO_PAR_FLOATS 12288
+#define PNP_WINO_RGB_FLOATS 4096
 
 // persistent single-source variant (conv_persist.hip)
 bool conv_persist_eligible(const ConvArgs& a, int cfg, int grid_y);

@@ -469,7 +469,7 @@ int launch_conv3x3(const ConvArgs& a, int cfg, int grid_y, hipStream_t stream) {
     if (a.prec == 1 && conv_f16_eligible(a, cfg, grid_y)) return launch_conv3x3_f16(a, grid_y, stream);
     if (a.prec == 2 && conv_f16x3_eligible(a, cfg, grid_y)) return launch_conv3x3_f16x3(a, cfg, stream);
     if (a.src_f16 || a.out_f16) return PNP_ERR_UNSUPPORTED;     // fp16 maps exist only between two fp16 launches
-    if (conv_wino_eligible(a, cfg, grid_y)) return launch_conv3x3_wino(a, stream);
+    if (conv_wino_eligible(a, cfg, grid_y) || conv_wino_ms_eligible(a, cfg, grid_y)) return launch_conv3x3_wino(a, stream);
     if (conv_last_valu_eligible(a, cfg, grid_y)) return launch_conv_last_valu(a, stream);
     if (conv_persist_eligible(a, cfg, grid_y)) return launch_conv3x3_persist(a, stream);
     switch (cfg) {

@@ -33,6 +33,7 @@
 //   * epilogue: Y = A^T M A in registers, + bias (* gamma), activation; one N tile at a time through 4 KiB of LDS per wave (the ring
 //     slot the tile's last chunk has just left) so that residual loads and stores move 16 B per lane (64-B channel runs per pixel).
 #include "conv_mfma.h"
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -79,10 +80,18 @@ struct WinoArgs {
     float* out;
     int H, W, act;
     unsigned long long* dbg;
+    // MS (the input conv over the virtual concat [lr, wide sources...], iconvsr_ipb_par.py:90,125): src / U above are unused
+    const float* srcs[3];   // the 64-channel sources, NHWC64
+    unsigned u_off[3];      // byte offset of each source's 16-chunk image from ubase
+    const float* ubase;
+    int nsrc;               // 1..3
+    const float* rgb;       // the frame as (H,W,4) RGB0
+    const float* Urgb;      // launch_wino_rgb_image: 4 chunks of 4 KiB
 };
 
-template <bool PAR, bool RES>
+template <bool PAR, bool RES, bool MS>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) {
+    static_assert(!MS || (!PAR && !RES), "the multi-source form is the input conv: no branches, no residual");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -108,8 +117,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
     // halo pixel (ry, rx) of a tile at (y0, x0) is image pixel (y0 - 1 + ry, x0 - 1 + rx): the descriptor's base sits one row and one
     // pixel before the map so that lane offsets stay non-negative; lanes outside the image carry the offset OOBW (-> zeros)
-    const __amdgpu_buffer_rsrc_t r_src = rsrc_of(reinterpret_cast<const char*>(a.src) - ((long)W + 1) * 256, OOBW);
-    const __amdgpu_buffer_rsrc_t r_u = rsrc_of(a.U, 16u * 16384u);
+    // (MS: r_src is the source the NEXT halo slabs come from -- the next source of this tile or the first one of the next tile --
+    //  re-made per segment; r_u spans every source's image, the segment adds its byte offset)
+    __amdgpu_buffer_rsrc_t r_src = rsrc_of(reinterpret_cast<const char*>(MS ? a.srcs[0] : a.src) - ((long)W + 1) * 256, OOBW);
+    const __amdgpu_buffer_rsrc_t r_u = rsrc_of(MS ? a.ubase : a.U, MS ? OOBW : 16u * 16384u);
+    const __amdgpu_buffer_rsrc_t r_urgb = rsrc_of(MS ? a.Urgb : a.U, 4u * 4096u);
+    const __amdgpu_buffer_rsrc_t r_rgb = rsrc_of(reinterpret_cast<const char*>(MS ? a.rgb : a.src) - ((long)W + 1) * 16, OOBW);
     const __amdgpu_buffer_rsrc_t r_up = rsrc_of(PAR ? a.Upar : a.U, 4u * 12288u);
     const __amdgpu_buffer_rsrc_t r_out = rsrc_of(a.out, map_bytes);
     const __amdgpu_buffer_rsrc_t r_res = rsrc_of(RES ? a.residual : a.src, RES ? map_bytes : 0u);
@@ -201,6 +214,33 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             }
         }
     };
+    // MS: the frame's halo (18 x 18 pixels x RGB0 = 5 KiB) lives where the branch kernels keep their partition values; pixel order as in
+    // the slabs (even columns of a row first).  Thread t moves pixels t and t + 256 (clamped to 323: duplicates rewrite the same value)
+    f32x4 rgbreg[2];
+    float Vr[16];
+    auto rgb_request = [&](int tq_, int y0, int x0) {
+        if constexpr (MS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int e = tq_ + 256 * i;
+                e = e < NPX ? e : NPX - 1;
+                const int ry = (e * 3641) >> 16, col = e - ry * HP, rx = col < 9 ? 2 * col : 2 * col - 17;
+                const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+                const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                rgbreg[i] = bload4(r_rgb, inb ? (unsigned)(ry * W + rx) * 16u : OOBW, (unsigned)(y0 * W + x0) * 16u);
+            }
+        }
+    };
+    auto rgb_store = [&](int tq_) {
+        if constexpr (MS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int e = tq_ + 256 * i;
+                e = e < NPX ? e : NPX - 1;
+                *reinterpret_cast<f32x4*>(smem + PV_B + e * 16) = rgbreg[i];
+            }
+        }
+    };
     int ty0 = (tile / tiles_x) * 16, tx0 = (tile % tiles_x) * 16;
     // ---- prologue: whole halo of the first tile, chunks 0..2, first patch
     {
@@ -217,10 +257,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         for (int c = 0; c < 3; ++c) {
             const bool brc = PAR && (c % 5 == 0);
 #pragma unroll
-            for (int i = 0; i < (brc ? 3 : 4); ++i)
-                rg[c][i] = brc ? bload4(r_up, t16, (c / 5) * 12288 + i * 4096)
+            for (int i = 0; i < (MS ? 1 : brc ? 3 : 4); ++i)
+                rg[c][i] = MS ? bload4(r_urgb, t16, c * 4096)
+                         : brc ? bload4(r_up, t16, (c / 5) * 12288 + i * 4096)
                                : bload4(r_u, t16, (PAR ? (c / 5) * 4 + (c % 5) - 1 : c) * 16384 + i * 4096);
         }
+        rgb_request(t, ty0, tx0);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -233,8 +275,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         for (int c = 0; c < 3; ++c) {
             const bool brc = PAR && (c % 5 == 0);
 #pragma unroll
-            for (int i = 0; i < (brc ? 3 : 4); ++i) *reinterpret_cast<f32x4*>(smem + (c & 3) * 16384 + i * 4096 + t16) = rg[c][i];
+            for (int i = 0; i < (MS ? 1 : brc ? 3 : 4); ++i) *reinterpret_cast<f32x4*>(smem + (c & 3) * 16384 + i * 4096 + t16) = rg[c][i];
         }
+        rgb_store(t);
         pv_request(t, ty0, tx0);
         pv_finish(t);
         __syncthreads();
@@ -251,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     }
     // (the B fragment of lane l, N tile n, position column pj of a chunk in slot z sits at z * 16384 + (pj * 4 + n) * 1024 + l * 16)
     const unsigned bl = (unsigned)lane * 16u;
-    if constexpr (!PAR) {
+    if constexpr (!PAR && !MS) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) bf[0][n] = lds4(bl + n * 1024);
     }
@@ -270,8 +313,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         const bool has_next = ntile < tend;
         const int nty0 = has_next ? (ntile / tiles_x) * 16 : ty0, ntx0 = has_next ? (ntile % tiles_x) * 16 : tx0;
         const unsigned nso = (unsigned)(nty0 * W + ntx0) * 256u;
-        halo_offsets(tq, nty0, ntx0);
+        if constexpr (!MS) halo_offsets(tq, nty0, ntx0);
         const unsigned tq16 = (unsigned)tq * 16u;
+        // MS: per segment (= one 64-channel source): where its weight image starts, where the next segment's does, whether it is the
+        // tile's last one (then the next chunks are the next tile's RGB chunks), and the tile origin of the slabs it refills
+        unsigned u_so = 0, u_so_next = 0, ref_so = nso;
+        bool last_seg = true;
         int need = 7;
         if constexpr (PAR) {
             // par_flags != nullptr only ENABLES branch skipping here (the caller's PNP_OPT_PAR_SKIP switch): the decision is per wave,
@@ -344,7 +391,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     const int pj = g >> 4, k = (g >> 2) & 3, n = g & 3, p = PG * 4 + pj;
                     // step 0, first k-step: C operand = 0 (no accumulator clearing; the four positions the branches use excepted),
                     // or the bias at position (1,1), which A^T . A carries to all four output pixels with weight 1
-                    const bool fresh = S == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
+                    // (MS: the RGB chunks in front of the first source start the accumulators)
+                    const bool fresh = !MS && S == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
                     const f32x4 c0 = p == 5 ? f32x4{bgv[n], bgv[n], bgv[n], bgv[n]} : f32x4{0.f, 0.f, 0.f, 0.f};
                     acc[p][n] = mfma16(V[p][k], bf[pj & 1][n][k], fresh ? c0 : acc[p][n]);
                     // ---- the gap behind it
@@ -355,10 +403,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         *reinterpret_cast<f32x4*>(smem + (NCB & 3) * 16384 + g * 4096 + tq16) = breg[g];
                     }
                     if ((g & 15) < 4 && !(pj == 3 && NEXT_IS_BR)) {
-                        const unsigned nb = pj < 3 ? (C & 3) * 16384 + (pj + 1) * 4096 : ((C + 1) & 3) * 16384;
-                        bf[(pj + 1) & 1][g & 3] = lds4(nb + bl + (g & 3) * 1024);
+                        // (MS, the tile's last chunk: the next one is an RGB chunk of the next tile, which reads its own fragments)
+                        if (!(MS && C == 15 && pj == 3 && last_seg)) {
+                            const unsigned nb = pj < 3 ? (C & 3) * 16384 + (pj + 1) * 4096 : ((C + 1) & 3) * 16384;
+                            bf[(pj + 1) & 1][g & 3] = lds4(nb + bl + (g & 3) * 1024);
+                        }
                     }
-                    if (g >= 4 && g < 4 + NRING)
+                    if constexpr (MS) {
+                        // the chunk three ahead: this source's, the next source's first chunks, or (last source) the next tile's RGB chunks,
+                        // which are one 4-KiB piece each
+                        if (g >= 4 && g < 8) {
+                            if (C < 13) breg[g - 4] = bload4(r_u, tq16, u_so + (C + 3) * 16384 + (g - 4) * 4096);
+                            else if (!last_seg) breg[g - 4] = bload4(r_u, tq16, u_so_next + (C - 13) * 16384 + (g - 4) * 4096);
+                            else if (g == 4) breg[0] = bload4(r_urgb, tq16, (C - 13) * 4096);
+                        }
+                    } else if (g >= 4 && g < 4 + NRING)
                         breg[g - 4] = NBR ? bload4(r_up, tq16, NSTEP * 12288 + (g - 4) * 4096) : bload4(r_u, tq16, (NSTEP * 4 + NPG) * 16384 + (g - 4) * 4096);
                     if (S == 0 && PG == 1 && g == 7) bgv = *reinterpret_cast<const f32x4*>(smem + BG_B + (tq & 15) * 16);
                     if ((PG == 1 || PG == 2) && g >= 8 && g < 11) {        // (before this chunk's own halo requests reuse the registers)
@@ -366,7 +425,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         e = e < NPX * 4 ? e : NPX * 4 - 1;
                         *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[g - 8];
                     }
-                    if ((PG == 0 || PG == 1) && g >= 11 && g < 14) hreg[g - 11] = bload4(r_src, hoff[g - 11 + 3 * PG], nso + S * 64);
+                    if ((PG == 0 || PG == 1) && g >= 11 && g < 14) hreg[g - 11] = bload4(r_src, hoff[g - 11 + 3 * PG], ref_so + S * 64);
+                    // MS, last source: the next tile's RGB halo, requested in step 1 and stored a chunk later (this tile's RGB patch was read
+                    // before its first chunk)
+                    if (MS && S == 1 && PG == 0 && g == 14 && last_seg) rgb_request(tq, nty0, ntx0);
+                    if (MS && S == 1 && PG == 1 && g == 14 && last_seg) rgb_store(tq);
                     if (RES && S == 3 && PG == 0 && g == 16 && !(ty0 + 16 > H || tx0 + 16 > W)) {
                         // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (8 rows x
                         // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
@@ -412,7 +475,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                             V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
                         }
                     }
-                    if (g >= 52 && g < 52 + NRING) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
+                    if (g >= 52 && g < 52 + NRING) {
+                        if (!(MS && C >= 13 && last_seg && g > 52)) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -438,10 +503,85 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         };
         unsigned long long dbg_a = 0, dbg_b = 0;
         if (a.dbg) dbg_a = __builtin_amdgcn_s_memtime();
-        step(I<0>{});
-        step(I<1>{});
-        step(I<2>{});
-        step(I<3>{});
+        if constexpr (MS) {
+            // ---- the frame itself first: 3 (+1 zero) channels are ONE k-step of the MFMA (channel = lane quarter), so its Winograd
+            //      contraction is 4 chunks of 16 MFMAs; they start the accumulators (zero C operand; the bias at position (1,1))
+            {
+                const unsigned rb = PV_B + ((2 * ty) * HP + tx) * 16 + kq * 4;
+                float dr[16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dr[r * 4 + c] = *reinterpret_cast<const float*>(smem + rb + (r * HP + (c & 1) * 9 + (c >> 1)) * 16);
+                float tr[16];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tr[0 * 4 + c] = dr[0 * 4 + c] - dr[2 * 4 + c];
+                    tr[1 * 4 + c] = dr[1 * 4 + c] + dr[2 * 4 + c];
+                    tr[2 * 4 + c] = dr[2 * 4 + c] - dr[1 * 4 + c];
+                    tr[3 * 4 + c] = dr[1 * 4 + c] - dr[3 * 4 + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    Vr[i * 4 + 0] = tr[i * 4 + 0] - tr[i * 4 + 2];
+                    Vr[i * 4 + 1] = tr[i * 4 + 1] + tr[i * 4 + 2];
+                    Vr[i * 4 + 2] = tr[i * 4 + 2] - tr[i * 4 + 1];
+                    Vr[i * 4 + 3] = tr[i * 4 + 1] - tr[i * 4 + 3];
+                }
+            }
+            const f32x4 bgv = *reinterpret_cast<const f32x4*>(smem + BG_B + (tq & 15) * 16);
+            auto rgb_chunk = [&](auto pg_c) {
+                constexpr int PG = decltype(pg_c)::value;         // chunk PG of the tile, ring slot PG
+                lds_bar();
+                f32x4 br[4];
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj) br[pj] = lds4(PG * 16384 + (pj * 64 + (tq & 63)) * 16);
+                // three ahead: RGB chunk 3 (one piece), then the first source's chunks 0..2
+                if (PG == 0) breg[0] = bload4(r_urgb, tq16, 3 * 4096);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) breg[i] = bload4(r_u, tq16, a.u_off[0] + (PG - 1) * 16384 + i * 4096);
+                }
+#pragma unroll
+                for (int pj = 0; pj < 4; ++pj)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int p = PG * 4 + pj;
+                        const f32x4 c0 = p == 5 ? f32x4{bgv[n], bgv[n], bgv[n], bgv[n]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[p][n] = mfma16(Vr[p], br[pj][n], c0);
+                    }
+                if (PG == 3) {                                     // the first fragments of the first source's first chunk
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bf[0][n] = lds4(bl + n * 1024);
+                }
+#pragma unroll
+                for (int i = 0; i < (PG == 0 ? 1 : 4); ++i) *reinterpret_cast<f32x4*>(smem + ((PG + 3) & 3) * 16384 + i * 4096 + tq16) = breg[i];
+            };
+            rgb_chunk(I<0>{});
+            rgb_chunk(I<1>{});
+            rgb_chunk(I<2>{});
+            rgb_chunk(I<3>{});
+            // ---- then one segment of 16 chunks per 64-channel source
+            const int nw = a.nsrc;
+            for (int ks = 0; ks < nw; ++ks) {
+                last_seg = ks + 1 >= nw;
+                u_so = a.u_off[ks];
+                u_so_next = a.u_off[last_seg ? 0 : ks + 1];
+                // the slabs this segment refills belong to the next source of this tile, or to the first source of the next tile
+                r_src = rsrc_of(reinterpret_cast<const char*>(a.srcs[last_seg ? 0 : ks + 1]) - ((long)W + 1) * 256, OOBW);
+                ref_so = last_seg ? nso : (unsigned)(ty0 * W + tx0) * 256u;
+                halo_offsets(tq, last_seg ? nty0 : ty0, last_seg ? ntx0 : tx0);
+                step(I<0>{});
+                step(I<1>{});
+                step(I<2>{});
+                step(I<3>{});
+            }
+        } else {
+            step(I<0>{});
+            step(I<1>{});
+            step(I<2>{});
+            step(I<3>{});
+        }
         if (a.dbg) {
             dbg_b = __builtin_amdgcn_s_memtime();
             dbg_k += dbg_b - dbg_a;
@@ -577,7 +717,38 @@ __global__ __launch_bounds__(256) void wino_par_image_kernel(const float* __rest
     dst[(((ci >> 4) * 3 + br) * 4 + (co >> 4)) * 256 + (((ci >> 2) & 3) * 16 + (co & 15)) * 4 + (ci & 3)] = v;
 }
 
+// the RGB frame's chunk (PACK_RGB4, common.h: float index ((q * 2 + nt32) * 64 + h * 32 + n32) * 4 + j  <->  tap 2 q + h, channel j,
+// co = 32 nt32 + n32) -> four position-row chunks of 1024 floats: float index (pj * 64 + kq * 16 + n16) * 4 + nt  <->  position
+// (i, pj), input channel kq (the MFMA's k index: one k-step covers R, G, B and the zero channel), co = 16 nt + n16
+__global__ __launch_bounds__(256) void wino_rgb_image_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // 256 = 4 channels x 64 output channels
+    const int c = idx >> 6, co = idx & 63;
+    double g[3][3];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        g[tap / 3][tap % 3] = src[(((tap >> 1) * 2 + (co >> 5)) * 64 + (tap & 1) * 32 + (co & 31)) * 4 + c];
+    double tmp[4][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        tmp[0][x] = g[0][x];
+        tmp[1][x] = 0.5 * (g[0][x] + g[1][x] + g[2][x]);
+        tmp[2][x] = 0.5 * (g[0][x] - g[1][x] + g[2][x]);
+        tmp[3][x] = g[2][x];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double u[4] = {tmp[i][0], 0.5 * (tmp[i][0] + tmp[i][1] + tmp[i][2]), 0.5 * (tmp[i][0] - tmp[i][1] + tmp[i][2]), tmp[i][2]};
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) dst[i * 1024 + (pj * 64 + c * 16 + (co & 15)) * 4 + (co >> 4)] = (float)u[pj];
+    }
+}
+
 }  // namespace
+
+int launch_wino_rgb_image(const float* src, float* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(wino_rgb_image_kernel, dim3(1), dim3(256), 0, stream, src, dst);
+    return (int)hipGetLastError();
+}
 
 int launch_wino_images(const float* const* src, float* const* dst, int n, const float* gamma, hipStream_t stream) {
     if (n < 1 || n > 16) return PNP_ERR_BAD_ARG;
@@ -596,6 +767,16 @@ int launch_wino_par_image(const float* src, float* dst, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// the input conv: source 0 the RGB frame, then 1..3 64-channel sources, every one with its Winograd image (and the frame's)
+bool conv_wino_ms_eligible(const ConvArgs& a, int cfg, int grid_y) {
+    if (!a.wwino_rgb || a.prec != 0 || cfg == CONV_CFG_RGB || grid_y != 1 || a.out_mode != 0) return false;
+    if (a.nsrc < 2 || a.nsrc > 4 || a.src_c[0] != 4 || a.src_f16 || a.out_f16 || a.out16) return false;
+    if (a.wpar || a.residual || a.gamma) return false;
+    for (int s = 1; s < a.nsrc; ++s)
+        if (a.src_c[s] != 64 || !a.wwino_src[s]) return false;
+    return (long)a.H * a.W * 256 < ((long)1 << 32) - 65536;
+}
+
 bool conv_wino_eligible(const ConvArgs& a, int cfg, int grid_y) {
     if (!a.wwino || a.prec != 0 || cfg == CONV_CFG_RGB || grid_y != 1 || a.out_mode != 0) return false;
     if (a.nsrc != 1 || a.src_c[0] != 64 || a.src_f16 || a.out_f16 || a.out16) return false;
@@ -608,17 +789,19 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
     int cus = 256;
     const hipError_t attr_err = once.run([](int dev, int& g) {
         hipError_t e = hipSuccess;
-        const void* fns[4] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false>),
-                              reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true>),
-                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, false>),
-                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, true>)};
-        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
+        const void* fns[5] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false>),
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false>),
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, false, false>),
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, true, false>),
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, true>)};
+        for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
         g = 256;
         (void)hipDeviceGetAttribute(&g, hipDeviceAttributeMultiprocessorCount, dev);
         return e;
     }, &cus);
     if (attr_err != hipSuccess) return (int)attr_err;
     WinoArgs w;
+    memset(&w, 0, sizeof(w));
     w.src = a.src[0];
     w.U = a.wwino;
     w.Upar = a.wpar ? a.wwino_par : nullptr;
@@ -636,9 +819,25 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
     const int ntiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     int grid = ntiles < cus ? ntiles : cus;                 // one resident block per CU
     if (grid >= 8) grid -= grid % 8;
-    if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-    else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-    else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-    else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    if (conv_wino_ms_eligible(a, CONV_CFG_BIG, 1) && !a.wwino) {
+        // the input conv: the frame + the 64-channel sources; the images must sit within 4 GiB of the lowest one (one descriptor)
+        const float* lo = a.wwino_src[1];
+        for (int s = 2; s < a.nsrc; ++s)
+            if (a.wwino_src[s] < lo) lo = a.wwino_src[s];
+        w.ubase = lo;
+        w.nsrc = a.nsrc - 1;
+        for (int s = 1; s < a.nsrc; ++s) {
+            const long off = (const char*)a.wwino_src[s] - (const char*)lo;
+            if (off < 0 || off >= ((long)1 << 32) - PNP_WINO_IMG_FLOATS * 4) return PNP_ERR_UNSUPPORTED;
+            w.srcs[s - 1] = a.src[s];
+            w.u_off[s - 1] = (unsigned)off;
+        }
+        w.rgb = a.src[0];
+        w.Urgb = a.wwino_rgb;
+        hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    } else if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     return (int)hipGetLastError();
 }

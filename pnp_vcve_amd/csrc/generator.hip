@@ -54,6 +54,7 @@ struct BranchPk {
     int64_t in_wide01 = -1;       // packed: in_wide[0] + in_wide[1] (align_key with an adjacent key frame: both are the
                                   // same warped tensor, conv(x, W0) + conv(x, W1) = conv(x, W0 + W1))
     int n_wide = 0;
+    int64_t in_lr_wino = -1, in_wide_wino[3] = {-1, -1, -1}, in_wide01_wino = -1;   // packed: their Winograd images (conv_wino.hip, MS form)
     int64_t in_bias = -1;         // flat
     std::vector<BlockPk> blocks;
 };
@@ -242,6 +243,12 @@ int build_layout(pnp_generator* g) {
     }
     // Winograd images of the static 64 -> 64 convs and of the 1x1 branches (PNP_OPT_WINOGRAD; conv_wino.hip).  Appended last: no
     // earlier offset moves.  The dynamic convs get theirs per frame in the workspace (their channel gain is folded in).
+    for (int b = 0; b < 2; ++b) {
+        BranchPk& B = g->br[b];
+        B.in_lr_wino = g->add_packed(PNP_WINO_RGB_FLOATS);
+        for (int s = 0; s < B.n_wide; ++s) B.in_wide_wino[s] = g->add_packed(PNP_WINO_IMG_FLOATS);
+        if (B.in_wide01 >= 0) B.in_wide01_wino = g->add_packed(PNP_WINO_IMG_FLOATS);
+    }
     for (int b = 0; b < 2; ++b)
         for (auto& K : g->br[b].blocks) {
             if (K.conv1_img >= 0) K.conv1_wino = g->add_packed(PNP_WINO_IMG_FLOATS);
@@ -339,9 +346,12 @@ struct ConvCall {
     int bias_ystride_ = 0, act_ = 0, H, W, mode_ = 0, cfg_, gy_ = 1, io16_ = 0;
 
     ConvCall(int h, int w, int cfg) : H(h), W(w), cfg_(cfg) {}
-    ConvCall& source(const float* s, int channels, const float* wimg) {   // next member of the virtual concat
+    const float* wsrc_wino_[4] = {nullptr, nullptr, nullptr, nullptr};
+    // next member of the virtual concat; wino: the Winograd image of wimg (input conv on conv_wino.hip's multi-source form) or nullptr
+    ConvCall& source(const float* s, int channels, const float* wimg, const float* wino = nullptr) {
         src[nsrc] = s;
         sc[nsrc] = channels;
+        wsrc_wino_[nsrc] = wino;
         w[nsrc++] = wimg;
         return *this;
     }
@@ -604,6 +614,13 @@ int pnp_generator_pack(const pnp_generator* g, const float* flat, float* packed,
     if (g->prec == PNP_PREC_F32) {   // Winograd images (only the fp32 path has a Winograd kernel)
         std::vector<const float*> ws;
         std::vector<float*> wd;
+        for (int b = 0; b < 2; ++b) {
+            const BranchPk& B = g->br[b];
+            rc = launch_wino_rgb_image(packed + B.in_lr, packed + B.in_lr_wino, st);
+            if (rc) return rc;
+            for (int s = 0; s < B.n_wide; ++s) { ws.push_back(packed + B.in_wide[s]); wd.push_back(packed + B.in_wide_wino[s]); }
+            if (B.in_wide01 >= 0) { ws.push_back(packed + B.in_wide01); wd.push_back(packed + B.in_wide01_wino); }
+        }
         for (int b = 0; b < 2; ++b)
             for (const auto& K : g->br[b].blocks) {
                 if (K.conv1_wino >= 0) { ws.push_back(packed + K.conv1_img); wd.push_back(packed + K.conv1_wino); }
@@ -691,6 +708,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.wpar = q.wpar_;
         a.wwino = q.wino_;
         a.wwino_par = q.wino_par_;
+        if (q.nsrc >= 2 && q.sc[0] == 4 && q.wsrc_wino_[0]) {      // input conv with Winograd images on every member
+            a.wwino_rgb = q.wsrc_wino_[0];
+            for (int s = 1; s < q.nsrc; ++s) a.wwino_src[s] = q.wsrc_wino_[s];
+        }
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
@@ -954,17 +975,19 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         for (int i = t - 1; i >= 0; --i) {
             const BranchPk& B = g->br[0];
             ConvCall in(h, w, cfg_lr);
-            in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr);
+            const bool wn = wino_ok(h, w);
+            auto wi = [&](int64_t off) -> const float* { return wn ? packed + off : nullptr; };
+            in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr, wi(B.in_lr_wino));
             if (i < t - 1) {
                 int k = i + 1;
                 while (!key[k]) ++k;
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 2) * hw, mv_b + ((int64_t)i * 4 + 3) * hw);
                 if (rc) return rc;
                 if (c.with_cat && c.align_key && k == i + 1) {     // neighbour == key frame: one source, summed weights
-                    in.source(W.kw, 64, packed + B.in_wide01).mirror16(kw16);
+                    in.source(W.kw, 64, packed + B.in_wide01, wi(B.in_wide01_wino)).mirror16(kw16);
                 } else {
-                    in.source(W.kw, 64, packed + B.in_wide[0]).mirror16(kw16);
-                    if (c.with_cat) in.source(W.slots + (int64_t)(i + 1) * fm, 64, packed + B.in_wide[1]).mirror16(s16of(i + 1));
+                    in.source(W.kw, 64, packed + B.in_wide[0], wi(B.in_wide_wino[0])).mirror16(kw16);
+                    if (c.with_cat) in.source(W.slots + (int64_t)(i + 1) * fm, 64, packed + B.in_wide[1], wi(B.in_wide_wino[1])).mirror16(s16of(i + 1));
                 }
             }
             rc = run_branch(0, i, in);
@@ -974,20 +997,22 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         for (int i = 0; i < t; ++i) {
             const BranchPk& B = g->br[1];
             ConvCall in(h, w, cfg_lr);
-            in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr);
+            const bool wn = wino_ok(h, w);
+            auto wi = [&](int64_t off) -> const float* { return wn ? packed + off : nullptr; };
+            in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr, wi(B.in_lr_wino));
             if (i > 0) {
                 int k = i - 1;
                 while (!key[k]) --k;
                 rc = align(W.slots + (int64_t)k * fm, mv_b + ((int64_t)i * 4 + 0) * hw, mv_b + ((int64_t)i * 4 + 1) * hw);
                 if (rc) return rc;
                 if (c.with_cat && c.align_key && k == i - 1) {
-                    in.source(W.kw, 64, packed + B.in_wide01).mirror16(kw16);
+                    in.source(W.kw, 64, packed + B.in_wide01, wi(B.in_wide01_wino)).mirror16(kw16);
                 } else {
-                    in.source(W.kw, 64, packed + B.in_wide[0]).mirror16(kw16);
-                    if (c.with_cat) in.source(W.slots + (int64_t)(i - 1) * fm, 64, packed + B.in_wide[1]).mirror16(s16of(i - 1));
+                    in.source(W.kw, 64, packed + B.in_wide[0], wi(B.in_wide_wino[0])).mirror16(kw16);
+                    if (c.with_cat) in.source(W.slots + (int64_t)(i - 1) * fm, 64, packed + B.in_wide[1], wi(B.in_wide_wino[1])).mirror16(s16of(i - 1));
                 }
             }
-            in.source(W.slots + (int64_t)i * fm, 64, packed + B.in_wide[B.n_wide - 1]).mirror16(s16of(i));   // backward feature of this frame
+            in.source(W.slots + (int64_t)i * fm, 64, packed + B.in_wide[B.n_wide - 1], wi(B.in_wide_wino[B.n_wide - 1])).mirror16(s16of(i));   // backward feature of this frame
             rc = run_branch(1, i, in);
             if (rc) return rc;
 
@@ -1248,6 +1273,35 @@ int pnp_pack_conv1x1_f32(const float* w, float* dst, void* st) {
 
 int64_t pnp_wino_image_floats(void) { return PNP_WINO_IMG_FLOATS; }
 int64_t pnp_wino_par_image_floats(void) { return PNP_WINO_PAR_FLOATS; }
+
+int64_t pnp_wino_rgb_image_floats(void) { return PNP_WINO_RGB_FLOATS; }
+
+int pnp_wino_rgb_image_from_packed_f32(const float* packed_rgb_chunk, float* dst, void* st) {
+    return launch_wino_rgb_image(packed_rgb_chunk, dst, (hipStream_t)st);
+}
+
+int pnp_conv3x3_wino_ms_f32(int nsrc, const float* const* srcs, const float* const* wino_w, const float* bias, int act, float* out,
+                            int h, int w, void* st) {
+    if (nsrc < 2 || nsrc > 4 || !srcs || !wino_w || !out || act < 0 || act > 2) return PNP_ERR_BAD_ARG;
+    if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsrc = nsrc;
+    for (int s = 0; s < nsrc; ++s) {
+        if (!srcs[s] || !wino_w[s]) return PNP_ERR_BAD_ARG;
+        a.src[s] = srcs[s];
+        a.src_c[s] = s == 0 ? 4 : 64;
+        a.wwino_src[s] = wino_w[s];
+    }
+    a.wwino_rgb = wino_w[0];
+    a.bias = bias;
+    a.out = out;
+    a.H = h;
+    a.W = w;
+    a.act = act;
+    if (!conv_wino_ms_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
+    return launch_conv3x3_wino(a, (hipStream_t)st);
+}
 
 int pnp_wino_image_from_packed_f32(const float* packed_w, const float* gamma, float* dst, void* st) {
     return launch_wino_images(&packed_w, &dst, 1, gamma, (hipStream_t)st);

@@ -352,6 +352,34 @@ def wino_par_image(packed_w1x1):
 
 
 @_on_device_of_first_tensor
+def wino_rgb_image(packed_rgb):
+    """Winograd image (4096 floats) of the frame's packed chunk (pack_conv3x3(w, cbase=0, csrc=3))."""
+    packed_rgb = _chk(packed_rgb, 'packed_rgb')
+    out = torch.empty(int(_native.lib().pnp_wino_rgb_image_floats()), device=packed_rgb.device, dtype=torch.float32)
+    _native.check(_native.lib().pnp_wino_rgb_image_from_packed_f32(_ptr(packed_rgb), _ptr(out), _stream()),
+                  'pnp_wino_rgb_image_from_packed_f32')
+    return out
+
+
+@_on_device_of_first_tensor
+def conv3x3_wino_ms(srcs, wino_ws, bias=None, act=0):
+    """The input conv on conv_wino.hip: srcs = [(h,w,4) frame, (h,w,64) maps ...], wino_ws = [wino_rgb_image(...), wino_image(...) ...];
+    the 64-channel sources' images must sit within 4 GiB of each other (slices of ONE tensor do)."""
+    srcs = [_chk(x, 'src') for x in srcs]
+    wino_ws = [_chk(x, 'wino_w') for x in wino_ws]
+    h, w = srcs[0].shape[:2]
+    n = len(srcs)
+    if n != len(wino_ws) or srcs[0].shape[2] != 4 or any(x.shape != (h, w, 64) for x in srcs[1:]):
+        raise ValueError('srcs must be [(h,w,4), (h,w,64) ...] with one Winograd image each')
+    out = torch.empty((h, w, 64), device=srcs[0].device, dtype=torch.float32)
+    sp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in srcs])
+    wp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in wino_ws])
+    _native.check(_native.lib().pnp_conv3x3_wino_ms_f32(n, sp, wp, _ptr(_chk(bias, 'bias')) if bias is not None else None, int(act),
+                                                        _ptr(out), h, w, _stream()), 'pnp_conv3x3_wino_ms_f32')
+    return out
+
+
+@_on_device_of_first_tensor
 def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par_flags=None, residual=None, act=0, trace=None):
     """act(gamma * (conv3x3(x; W) + bias) + sum_j par_j * conv1x1_j(x)) + residual on conv_wino.hip; x (h,w,64) NHWC fp32,
     wino_w = wino_image(packed W, gamma) -- the SAME gamma -- and wino_w1x1 = wino_par_image(packed 1x1 images)."""

@@ -216,6 +216,10 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
         RD("the partition planes", a.par, (size_t)(2 * a.par_plane + hw) * 4);
         if (a.par_flags) RD("the partition tile flags", a.par_flags, (size_t)((a.W + 15) / 16) * ((a.H + 7) / 8) * 4);
     }
+    if (path == 0 && conv_wino_ms_eligible(a, cfg, gy) && !a.wwino) {
+        RD("the frame's Winograd weight image", a.wwino_rgb, (size_t)PNP_WINO_RGB_FLOATS * 4);
+        for (int s = 1; s < a.nsrc; ++s) RD("a source's Winograd weight image", a.wwino_src[s], (size_t)PNP_WINO_IMG_FLOATS * 4);
+    }
     if (path == 0 && a.wwino && conv_wino_eligible(a, cfg, gy)) {      // the Winograd kernel reads these INSTEAD of wsrc / wpar (read above as well: harmless over-check)
         RD("the Winograd weight image", a.wwino, (size_t)PNP_WINO_IMG_FLOATS * 4);
         if (a.wpar) RD("the Winograd 1x1 weight image", a.wwino_par, (size_t)PNP_WINO_PAR_FLOATS * 4);
@@ -287,6 +291,21 @@ bool conv_wino_eligible(const ConvArgs& a, int cfg, int grid_y) {       // conv_
     if (a.nsrc != 1 || a.src_c[0] != 64 || a.src_f16 || a.out_f16 || a.out16) return false;
     if (a.wpar && (!a.wwino_par || !a.par)) return false;
     return (long)a.H * a.W * 256 < ((long)1 << 32) - 65536;
+}
+bool conv_wino_ms_eligible(const ConvArgs& a, int cfg, int grid_y) {    // conv_wino.hip's rule, restated
+    if (!a.wwino_rgb || a.prec != 0 || cfg == CONV_CFG_RGB || grid_y != 1 || a.out_mode != 0) return false;
+    if (a.nsrc < 2 || a.nsrc > 4 || a.src_c[0] != 4 || a.src_f16 || a.out_f16 || a.out16) return false;
+    if (a.wpar || a.residual || a.gamma) return false;
+    for (int s = 1; s < a.nsrc; ++s)
+        if (a.src_c[s] != 64 || !a.wwino_src[s]) return false;
+    return (long)a.H * a.W * 256 < ((long)1 << 32) - 65536;
+}
+int launch_wino_rgb_image(const float* src, float* dst, hipStream_t s) {
+    stub::cur = "launch_wino_rgb_image";
+    stub::note_launch(s);
+    stub::RD("the frame's packed weight chunk", src, 4096 * 4);
+    stub::WR("the frame's Winograd weight image", dst, (size_t)PNP_WINO_RGB_FLOATS * 4);
+    return 0;
 }
 int launch_wino_images(const float* const* src, float* const* dst, int n, const float* gamma, hipStream_t s) {
     stub::cur = "launch_wino_images";
@@ -565,13 +584,14 @@ int run(const Scenario& sc) {
     json_ints("warp_context", warp_ctx);
     json_ints("warp_f16", warp_f16);
     // expert mixtures: one per distinct routing value and context-sample; which one each partition-branch conv used
-    std::vector<int> mix_slot, block_frame, block_mix, conv_f16, conv_nsrc, conv_mask, conv_wino;
+    std::vector<int> mix_slot, block_frame, block_mix, conv_f16, conv_nsrc, conv_mask, conv_wino, conv_wino_ms;
     const Workspace W0 = carve(g, ws, sc.t, sc.h, sc.w);
     for (const MixRec& m : mixes) mix_slot.push_back((int)(((const float*)m.dst - W0.mixw) % ((int64_t)ctx_bytes / 4) / ((int64_t)g->ndyn * IMG_WIDE)));
     for (const ConvRec& c : convs) {
         conv_f16.push_back(c.path);
         conv_nsrc.push_back(c.a.nsrc);
         conv_wino.push_back((c.path == 0 && conv_wino_eligible(c.a, c.cfg, c.gy)) ? 1 : 0);
+        conv_wino_ms.push_back((c.path == 0 && conv_wino_ms_eligible(c.a, c.cfg, c.gy)) ? 1 : 0);
         conv_mask.push_back(c.a.src_f16 | (c.a.out_f16 ? 16 : 0) | (c.a.out16 ? 32 : 0));
         if (!(c.a.wpar || c.a.wpar_h)) continue;
         const size_t pl = (c.a.par - par) / (3 * hw);
@@ -597,6 +617,7 @@ int run(const Scenario& sc) {
     json_ints("conv_f16_path", conv_f16);
     json_ints("conv_nsrc", conv_nsrc);
     json_ints("conv_wino", conv_wino);
+    json_ints("conv_wino_ms", conv_wino_ms);
     json_ints("conv_map_mask", conv_mask);
     json_ints("launch_stream", launch_streams);
     std::vector<int> wait_stream, wait_on;

@@ -166,6 +166,58 @@ def test_wino_conv_720p_crop_consistency_scaling_and_determinism():
     assert float((got - ref[0, :, 1:-1, 1:-1]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize('hw', [(16, 16), (40, 72), (37, 53), (128, 160)])
+@pytest.mark.parametrize('nwide', [1, 2, 3])
+def test_wino_input_conv_over_the_virtual_concat(hw, nwide):
+    """lrelu(conv3x3(cat([lr, wide sources...])) + b) (basicvsr_net.py:484 over iconvsr_ipb_par.py:90,125's concat, never materialised):
+    the frame as four RGB chunks of 16 MFMAs that start the accumulators, then one 16-chunk segment per 64-channel source"""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    cin = 3 + 64 * nwide
+    lr = gu.syn.uniform(21, f'lr{h}', (1, 3, h, w), 0, 1)
+    wide = [gu.syn.uniform(21, f'x{k}{h}', (1, 64, h, w), -1, 1) for k in range(nwide)]
+    wt = gu.syn.uniform(21, f'w{nwide}', (64, cin, 3, 3), -0.06, 0.06)
+    b = gu.syn.uniform(21, 'b', (64,), -0.1, 0.1)
+    ref = F.leaky_relu(F.conv2d(torch.from_numpy(np.concatenate([lr] + wide, 1)).double(), torch.from_numpy(wt).double(),
+                                torch.from_numpy(b).double(), padding=1), 0.1)
+    lr4 = torch.zeros(h, w, 4, device=dev())
+    lr4[..., :3] = G(lr)[0].permute(1, 2, 0)
+    imgs = torch.empty(nwide, 65536, device=dev())                      # ONE tensor: the images within 4 GiB of each other
+    for k in range(nwide):
+        imgs[k] = ops.wino_image(ops.pack_conv3x3(G(wt), cbase=3 + 64 * k, csrc=64))
+    urgb = ops.wino_rgb_image(ops.pack_conv3x3(G(wt), cbase=0, csrc=3))
+    out = ops.conv3x3_wino_ms([lr4] + [nhwc(x) for x in wide], [urgb] + [imgs[k] for k in range(nwide)], bias=G(b), act=2)
+    d = float((nchw(out).double() - ref).abs().max())
+    direct = ops.conv3x3([lr4] + [nhwc(x) for x in wide],
+                         [ops.pack_conv3x3(G(wt), cbase=0, csrc=3)] + [ops.pack_conv3x3(G(wt), cbase=3 + 64 * k, csrc=64) for k in range(nwide)],
+                         bias=G(b), act=2)
+    dd = float((nchw(direct).double() - ref).abs().max())
+    print(hw, nwide, 'winograd vs fp64', d, ' direct vs fp64', dd, ' max|ref|', float(ref.abs().max()))
+    assert d < TOL_OP * max(1.0, float(ref.abs().max()))
+
+
+def test_wino_input_conv_720p_against_the_direct_kernel_and_itself():
+    from pnp_vcve_amd import ops
+    h, w = 720, 1280
+    g = torch.Generator(device=dev()).manual_seed(5)
+    lr4 = torch.rand(h, w, 4, device=dev(), generator=g)
+    lr4[..., 3] = 0
+    xs = [torch.randn(h, w, 64, device=dev(), generator=g) for _ in range(3)]
+    wt = torch.randn(64, 195, 3, 3, device=dev(), generator=g) * 0.03
+    b = torch.randn(64, device=dev(), generator=g) * 0.1
+    packs = [ops.pack_conv3x3(wt, cbase=0, csrc=3)] + [ops.pack_conv3x3(wt, cbase=3 + 64 * k, csrc=64) for k in range(3)]
+    imgs = torch.stack([ops.wino_image(p) for p in packs[1:]])
+    urgb = ops.wino_rgb_image(packs[0])
+    direct = ops.conv3x3([lr4] + xs, packs, bias=b, act=2)
+    y = ops.conv3x3_wino_ms([lr4] + xs, [urgb] + [imgs[k] for k in range(3)], bias=b, act=2)
+    assert float((y - direct).abs().max()) < 2e-5                      # |out| up to ~10 here
+    for _ in range(5):
+        assert torch.equal(ops.conv3x3_wino_ms([lr4] + xs, [urgb] + [imgs[k] for k in range(3)], bias=b, act=2), y)
+    y2 = ops.conv3x3_wino_ms([lr4] + xs[:2], [urgb, imgs[0], imgs[1]], bias=b, act=2)
+    d2 = ops.conv3x3([lr4] + xs[:2], packs[:3], bias=b, act=2)
+    assert float((y2 - d2).abs().max()) < 2e-5
+
+
 def test_wino_op_refuses_what_it_cannot_do():
     from pnp_vcve_amd import ops
     x = torch.zeros(32, 32, 64, device=dev())

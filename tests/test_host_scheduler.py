@@ -186,6 +186,10 @@ def test_winograd_option_routes_the_single_source_64_channel_convs(stub_run):
     # t = 7, 8 blocks: 2 sweeps x 7 frames x 16 block halves + 7 conv_hr
     assert sum(d['conv_wino']) == 2 * 7 * 16 + 7
     assert all(w == 0 for w, ns in zip(d['conv_wino'], d['conv_nsrc']) if ns > 1)
+    # the input convs with at least one 64-channel source take the multi-source form: every frame of both sweeps but the last
+    # frame's backward one (the frame alone)
+    assert sum(d['conv_wino_ms']) == 2 * 7 - 1 and all(ns > 1 for m, ns in zip(d['conv_wino_ms'], d['conv_nsrc']) if m)
+    assert set(ref['conv_wino_ms']) == {0} and set(docs['f16_wino2_ibbbp_t7']['conv_wino_ms']) == {0}
     # one launch per branch and frame makes the 8 images of the expert-mixed convs: 14 more launches than the direct schedule
     assert d['launches_first_forward'] == ref['launches_first_forward'] + 14
     assert set(docs['f32_wino1_ibbbp_t7']['conv_wino']) == {0}                   # 24 tiles: below the threshold
