@@ -20,7 +20,12 @@ EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize'],
                # conv_wino.hip (r05): the same signature a third time -- with v_pk_{add,mul}_f32 in the epilogue / the input transform, a few
                # fixed (lane, register) slots of the output came out wrong, deterministically, and moved when unrelated code moved
                # (tools/repro/wino_packed_f32_hazard.py; profiles/r05_wino_packed_f32_hazard.txt).  The kernel is built without packed fp32 VALU ops at all
-               'conv_wino.hip': ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']}
+               #   -pragma-unroll-threshold: the K loop of a tile is ~1200 MFMAs unrolled from `#pragma unroll` loops; past LLVM's default
+               #   limit of 16384 (estimated) instructions a loop silently stays rolled, the accumulator array gets indexed dynamically
+               #   and lands in scratch MEMORY (private_segment 1616 B, results right, ten times slower).  That is what "source orders
+               #   hipcc does not like" were in DESIGN.md 8; with the limit out of the way partial effects go too (22 -> 13, 65 -> 46
+               #   spill slots in the residual kernels)
+               'conv_wino.hip': ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops', '-mllvm', '-pragma-unroll-threshold=1000000']}
 
 
 def _stale(target, deps):

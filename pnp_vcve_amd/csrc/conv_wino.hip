@@ -66,6 +66,12 @@ __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff,
 __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
+// Float4 sums written element by element.  As `a - b` on the vector type the four lanes stay one 128-bit value and the register
+// allocator needs an aligned quad for every intermediate of the rolling input transform; as four scalar ops they are independent
+// 32-bit values: 13 instead of 33 / 37 spill slots in the plain kernels, back half 373 -> 351 us, conv_hr 336 -> 318 us (same session).
+// The branch kernels pin V as quads anyway (asm volatile "+v") and lose 1.4 % with this form: they keep the vector ops.
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) { return f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]}; }
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { return f32x4{a[0] - b[0], a[1] - b[1], a[2] - b[2], a[3] - b[3]}; }
 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the weight / halo requests kept in flight
 __device__ __forceinline__ void lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -468,11 +474,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         }
                         if (g >= 36 && g < 40) {                 // first the row combination ...
                             const int c = g - 36;
-                            tt[c] = TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
+                            tt[c] = TR == 0 ? sub4(d0[c], d2[c]) : (TR == 1 ? add4(d1[c], d2[c]) : (TR == 2 ? sub4(d2[c], d1[c]) : sub4(d1[c], d3[c])));
                         }
                         if (g >= 40 && g < 44) {                 // ... then the column combination
                             const int c = g - 40;
-                            V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
+                            V[4 * TR + c] = c == 0 ? sub4(tt[0], tt[2]) : (c == 1 ? add4(tt[1], tt[2]) : (c == 2 ? sub4(tt[2], tt[1]) : sub4(tt[1], tt[3])));
                         }
                     }
                     if (g >= 52 && g < 52 + NRING) {
