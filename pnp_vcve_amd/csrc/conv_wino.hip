@@ -365,7 +365,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     const f32x4 pv = lds4(PV_B + tq * 48 + J * 16);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 ax = (q == 0 ? d1[1] : (q == 1 ? d1[2] : (q == 2 ? d2[1] : d2[2]))) * pv[q];
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 ax = (q == 0 ? d1[1] : (q == 1 ? d1[2] : (q == 2 ? d2[1] : d2[2]))) * pv[q];
+                        // (all four products in ONE gap: left alone each v_mul sits in front of its first MFMA, and a gap with any VALU
+                        //  instruction costs ~20 cycles of matrix time before the 4 per instruction)
+                        asm volatile("" : "+v"(ax));
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 //      clusters the loads, the LDS traffic and the transform in front of and behind the MFMAs) --
                 //        gaps 0-3 of every position: the B fragments of the next position (across the chunk seam too)
                 //        gaps 4-7: the weight requests;  8-10: halo pieces requested a chunk ago -> LDS;  11-13: halo requests
-                //        gaps 16-23: the rolling input transform (one float4 add each);  28-35: patch rows of step S + 1
+                //        gaps 36-43 (branch kernels: 16, 17): the rolling input transform;  20-27 (28-35): patch rows of step S + 1
                 //        gaps 52-55: the weight chunk requested at the top -> ring
                 using SN = I<(S + 1) & 3>;
                 constexpr int NRING = NBR ? 3 : 4;
@@ -450,12 +455,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     // where nothing overlaps them: 96 VALU instructions per branch chunk in the first PAR build).  Plain kernels: the
                     // same source order makes hipcc keep `acc` and `V` in scratch MEMORY (private_seg_size 1616, ten times slower), and
                     // the pin costs the back half 8 %: they keep reads first, transform second, unpinned.
+                    //   The branch kernels do the 32 adds in TWO gaps (16 + 16): a gap with any vector-ALU instruction in it costs ~9-20
+                    // cycles of matrix time before the 4 per instruction (tools/ubench/ub_valu_gap.hip; front half 427 -> 423 us).  The
+                    // plain kernels keep one float4 per gap: lumped, the residual kernel spills 22 instead of 13 registers (+3 %).
                     if constexpr (PAR) {
-                        if (g >= 16 && g < 20) tt[g - 16] = TR == 0 ? d0[g - 16] - d2[g - 16] : (TR == 1 ? d1[g - 16] + d2[g - 16] : (TR == 2 ? d2[g - 16] - d1[g - 16] : d1[g - 16] - d3[g - 16]));
-                        if (g >= 20 && g < 24) {
-                            const int c = g - 20;
-                            V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
-                            asm volatile("" : "+v"(V[4 * TR + c]));
+                        if (g == 16) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) tt[c] = TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
+                        }
+                        if (g == 17) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
+                                asm volatile("" : "+v"(V[4 * TR + c]));
+                            }
                         }
                         if (g >= 28 && g < 36) {                 // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
                             const int c = (g - 28) & 3;
