@@ -49,6 +49,9 @@ constexpr int PV_B = RING_B + 4 * SLAB_B;      // per thread 3 float4: the parti
 constexpr int BG_B = PV_B + 256 * 48;         // 64 floats: bias * gamma
 constexpr int WINO_LDS = BG_B + 256;          // 161024
 constexpr unsigned OOBW = 0xFFFFFFF0u;
+#ifndef WINO_QUAD
+#define WINO_QUAD 1      // A/B switch of the quadrant units (conv3x3_wino_kernel's tail)
+#endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, unsigned bytes) {
@@ -93,6 +96,7 @@ struct WinoArgs {
     int nsrc;               // 1..3
     const float* rgb;       // the frame as (H,W,4) RGB0
     const float* Urgb;      // launch_wino_rgb_image: 4 chunks of 4 KiB
+    int quad;               // the tiles beyond an XCD band's whole rounds are worked on as four 8x8 quadrants by four blocks (see the kernel's tail)
 };
 
 template <bool PAR, bool RES, bool MS>
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const int tiles_x = (W + 15) >> 4, ntiles = tiles_x * ((H + 15) >> 4);
 
     // ---- strip of tiles: XCD x owns a contiguous band, dealt round-robin to its resident blocks (neighbouring halos share its L2)
-    int tile, tstep, tend;
+    int tile, tstep, tend, qtile = -1, qquad = 0;
     if ((gridDim.x & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int bq = ntiles >> 3, br = ntiles & 7;
@@ -113,6 +117,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         tend = xbeg + bq + (xcd < br ? 1 : 0);
         tile = xbeg + slot;
         tstep = gridDim.x >> 3;
+        // 720p: 450 tiles per band on 32 blocks = 14 rounds + 2 tiles, i.e. a fifteenth round with 2 of 32 CUs busy (-6 %).  Those
+        // L tiles are cut into 4 L quadrant units instead, one per block, worked on behind the block's last whole tile with the four
+        // waves splitting the output channels (a quarter of a tile's MFMAs per wave): the tail costs a third of a round
+        const int nband = tend - xbeg, rounds = nband / tstep, left = nband - rounds * tstep;
+        if (!MS && a.quad && rounds >= 1 && left > 0 && 4 * left <= tstep) {
+            tend = xbeg + rounds * tstep;
+            if (slot < 4 * left) {
+                qtile = tend + (slot >> 2);
+                qquad = slot & 3;
+            }
+        }
     } else {
         tile = blockIdx.x;
         tstep = gridDim.x;
@@ -317,7 +332,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         asm volatile("" : "+v"(tq));
         const int ntile = tile + tstep;
         const bool has_next = ntile < tend;
-        const int nty0 = has_next ? (ntile / tiles_x) * 16 : ty0, ntx0 = has_next ? (ntile % tiles_x) * 16 : tx0;
+        // (behind the block's last whole tile the "next tile" of the halo pipeline is the tile its quadrant unit belongs to)
+        const int ptile = has_next ? ntile : (qtile >= 0 ? qtile : tile);
+        const int nty0 = (ptile / tiles_x) * 16, ntx0 = (ptile % tiles_x) * 16;
         const unsigned nso = (unsigned)(nty0 * W + ntx0) * 256u;
         if constexpr (!MS) halo_offsets(tq, nty0, ntx0);
         const unsigned tq16 = (unsigned)tq * 16u;
@@ -678,6 +695,140 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         ty0 = nty0;
         tx0 = ntx0;
     }
+    // ---- quadrant unit (see the strip assignment): 8x8 pixels of tile qtile, wave w = output channels 16 w .. + 15.  Same arithmetic
+    // in the same order as a whole tile -- per accumulator: branches, then the position's 4 k-steps, step by step; bias through the C
+    // operand of position (1,1) -- so a pixel's value does not depend on which form computed it (bit for bit; tested).  Straight-line code:
+    // the patch comes out of the slabs (the last whole tile's K loop fetched this tile's halo as its "next tile"), the B fragments straight
+    // from L2 into registers, a step ahead (a wave reads only its own N tile's).
+    if constexpr (!MS) {
+        const int qy0 = (qtile / tiles_x) * 16 + 8 * (qquad >> 1), qx0 = (qtile % tiles_x) * 16 + 8 * (qquad & 1);
+        if (qtile >= 0 && qy0 < H && qx0 < W) {
+            // (its tile's halo is in the slabs already: the last whole tile's K loop fetched it as "the next tile")
+            const int tyq = m >> 2, txq = m & 3;
+            const unsigned wq16 = (unsigned)lane * 16u + (unsigned)wave * 1024u;
+            // partition values of the lane's tile (as pv_request / pv_finish) and the branches the unit needs
+            float pq[3][4];
+            int needq = 7;
+            if constexpr (PAR) {
+                int nz_any = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    bool nz = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gy = qy0 + 2 * tyq + (q >> 1), gx = qx0 + 2 * txq + (q & 1);
+                        const float v = (gy < H && gx < W) ? a.par[(long)j * a.par_plane + (long)gy * W + gx] : 0.f;
+                        nz = nz || v != 0.f;
+                        pq[j][q] = (q == 1 || q == 2) ? -v : v;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(nz) != 0) nz_any |= 1 << j;
+                }
+                if (a.par_flags) needq = __builtin_amdgcn_readfirstlane(nz_any);
+            }
+            const unsigned qb0 = RING_B + ((2 * (4 * (qquad >> 1) + tyq)) * HP + 4 * (qquad & 1) + txq) * 64 + kq * 16, qb1 = qb0 + 2 * SLAB_B;
+            float resq[16];
+            if constexpr (RES) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gy = qy0 + 2 * kq + (q >> 1), gx = qx0 + 2 * r + (q & 1);
+                        resq[q * 4 + r] = (gy < H && gx < W) ? a.residual[((long)gy * W + gx) * 64 + wave * 16 + m] : 0.f;
+                    }
+            }
+            const float bgq = *reinterpret_cast<const float*>(smem + BG_B + (m * 4 + wave) * 4);
+            f32x4 Bq[16], Bn[16], Bp[3][2];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) Bq[p] = bload4(r_u, wq16, (unsigned)((p >> 2) * 16384 + (p & 3) * 4096));
+            if constexpr (PAR) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Bp[j][0] = bload4(r_up, wq16, (unsigned)(j * 4096));
+#pragma unroll
+                for (int n = 0; n < 1; ++n) acc[0][0] = acc[3][0] = acc[12][0] = acc[15][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 < 3) {
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) Bn[p] = bload4(r_u, wq16, (unsigned)(((s4 + 1) * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
+                    if constexpr (PAR) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) Bp[j][(s4 + 1) & 1] = bload4(r_up, wq16, (unsigned)((s4 + 1) * 12288 + j * 4096));
+                    }
+                }
+                f32x4 dq[4][4], tq4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        dq[r][c] = lds4((s4 < 2 ? qb0 : qb1) + (s4 & 1) * SLAB_B + (r * HP + (c & 1) * 9 + (c >> 1)) * 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tq4[c] = i == 0 ? dq[0][c] - dq[2][c] : (i == 1 ? dq[1][c] + dq[2][c] : (i == 2 ? dq[2][c] - dq[1][c] : dq[1][c] - dq[3][c]));
+                    V[4 * i + 0] = tq4[0] - tq4[2];
+                    V[4 * i + 1] = tq4[1] + tq4[2];
+                    V[4 * i + 2] = tq4[2] - tq4[1];
+                    V[4 * i + 3] = tq4[1] - tq4[3];
+                }
+                if constexpr (PAR) {
+                    auto qbranch = [&](auto j_c) {
+                        constexpr int J = decltype(j_c)::value;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 ax = (q == 0 ? dq[1][1] : (q == 1 ? dq[1][2] : (q == 2 ? dq[2][1] : dq[2][2]))) * pq[J][q];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                f32x4& ac = q == 0 ? acc[0][0] : (q == 1 ? acc[3][0] : (q == 2 ? acc[12][0] : acc[15][0]));
+                                ac = mfma16(ax[k], Bp[J][s4 & 1][k], ac);
+                            }
+                        }
+                    };
+                    if (needq & 1) qbranch(I<0>{});
+                    if (needq & 2) qbranch(I<1>{});
+                    if (needq & 4) qbranch(I<2>{});
+                }
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool fresh = s4 == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
+                        const f32x4 c0 = p == 5 ? f32x4{bgq, bgq, bgq, bgq} : f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[p][0] = mfma16(V[p][k], Bq[p][k], fresh ? c0 : acc[p][0]);
+                    }
+                if (s4 < 3) {
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) Bq[p] = Bn[p];
+                }
+            }
+            // output transform, activation, residual, 4-B stores (a wave instruction writes 64 B of four pixels)
+            f32x4 w0[4], w1[4], yq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w0[i] = acc[i * 4 + 0][0] + acc[i * 4 + 1][0] + acc[i * 4 + 2][0];
+                w1[i] = acc[i * 4 + 1][0] - acc[i * 4 + 2][0] - acc[i * 4 + 3][0];
+            }
+            yq[0] = w0[0] + w0[1] + w0[2];
+            yq[1] = w1[0] + w1[1] + w1[2];
+            yq[2] = w0[1] - w0[2] - w0[3];
+            yq[3] = w1[1] - w1[2] - w1[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                yq[q] = __builtin_elementwise_max(yq[q], act_lo * yq[q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = qy0 + 2 * kq + (q >> 1), gx = qx0 + 2 * r + (q & 1);
+                    if (gy < H && gx < W) {
+                        const long o = ((long)gy * W + gx) * 64 + wave * 16 + m;
+                        float v = yq[q][r];
+                        if (RES) v += resq[q * 4 + r];
+                        a.out[o] = v;
+                    }
+                }
+            }
+        }
+    }
     if (a.dbg && t == 0) {
         unsigned long long* d = a.dbg + (size_t)blockIdx.x * 16;
         d[0] = dbg_t0;
@@ -835,6 +986,7 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
     w.W = a.W;
     w.act = a.act;
     w.dbg = a.dbg;
+    w.quad = WINO_QUAD;
     const int ntiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     int grid = ntiles < cus ? ntiles : cus;                 // one resident block per CU
     if (grid >= 8) grid -= grid % 8;
