@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         dbg_r0 = __builtin_amdgcn_s_memrealtime();
     }
     int dbg_n = 0;
+    unsigned long long dbg_q0 = 0, dbg_q1 = 0, dbg_q2 = 0;
     int tq = t;
     for (;;) {
         asm volatile("" : "+v"(tq));
@@ -629,7 +630,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         const unsigned so = (unsigned)(ty0 * W + tx0) * 256u;
         const bool partial = ty0 + 16 > H || tx0 + 16 > W;
         lds_bar();                       // every wave has read its last fragments out of slot 3
-        pv_request(tq, nty0, ntx0);
+        // (next = the block's quadrant unit: every wave fetches quadrant qquad's values)
+        const int tqp = (!has_next && qtile >= 0) ? ((qquad << 6) | (tq & 63)) : tq;
+        pv_request(tqp, nty0, ntx0);
         auto epilogue = [&](auto partial_c) {
             constexpr bool PARTIAL = decltype(partial_c)::value;
             const int lq = tq & 63, wq = tq >> 6, kqq = lq >> 4, mq = lq & 15;
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         };
         if (partial) epilogue(std::true_type{});
         else epilogue(std::false_type{});
-        pv_finish(tq);
+        pv_finish(tqp);
         ++dbg_n;
         if (a.dbg) dbg_e += __builtin_amdgcn_s_memtime() - dbg_b;
         if (!has_next) break;
@@ -704,57 +707,48 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         const int qy0 = (qtile / tiles_x) * 16 + 8 * (qquad >> 1), qx0 = (qtile % tiles_x) * 16 + 8 * (qquad & 1);
         if (qtile >= 0 && qy0 < H && qx0 < W) {
             // (its tile's halo is in the slabs already: the last whole tile's K loop fetched it as "the next tile")
+            if (a.dbg) dbg_q0 = __builtin_amdgcn_s_memtime();
             const int tyq = m >> 2, txq = m & 3;
             const unsigned wq16 = (unsigned)lane * 16u + (unsigned)wave * 1024u;
-            // partition values of the lane's tile (as pv_request / pv_finish) and the branches the unit needs
-            float pq[3][4];
-            int needq = 7;
-            if constexpr (PAR) {
-                int nz_any = 0;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    bool nz = false;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int gy = qy0 + 2 * tyq + (q >> 1), gx = qx0 + 2 * txq + (q & 1);
-                        const float v = (gy < H && gx < W) ? a.par[(long)j * a.par_plane + (long)gy * W + gx] : 0.f;
-                        nz = nz || v != 0.f;
-                        pq[j][q] = (q == 1 || q == 2) ? -v : v;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(nz) != 0) nz_any |= 1 << j;
-                }
-                if (a.par_flags) needq = __builtin_amdgcn_readfirstlane(nz_any);
-            }
             const unsigned qb0 = RING_B + ((2 * (4 * (qquad >> 1) + tyq)) * HP + 4 * (qquad & 1) + txq) * 64 + kq * 16, qb1 = qb0 + 2 * SLAB_B;
+            // B fragments of step 0 first (the first MFMAs wait for these only), then the residual values
+            f32x4 Bq[2][16], Bp[2][3];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) Bq[0][p] = bload4(r_u, wq16, (unsigned)((p >> 2) * 16384 + (p & 3) * 4096));
+            if constexpr (PAR) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Bp[0][j] = bload4(r_up, wq16, (unsigned)(j * 4096));
+            }
+            // output offsets of the lane's 16 values: value (q = 2 a + b, r) is pixel (2 kq + a, 2 r + b) of the quadrant, channel 16 w + m
+            const unsigned qo = (unsigned)((qy0 + 2 * kq) * W + qx0) * 256u + (unsigned)(wave * 16 + m) * 4u;
             float resq[16];
             if constexpr (RES) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int gy = qy0 + 2 * kq + (q >> 1), gx = qx0 + 2 * r + (q & 1);
-                        resq[q * 4 + r] = (gy < H && gx < W) ? a.residual[((long)gy * W + gx) * 64 + wave * 16 + m] : 0.f;
+                        const bool inq = qy0 + 2 * kq + (q >> 1) < H && qx0 + 2 * r + (q & 1) < W;
+                        resq[q * 4 + r] = bload1(r_res, inq ? qo : OOBW, (unsigned)((q >> 1) * W + 2 * r + (q & 1)) * 256u);
                     }
             }
             const float bgq = *reinterpret_cast<const float*>(smem + BG_B + (m * 4 + wave) * 4);
-            f32x4 Bq[16], Bn[16], Bp[3][2];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) Bq[p] = bload4(r_u, wq16, (unsigned)((p >> 2) * 16384 + (p & 3) * 4096));
             if constexpr (PAR) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) Bp[j][0] = bload4(r_up, wq16, (unsigned)(j * 4096));
 #pragma unroll
                 for (int n = 0; n < 1; ++n) acc[0][0] = acc[3][0] = acc[12][0] = acc[15][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            __syncthreads();
+            lds_bar();       // (the slabs are complete and every wave is out of the last epilogue; the requests above stay in flight)
+            if (a.dbg) dbg_q1 = __builtin_amdgcn_s_memtime();
+            // the partition values and the branch decision of this quadrant came through the tile pipeline (pv_request / pv_finish with
+            // every wave on quadrant qquad)
+            const int needq = (PAR && a.par_flags) ? __builtin_amdgcn_readfirstlane(need_next) : 7;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if (s4 < 3) {
 #pragma unroll
-                    for (int p = 0; p < 16; ++p) Bn[p] = bload4(r_u, wq16, (unsigned)(((s4 + 1) * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
+                    for (int p = 0; p < 16; ++p) Bq[(s4 + 1) & 1][p] = bload4(r_u, wq16, (unsigned)(((s4 + 1) * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
                     if constexpr (PAR) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) Bp[j][(s4 + 1) & 1] = bload4(r_up, wq16, (unsigned)((s4 + 1) * 12288 + j * 4096));
+                        for (int j = 0; j < 3; ++j) Bp[(s4 + 1) & 1][j] = bload4(r_up, wq16, (unsigned)((s4 + 1) * 12288 + j * 4096));
                     }
                 }
                 f32x4 dq[4][4], tq4[4];
@@ -772,36 +766,48 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     V[4 * i + 2] = tq4[2] - tq4[1];
                     V[4 * i + 3] = tq4[1] - tq4[3];
                 }
+                // the whole transform first, then the MFMAs back to back: interleaved (what the scheduler does by itself) every MFMA gap
+                // holds 2-3 vector-ALU instructions and costs ~25 cycles of matrix time (tools/ubench/ub_valu_gap.hip)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(V[i]));
+                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (PAR) {
                     auto qbranch = [&](auto j_c) {
                         constexpr int J = decltype(j_c)::value;
+                        const f32x4 pv = lds4(PV_B + (unsigned)((qquad << 6) | lane) * 48 + J * 16);
+                        f32x4 ax[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const f32x4 ax = (q == 0 ? dq[1][1] : (q == 1 ? dq[1][2] : (q == 2 ? dq[2][1] : dq[2][2]))) * pq[J][q];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                f32x4& ac = q == 0 ? acc[0][0] : (q == 1 ? acc[3][0] : (q == 2 ? acc[12][0] : acc[15][0]));
-                                ac = mfma16(ax[k], Bp[J][s4 & 1][k], ac);
-                            }
+                            ax[q] = (q == 0 ? dq[1][1] : (q == 1 ? dq[1][2] : (q == 2 ? dq[2][1] : dq[2][2]))) * pv[q];
+                            asm volatile("" : "+v"(ax[q]));
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // (k outermost: four independent accumulators in a row; each one still sees its k-steps in order)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f32x4& ac = q == 0 ? acc[0][0] : (q == 1 ? acc[3][0] : (q == 2 ? acc[12][0] : acc[15][0]));
+                                ac = mfma16(ax[q][k], Bp[s4 & 1][J][k], ac);
+                            }
                     };
                     if (needq & 1) qbranch(I<0>{});
                     if (needq & 2) qbranch(I<1>{});
                     if (needq & 4) qbranch(I<2>{});
                 }
 #pragma unroll
-                for (int p = 0; p < 16; ++p)
+                for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const bool fresh = s4 == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
-                        const f32x4 c0 = p == 5 ? f32x4{bgq, bgq, bgq, bgq} : f32x4{0.f, 0.f, 0.f, 0.f};
-                        acc[p][0] = mfma16(V[p][k], Bq[p][k], fresh ? c0 : acc[p][0]);
-                    }
-                if (s4 < 3) {
+                    for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int p = 0; p < 16; ++p) Bq[p] = Bn[p];
-                }
+                        for (int pc = 0; pc < 4; ++pc) {
+                            const int p = pr * 4 + pc;
+                            const bool fresh = s4 == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
+                            const f32x4 c0 = p == 5 ? f32x4{bgq, bgq, bgq, bgq} : f32x4{0.f, 0.f, 0.f, 0.f};
+                            acc[p][0] = mfma16(V[p][k], Bq[s4 & 1][p][k], fresh ? c0 : acc[p][0]);
+                        }
             }
+            if (a.dbg) dbg_q2 = __builtin_amdgcn_s_memtime();
             // output transform, activation, residual, 4-B stores (a wave instruction writes 64 B of four pixels)
             f32x4 w0[4], w1[4], yq[4];
 #pragma unroll
@@ -818,13 +824,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 yq[q] = __builtin_elementwise_max(yq[q], act_lo * yq[q]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int gy = qy0 + 2 * kq + (q >> 1), gx = qx0 + 2 * r + (q & 1);
-                    if (gy < H && gx < W) {
-                        const long o = ((long)gy * W + gx) * 64 + wave * 16 + m;
-                        float v = yq[q][r];
-                        if (RES) v += resq[q * 4 + r];
-                        a.out[o] = v;
-                    }
+                    const bool inq = qy0 + 2 * kq + (q >> 1) < H && qx0 + 2 * r + (q & 1) < W;
+                    float v = yq[q][r];
+                    if (RES) v += resq[q * 4 + r];
+                    bstore1(r_out, inq ? qo : OOBW, (unsigned)((q >> 1) * W + 2 * r + (q & 1)) * 256u, v);
                 }
             }
         }
@@ -835,6 +838,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         d[1] = dbg_k;
         d[2] = dbg_e;
         d[3] = __builtin_amdgcn_s_memtime();
+        d[4] = dbg_q0;         // quadrant unit: start, first step, output transform (0: the block had none)
+        d[5] = dbg_q1;
+        d[6] = dbg_q2;
         d[7] = dbg_n;
         d[13] = dbg_r0;
         d[14] = __builtin_amdgcn_s_memrealtime();

@@ -56,6 +56,10 @@ def main():
               f'epilogue {np.median(d[:, 2] / n):7.0f}  (branch chunks {np.median(d[:, 8] / n):6.0f})  other {np.median((life - d[:, 1] - d[:, 2]) / n):6.0f}  '
               f'lifetime median {np.median(life):9.0f} max {life.max():9.0f} cycles  clock {np.median(clk):.2f} GHz  '
               f'launch {(d[:, 14].max() - d[:, 13].min()) * 10e-3:.1f} us', flush=True)
+        q = d[d[:, 4] > 0]
+        if len(q):      # blocks with a quadrant unit behind their last whole tile: wait for loads + barrier | four steps | output
+            print(f'{"":12s} quadrant units {len(q)}: start -> first step {np.median(q[:, 5] - q[:, 4]):6.0f} cycles, steps {np.median(q[:, 6] - q[:, 5]):6.0f}, '
+                  f'output {np.median(q[:, 3] - q[:, 6]):6.0f}; lifetime of these blocks {np.median(q[:, 3] - q[:, 0]):9.0f} vs the others {np.median((d[d[:, 4] == 0])[:, 3] - (d[d[:, 4] == 0])[:, 0]):9.0f}', flush=True)
 
 
 if __name__ == '__main__':
