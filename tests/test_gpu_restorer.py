@@ -217,10 +217,10 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
                 assert abs(rf['achieved'] - rf['achieved_wall']) < 1e-9
     assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm' and sec[5]['roofline']['bound'] == 'hbm'
     assert sec[2]['hip_graphs'] is True and sec[6]['vsr_x4_heads'] is True
-    assert sec[3]['value'] > 3 * d['value']       # fp16 operands at the headline shape: > 3x the fp32 rate
+    assert sec[3]['value'] > 2.8 * d['value']     # fp16 operands at the headline shape: ~3x the (Winograd) fp32 rate
     # split fp16 (fp32-level results, three fp16 MFMAs per product): priced on the matrix pipe, executed = 3 x algorithmic
     x3 = sec[4]
-    assert x3['dtype'].startswith('split f16') and x3['roofline']['bound'] == 'mfma' and x3['value'] > 1.8 * d['value']
+    assert x3['dtype'].startswith('split f16') and x3['roofline']['bound'] == 'mfma' and x3['value'] > 1.5 * d['value']
     assert x3['roofline']['achieved'] <= 3 * x3['roofline']['algorithmic_TFLOPs'] * 1.001
     assert abs(x3['psnr'] - d['psnr_per_rank'][0]) < 1e-3      # same clip, same weights: the fp32 headline's PSNR
     assert sec[7]['dtype'].startswith('split f16') and sec[7]['roofline']['bound'] == 'mfma' and abs(sec[7]['psnr'] - sec[0]['psnr']) < 1e-3
