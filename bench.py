@@ -124,7 +124,9 @@ def committed_pmc_traffic(tag):
 
 def _launch_weighted_traffic(pmc, prefix):
     """launch-weighted mean HBM bytes per launch over the kernel variants whose summarised name starts with `prefix`"""
-    ks = [v for k, v in pmc.items() if (k.startswith(prefix) or '::' + prefix in k) and 'hbm_bytes_per_launch' in v]
+    # (conv3x3_wino_kernel<PAR,RES,MS>: the multi-source instantiation is the input conv, not a block conv)
+    ks = [v for k, v in pmc.items() if (k.startswith(prefix) or '::' + prefix in k) and 'hbm_bytes_per_launch' in v
+          and not (prefix == 'conv3x3_wino_kernel' and k.replace(' ', '').endswith(',true>'))]
     if not ks:
         return None
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
