@@ -166,6 +166,44 @@ def test_wino_conv_720p_crop_consistency_scaling_and_determinism():
     assert float((got - ref[0, :, 1:-1, 1:-1]).abs().max()) < 1e-5
 
 
+def test_wino_quadrant_units_equal_whole_tiles_bit_for_bit():
+    """720p: an XCD band holds 450 tiles for 32 blocks = 14 whole rounds + 2 tiles, which are cut into 8 quadrant units (one per block,
+    the waves splitting the output channels).  The same pixels computed inside a 64x128 frame (one whole tile per block, no units) must
+    come out bit for bit the same: plain + activation, residual, partition branches with and without skipping; also on a frame whose
+    last tiles are ragged (quadrants partly or wholly outside the image)"""
+    from pnp_vcve_amd import ops
+    wt = torch.randn(64, 64, 3, 3, device=dev()) * 0.05
+    b = torch.randn(64, device=dev()) * 0.1
+    gamma = torch.rand(64, device=dev())
+    w1 = [torch.randn(64, 64, 1, 1, device=dev()) * 0.1 for _ in range(3)]
+    u, ug, up = ops.wino_image(ops.pack_conv3x3(wt)), ops.wino_image(ops.pack_conv3x3(wt), gamma), ops.wino_par_image(ops.pack_conv1x1(w1))
+    for h, w in ((720, 1280), (715, 1270)):
+        x = torch.randn(h, w, 64, device=dev())
+        res = torch.randn(h, w, 64, device=dev())
+        par = G(par_maps(31, h, w, 1.0 / 255.0))
+        tiles_x, ntiles = (w + 15) // 16, ((w + 15) // 16) * ((h + 15) // 16)
+        assert ntiles == 3600                                      # 8 bands of 450: tiles 448, 449 of every band are unit tiles
+        kinds = {
+            'plain': lambda xx, rr, pp, ff: ops.conv3x3_wino(xx, u, bias=b, act=2),
+            'residual': lambda xx, rr, pp, ff: ops.conv3x3_wino(xx, u, bias=b, residual=rr),
+            'branches': lambda xx, rr, pp, ff: ops.conv3x3_wino(xx, ug, bias=b, gamma=gamma, wino_w1x1=up, par=pp, par_flags=ff, act=1),
+            'branches, no skipping': lambda xx, rr, pp, ff: ops.conv3x3_wino(xx, ug, bias=b, gamma=gamma, wino_w1x1=up, par=pp, act=1),
+        }
+        for name, fn in kinds.items():
+            full = fn(x, res, par, ops.par_tile_flags(par))
+            for band in (0, 3, 7):
+                t0 = band * 450 + 448                               # the band's first unit tile (the second one is its right neighbour or wraps)
+                ty, tx = t0 // tiles_x, t0 % tiles_x
+                y0, x0 = max(0, 16 * ty - 16), max(0, min(16 * tx - 32, w - 128))      # (even offsets: the same 2x2 output tiles)
+                y1, x1 = min(h, y0 + 64), min(w, x0 + 128)
+                xc, rc, pc = x[y0:y1, x0:x1].contiguous(), res[y0:y1, x0:x1].contiguous(), par[:, y0:y1, x0:x1].contiguous()
+                crop = fn(xc, rc, pc, ops.par_tile_flags(pc))
+                # interior of the crop (its border row / column sees zeros where the frame has pixels), frame borders included
+                iy0, ix0 = (1 if y0 > 0 else 0), (1 if x0 > 0 else 0)
+                iy1, ix1 = (y1 - y0 - 1 if y1 < h else y1 - y0), (x1 - x0 - 1 if x1 < w else x1 - x0)
+                assert torch.equal(crop[iy0:iy1, ix0:ix1], full[y0 + iy0:y0 + iy1, x0 + ix0:x0 + ix1]), (name, h, w, band)
+
+
 @pytest.mark.parametrize('hw', [(16, 16), (40, 72), (37, 53), (128, 160)])
 @pytest.mark.parametrize('nwide', [1, 2, 3])
 def test_wino_input_conv_over_the_virtual_concat(hw, nwide):
