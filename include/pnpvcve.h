@@ -234,6 +234,12 @@ int pnp_conv3x3_wino_ms_f32(int nsrc, const float* const* srcs_dev, const float*
 int pnp_conv3x3_wino_f32(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
                          const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
                          const float* residual_dev, int act, float* out_dev, int h, int w, void* stream);
+/* The same conv with one block per 8x8 QUADRANT of a 16x16 tile (four waves = four 16-channel slices of the output): what
+ * pnp_generator_forward uses on frames too small to fill the chip with whole tiles (< 512 of them; PNP_OPT_WINOGRAD = 1).  Same
+ * arguments, same values bit for bit. */
+int pnp_conv3x3_wino_units_f32(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
+                               const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
+                               const float* residual_dev, int act, float* out_dev, int h, int w, void* stream);
 
 /* Which of the three 1x1 partition branches (sr_backbone_utils.py:310-311, Sum_j par_j * conv1x1_j(x)) an 8x16 pixel tile
  * needs at all: par_dev (3,h,w) -> flags_dev[((w+15)/16) * ((h+7)/8)] ints, bit j set iff plane j is nonzero somewhere in

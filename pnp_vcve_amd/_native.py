@@ -86,6 +86,7 @@ SIGNATURES = {
     'pnp_wino_image_from_packed_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'pnp_wino_par_image_from_packed_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
     'pnp_conv3x3_wino_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_int, c_int, c_void_p]),
+    'pnp_conv3x3_wino_units_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_int, c_int, c_void_p]),
     'pnp_conv3x3_f16x3': (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_void_p),
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_int, c_int, c_void_p]),

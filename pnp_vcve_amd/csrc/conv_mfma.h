@@ -14,6 +14,7 @@ struct ConvArgs {
     const float* wwino_par; // ... and of wpar (launch_wino_par_image; 12288 floats); required with wwino when wpar is set
     const float* wwino_src[4]; // the input conv in Winograd form (source 0 the RGB frame, then 1..3 64-channel sources): the image of
     const float* wwino_rgb;    // wsrc[s] for s >= 1 (launch_wino_images) and of the frame's chunk wsrc[0] (launch_wino_rgb_image)
+    int wino_units;            // with wwino: one block per 8x8 quadrant unit (conv3x3_wino_quad_kernel: frames too small to fill the chip with 16x16 tiles)
     const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
     const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo
                             // interleaved, twice the halfs; conv_f16x3.hip launch_f16x3_image)

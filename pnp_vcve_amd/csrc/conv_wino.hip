@@ -847,6 +847,175 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     }
 }
 
+// ---- small frames: every tile as four quadrant units -------------------------------------------------------------------------------
+// Below 512 tiles the persistent kernel above cannot fill the chip (128x128: 64 tiles for 256 CUs) and the direct kernel runs one
+// 4x16-pixel tile per CU (a 64 -> 64 conv = 9.6 us of MFMA in a 16 us launch).  Here block u works on quadrant u & 3 of tile u >> 2:
+// 8x8 pixels, the four waves splitting the output channels -- the arithmetic of the big kernel's tail units (bit for bit the same
+// values as a whole tile), as a kernel of its own: the 10x10x64 halo goes to LDS first, the B fragments come straight from L2 a step
+// ahead, 2.25x fewer matrix FLOPs than the direct form and four times as many blocks.
+template <bool PAR, bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArgs a) {
+    constexpr int QSTR = 272;                                // bytes per halo pixel in LDS (64 channels + 16: patch reads spread over banks)
+    __shared__ __attribute__((aligned(16))) char smem[100 * QSTR];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + 15) >> 4;
+    const int qtile = blockIdx.x >> 2, qquad = blockIdx.x & 3;
+    const int qy0 = (qtile / tiles_x) * 16 + 8 * (qquad >> 1), qx0 = (qtile % tiles_x) * 16 + 8 * (qquad & 1);
+    if (qy0 >= H || qx0 >= W) return;
+    const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
+    const __amdgpu_buffer_rsrc_t r_u = rsrc_of(a.U, 16u * 16384u);
+    const __amdgpu_buffer_rsrc_t r_up = rsrc_of(PAR ? a.Upar : a.U, 4u * 12288u);
+    const __amdgpu_buffer_rsrc_t r_out = rsrc_of(a.out, map_bytes);
+    const __amdgpu_buffer_rsrc_t r_res = rsrc_of(RES ? a.residual : a.src, RES ? map_bytes : 0u);
+    const float act_lo = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    {
+        f32x4 hv[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int e = t + 256 * i, pe = e >> 4, ry = pe / 10, rx = pe - ry * 10, gy = qy0 - 1 + ry, gx = qx0 - 1 + rx;
+            hv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < 1600 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                hv[i] = *reinterpret_cast<const f32x4*>(a.src + ((long)gy * W + gx) * 64 + (e & 15) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int e = t + 256 * i;
+            if (e < 1600) *reinterpret_cast<f32x4*>(smem + (e >> 4) * QSTR + (e & 15) * 16) = hv[i];
+        }
+    }
+    const int tyq = m >> 2, txq = m & 3;
+    const unsigned wq16 = (unsigned)lane * 16u + (unsigned)wave * 1024u;
+    f32x4 Bq[2][16], Bp[2][3];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) Bq[0][p] = bload4(r_u, wq16, (unsigned)((p >> 2) * 16384 + (p & 3) * 4096));
+    if constexpr (PAR) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Bp[0][j] = bload4(r_up, wq16, (unsigned)(j * 4096));
+    }
+    // partition values of the lane's tile, signed as the output transform wants them (positions (0,3), (3,0) negated), and the branches
+    // the unit needs at all (a plane that is zero on all 64 pixels adds exact zeros)
+    float pq[3][4];
+    int needq = 7;
+    if constexpr (PAR) {
+        int nz_any = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bool nz = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gy = qy0 + 2 * tyq + (q >> 1), gx = qx0 + 2 * txq + (q & 1);
+                const float v = (gy < H && gx < W) ? a.par[(long)j * a.par_plane + (long)gy * W + gx] : 0.f;
+                nz = nz || v != 0.f;
+                pq[j][q] = (q == 1 || q == 2) ? -v : v;
+            }
+            if (__builtin_amdgcn_ballot_w64(nz) != 0) nz_any |= 1 << j;
+        }
+        if (a.par_flags) needq = __builtin_amdgcn_readfirstlane(nz_any);
+    }
+    const unsigned qo = (unsigned)((qy0 + 2 * kq) * W + qx0) * 256u + (unsigned)(wave * 16 + m) * 4u;
+    float resq[16];
+    if constexpr (RES) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool inq = qy0 + 2 * kq + (q >> 1) < H && qx0 + 2 * r + (q & 1) < W;
+                resq[q * 4 + r] = bload1(r_res, inq ? qo : OOBW, (unsigned)((q >> 1) * W + 2 * r + (q & 1)) * 256u);
+            }
+    }
+    const int co = wave * 16 + m;
+    const float bgq = (a.bias ? a.bias[co] : 0.f) * (a.gamma ? a.gamma[co] : 1.f);
+    f32x4 acc[16], V[16];
+    if constexpr (PAR) acc[0] = acc[3] = acc[12] = acc[15] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lds_bar();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 < 3) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) Bq[(s4 + 1) & 1][p] = bload4(r_u, wq16, (unsigned)(((s4 + 1) * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
+            if constexpr (PAR) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Bp[(s4 + 1) & 1][j] = bload4(r_up, wq16, (unsigned)((s4 + 1) * 12288 + j * 4096));
+            }
+        }
+        f32x4 dq[4][4], tq4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                dq[r][c] = *reinterpret_cast<const f32x4*>(smem + ((2 * tyq + r) * 10 + 2 * txq + c) * QSTR + (16 * s4 + 4 * kq) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tq4[c] = i == 0 ? dq[0][c] - dq[2][c] : (i == 1 ? dq[1][c] + dq[2][c] : (i == 2 ? dq[2][c] - dq[1][c] : dq[1][c] - dq[3][c]));
+            V[4 * i + 0] = tq4[0] - tq4[2];
+            V[4 * i + 1] = tq4[1] + tq4[2];
+            V[4 * i + 2] = tq4[2] - tq4[1];
+            V[4 * i + 3] = tq4[1] - tq4[3];
+        }
+        // (the whole transform first, then the MFMAs back to back: see the tail units above)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(V[i]));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PAR) {
+            auto qbranch = [&](auto j_c) {
+                constexpr int J = decltype(j_c)::value;
+                f32x4 ax[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ax[q] = (q == 0 ? dq[1][1] : (q == 1 ? dq[1][2] : (q == 2 ? dq[2][1] : dq[2][2]))) * pq[J][q];
+                    asm volatile("" : "+v"(ax[q]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4& ac = q == 0 ? acc[0] : (q == 1 ? acc[3] : (q == 2 ? acc[12] : acc[15]));
+                        ac = mfma16(ax[q][k], Bp[s4 & 1][J][k], ac);
+                    }
+            };
+            if (needq & 1) qbranch(I<0>{});
+            if (needq & 2) qbranch(I<1>{});
+            if (needq & 4) qbranch(I<2>{});
+        }
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc) {
+                    const int p = pr * 4 + pc;
+                    const bool fresh = s4 == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
+                    const f32x4 c0 = p == 5 ? f32x4{bgq, bgq, bgq, bgq} : f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[p] = mfma16(V[p][k], Bq[s4 & 1][p][k], fresh ? c0 : acc[p]);
+                }
+    }
+    f32x4 w0[4], w1[4], yq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w0[i] = acc[i * 4 + 0] + acc[i * 4 + 1] + acc[i * 4 + 2];
+        w1[i] = acc[i * 4 + 1] - acc[i * 4 + 2] - acc[i * 4 + 3];
+    }
+    yq[0] = w0[0] + w0[1] + w0[2];
+    yq[1] = w1[0] + w1[1] + w1[2];
+    yq[2] = w0[1] - w0[2] - w0[3];
+    yq[3] = w1[1] - w1[2] - w1[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        yq[q] = __builtin_elementwise_max(yq[q], act_lo * yq[q]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool inq = qy0 + 2 * kq + (q >> 1) < H && qx0 + 2 * r + (q & 1) < W;
+            float v = yq[q][r];
+            if (RES) v += resq[q * 4 + r];
+            bstore1(r_out, inq ? qo : OOBW, (unsigned)((q >> 1) * W + 2 * r + (q & 1)) * 256u, v);
+        }
+    }
+}
+
 // ---- weight images ------------------------------------------------------------------------------------------------------------
 // U = G g G^T per (output channel, input channel), times gamma[co] when given (see launch_wino_images), from a packed direct-conv
 // B image (common.h: 9 chunks, chunk = tap; float index ((q * 2 + nt32) * 64 + h * 32 + n32) * 4 + j  <->  ci = 8 q + 4 h + j,
@@ -994,6 +1163,14 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
     w.dbg = a.dbg;
     w.quad = WINO_QUAD;
     const int ntiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
+    if (a.wino_units && a.wwino) {                          // small frames: one block per quadrant unit
+        const dim3 gq(4 * ntiles), bq(256);
+        if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_quad_kernel<true, true>), gq, bq, 0, stream, w);
+        else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_quad_kernel<true, false>), gq, bq, 0, stream, w);
+        else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_quad_kernel<false, true>), gq, bq, 0, stream, w);
+        else hipLaunchKernelGGL((conv3x3_wino_quad_kernel<false, false>), gq, bq, 0, stream, w);
+        return (int)hipGetLastError();
+    }
     int grid = ntiles < cus ? ntiles : cus;                 // one resident block per CU
     if (grid >= 8) grid -= grid % 8;
     if (conv_wino_ms_eligible(a, CONV_CFG_BIG, 1) && !a.wwino) {

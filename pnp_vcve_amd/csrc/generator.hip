@@ -368,6 +368,8 @@ struct ConvCall {
     // Winograd images of the (single) source's weights and of the branch weights; nullptr = the direct kernels
     const float *wino_ = nullptr, *wino_par_ = nullptr;
     ConvCall& wino(const float* u, const float* upar = nullptr) { wino_ = u; wino_par_ = upar; return *this; }
+    int units_ = 0;
+    ConvCall& units(bool on) { units_ = on ? 1 : 0; return *this; }      // with wino(): one block per 8x8 quadrant unit (small frames)
     ConvCall& act(int a) { act_ = a; return *this; }                      // 0 none, 1 relu, 2 leaky-relu(0.1)
     ConvCall& to(float* d) { dst = d; return *this; }
     // out_mode of conv_mfma.h with `gy` weight images `w_ystride` floats apart (pixel shuffle: 4, DCN offsets: 7)
@@ -687,7 +689,13 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     const bool par_skip = g->opt[PNP_OPT_PAR_SKIP] != 0;
     // Winograd form of the single-source 64 -> 64 convs (fp32 path only): 1 = frames that fill the chip with 16x16 tiles, 2 = always
     const int wopt = g->prec == PNP_PREC_F32 ? g->opt[PNP_OPT_WINOGRAD] : 0;
-    auto wino_ok = [&](int hh, int ww) { return wopt == 2 || (wopt == 1 && (int64_t)((hh + 15) / 16) * ((ww + 15) / 16) >= 512); };
+    // 1: a frame of N 16x16 tiles takes the quadrant-unit kernel up to N = 128 (4 N blocks; 128x128: 12 us per conv against the direct
+    // kernel's 15 and the tile kernel's 26 on 64 of 256 CUs) and the persistent tile kernel above (240 tiles: 31 us against 48 direct);
+    // the input convs keep the direct kernels below 512 tiles.  2 = the tile kernel at every size (tests)
+    auto ntiles16 = [](int hh, int ww) { return (int64_t)((hh + 15) / 16) * ((ww + 15) / 16); };
+    auto wino_ok = [&](int hh, int ww) { return wopt == 2 || wopt == 1; };
+    auto wino_units = [&](int hh, int ww) { return wopt == 1 && ntiles16(hh, ww) <= 128; };
+    auto wino_ms_ok = [&](int hh, int ww) { return wopt == 2 || (wopt == 1 && ntiles16(hh, ww) >= 512); };
     // every 64-channel map that is only read as an MFMA A operand gets an fp16 copy from its producer
     const bool mirrors = f16_maps && g->opt[PNP_OPT_F16_MIRRORS] && c.deform == 0 && W.x16 != nullptr;
     // ... and, optionally, the running map x INSIDE a branch too (input conv and every block write x16 next to x, every front
@@ -708,6 +716,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.wpar = q.wpar_;
         a.wwino = q.wino_;
         a.wwino_par = q.wino_par_;
+        a.wino_units = q.wino_ ? q.units_ : 0;
         if (q.nsrc >= 2 && q.sc[0] == 4 && q.wsrc_wino_[0]) {      // input conv with Winograd images on every member
             a.wwino_rgb = q.wsrc_wino_[0];
             for (int s = 1; s < q.nsrc; ++s) a.wwino_src[s] = q.wsrc_wino_[s];
@@ -913,7 +922,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0).also16(const_cast<void*>(x16)));
             if (r) return r;
             const float* x = W.tmp0;
-            const bool wino = wino_ok(h, w);
+            const bool wino = wino_ok(h, w), un = wino_units(h, w);
             if (wino && g->ndyn > 0) {      // this frame's Winograd images of the branch's expert-mixed convs, its channel gain folded in
                 std::vector<const float*> ws;
                 std::vector<float*> wd;
@@ -949,16 +958,16 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
                     r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(g2)
-                                 .partition(packed + K.w1x1, parp, pflags).wino(u2, up).act(1).to(W.tmp1).f16_map(o16));
+                                 .partition(packed + K.w1x1, parp, pflags).wino(u2, up).units(un).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
-                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).wino(u1).residual(x).to(dst)
+                        r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).wino(u1).units(un).residual(x).to(dst)
                                      .f16_map(s16).also16(dst16));
                 } else {                 // sr_backbone_utils.py:314-327
-                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).mirror16(x16).bias(b1).gamma(g1).wino(u1).act(1).to(W.tmp1)
+                    r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w1).mirror16(x16).bias(b1).gamma(g1).wino(u1).units(un).act(1).to(W.tmp1)
                                  .f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(g2)
-                                     .partition(packed + K.w1x1, parp, pflags).wino(u2, up).residual(x).to(dst).f16_map(s16).also16(dst16));
+                                     .partition(packed + K.w1x1, parp, pflags).wino(u2, up).units(un).residual(x).to(dst).f16_map(s16).also16(dst16));
                 }
                 if (r) return r;
                 x = dst;
@@ -975,7 +984,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         for (int i = t - 1; i >= 0; --i) {
             const BranchPk& B = g->br[0];
             ConvCall in(h, w, cfg_lr);
-            const bool wn = wino_ok(h, w);
+            const bool wn = wino_ms_ok(h, w);
             auto wi = [&](int64_t off) -> const float* { return wn ? packed + off : nullptr; };
             in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr, wi(B.in_lr_wino));
             if (i < t - 1) {
@@ -997,7 +1006,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         for (int i = 0; i < t; ++i) {
             const BranchPk& B = g->br[1];
             ConvCall in(h, w, cfg_lr);
-            const bool wn = wino_ok(h, w);
+            const bool wn = wino_ms_ok(h, w);
             auto wi = [&](int64_t off) -> const float* { return wn ? packed + off : nullptr; };
             in.source(W.lr4 + (int64_t)i * hw * 4, 4, packed + B.in_lr, wi(B.in_lr_wino));
             if (i > 0) {
@@ -1023,7 +1032,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
             if (!c.vsr) {   // :144-146
                 rc = conv(ConvCall(h, w, cfg_lr).source(feat, 64, packed + g->hr_img).mirror16(s16of(i)).bias(flat + g->hr_bias)
-                              .wino(wino_ok(h, w) ? packed + g->hr_wino : nullptr).act(2).to(W.tmp1).f16_map(o16));
+                              .wino(wino_ok(h, w) ? packed + g->hr_wino : nullptr).units(wino_units(h, w)).act(2).to(W.tmp1).f16_map(o16));
                 if (!rc)
                     rc = conv(ConvCall(h, w, CONV_CFG_RGB).source(W.tmp1, 64, packed + g->last_img).bias(packed + g->last_bias)
                                   .mode(2).rgb(lr_i, hw, packed + g->last_valu).to(out_i).f16_map(s16));
@@ -1038,7 +1047,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                                   .bias(packed + g->up_bias[1], 64).act(2).mode(1, 4, IMG_WIDE).to(W.u2).f16_map(o16 | s16));
                 if (!rc)
                     rc = conv(ConvCall(4 * h, 4 * w, conv_pick_cfg(4 * h, 4 * w)).source(W.u2, 64, packed + g->hr_img)
-                                  .bias(flat + g->hr_bias).wino(wino_ok(4 * h, 4 * w) ? packed + g->hr_wino : nullptr).act(2).to(W.u3)
+                                  .bias(flat + g->hr_bias).wino(wino_ok(4 * h, 4 * w) ? packed + g->hr_wino : nullptr).units(wino_units(4 * h, 4 * w)).act(2).to(W.u3)
                                   .f16_map(o16 | s16));
                 if (!rc)
                     rc = conv(ConvCall(4 * h, 4 * w, CONV_CFG_RGB).source(W.u3, 64, packed + g->last_img)
@@ -1317,6 +1326,14 @@ int pnp_conv3x3_wino_f32(const float* src, const float* wino_w, const float* bia
     return pnp_conv3x3_wino_f32_ex(src, wino_w, bias, gamma, wino_w1x1, par, par_flags, residual, act, out, h, w, nullptr, st);
 }
 
+int pnp_conv3x3_wino_units_f32(const float* src, const float* wino_w, const float* bias, const float* gamma, const float* wino_w1x1,
+                               const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
+                               void* st) {
+    // (trace = this function's own address: the marker pnp_conv3x3_wino_f32_ex reads as "quadrant-unit kernel, no timeline")
+    return pnp_conv3x3_wino_f32_ex(src, wino_w, bias, gamma, wino_w1x1, par, par_flags, residual, act, out, h, w,
+                                   (void*)&pnp_conv3x3_wino_units_f32, st);
+}
+
 int pnp_conv3x3_wino_f32_ex(const float* src, const float* wino_w, const float* bias, const float* gamma, const float* wino_w1x1,
                             const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
                             void* trace, void* st) {
@@ -1340,7 +1357,8 @@ int pnp_conv3x3_wino_f32_ex(const float* src, const float* wino_w, const float* 
     a.H = h;
     a.W = w;
     a.act = act;
-    a.dbg = (unsigned long long*)trace;
+    if (trace == (void*)&pnp_conv3x3_wino_units_f32) a.wino_units = 1;
+    else a.dbg = (unsigned long long*)trace;
     if (!conv_wino_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_wino(a, (hipStream_t)st);
 }

@@ -380,9 +380,10 @@ def conv3x3_wino_ms(srcs, wino_ws, bias=None, act=0):
 
 
 @_on_device_of_first_tensor
-def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par_flags=None, residual=None, act=0, trace=None):
+def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par_flags=None, residual=None, act=0, trace=None, units=False):
     """act(gamma * (conv3x3(x; W) + bias) + sum_j par_j * conv1x1_j(x)) + residual on conv_wino.hip; x (h,w,64) NHWC fp32,
-    wino_w = wino_image(packed W, gamma) -- the SAME gamma -- and wino_w1x1 = wino_par_image(packed 1x1 images)."""
+    wino_w = wino_image(packed W, gamma) -- the SAME gamma -- and wino_w1x1 = wino_par_image(packed 1x1 images).  units=True: one block
+    per 8x8 quadrant unit (the small-frame form, pnp_conv3x3_wino_units_f32; same values)."""
     x = _chk(x, 'x')
     h, w, c = x.shape
     if c != 64:
@@ -393,7 +394,9 @@ def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par
         raise ValueError('par_flags must be a CUDA int32 tensor')
     args = (_ptr(x), _ptr(_chk(wino_w, 'wino_w')), opt(bias, 'bias'), opt(gamma, 'gamma'), opt(wino_w1x1, 'wino_w1x1'), opt(par, 'par'),
             ctypes.c_void_p(par_flags.data_ptr()) if par_flags is not None else None, opt(residual, 'residual'), int(act), _ptr(out), h, w)
-    if trace is None:
+    if units:
+        _native.check(_native.lib().pnp_conv3x3_wino_units_f32(*args, _stream()), 'pnp_conv3x3_wino_units_f32')
+    elif trace is None:
         _native.check(_native.lib().pnp_conv3x3_wino_f32(*args, _stream()), 'pnp_conv3x3_wino_f32')
     else:       # include/pnpvcve_debug.h: 16 uint64 per block
         _native.check(_native.lib().pnp_conv3x3_wino_f32_ex(*args, ctypes.c_void_p(trace.data_ptr()), _stream()), 'pnp_conv3x3_wino_f32_ex')

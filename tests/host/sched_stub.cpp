@@ -584,7 +584,7 @@ int run(const Scenario& sc) {
     json_ints("warp_context", warp_ctx);
     json_ints("warp_f16", warp_f16);
     // expert mixtures: one per distinct routing value and context-sample; which one each partition-branch conv used
-    std::vector<int> mix_slot, block_frame, block_mix, conv_f16, conv_nsrc, conv_mask, conv_wino, conv_wino_ms;
+    std::vector<int> mix_slot, block_frame, block_mix, conv_f16, conv_nsrc, conv_mask, conv_wino, conv_wino_ms, conv_wino_units;
     const Workspace W0 = carve(g, ws, sc.t, sc.h, sc.w);
     for (const MixRec& m : mixes) mix_slot.push_back((int)(((const float*)m.dst - W0.mixw) % ((int64_t)ctx_bytes / 4) / ((int64_t)g->ndyn * IMG_WIDE)));
     for (const ConvRec& c : convs) {
@@ -592,6 +592,7 @@ int run(const Scenario& sc) {
         conv_nsrc.push_back(c.a.nsrc);
         conv_wino.push_back((c.path == 0 && conv_wino_eligible(c.a, c.cfg, c.gy)) ? 1 : 0);
         conv_wino_ms.push_back((c.path == 0 && conv_wino_ms_eligible(c.a, c.cfg, c.gy)) ? 1 : 0);
+        conv_wino_units.push_back((c.path == 0 && conv_wino_eligible(c.a, c.cfg, c.gy) && c.a.wino_units) ? 1 : 0);
         conv_mask.push_back(c.a.src_f16 | (c.a.out_f16 ? 16 : 0) | (c.a.out16 ? 32 : 0));
         if (!(c.a.wpar || c.a.wpar_h)) continue;
         const size_t pl = (c.a.par - par) / (3 * hw);
@@ -618,6 +619,7 @@ int run(const Scenario& sc) {
     json_ints("conv_nsrc", conv_nsrc);
     json_ints("conv_wino", conv_wino);
     json_ints("conv_wino_ms", conv_wino_ms);
+    json_ints("conv_wino_units", conv_wino_units);
     json_ints("conv_map_mask", conv_mask);
     json_ints("launch_stream", launch_streams);
     std::vector<int> wait_stream, wait_on;

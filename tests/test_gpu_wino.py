@@ -204,6 +204,28 @@ def test_wino_quadrant_units_equal_whole_tiles_bit_for_bit():
                 assert torch.equal(crop[iy0:iy1, ix0:ix1], full[y0 + iy0:y0 + iy1, x0 + ix0:x0 + ix1]), (name, h, w, band)
 
 
+@pytest.mark.parametrize('hw', [(16, 16), (37, 53), (64, 64), (128, 128), (180, 320)])
+def test_wino_unit_kernel_equals_the_tile_kernel_bit_for_bit(hw):
+    """small frames: one block per 8x8 quadrant unit (conv3x3_wino_quad_kernel) -- the same arithmetic in the same order as a whole
+    tile of the persistent kernel: plain + activation, residual, branches with and without skipping, branches + residual"""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    x = torch.randn(h, w, 64, device=dev())
+    res = torch.randn(h, w, 64, device=dev())
+    wt = torch.randn(64, 64, 3, 3, device=dev()) * 0.05
+    b = torch.randn(64, device=dev()) * 0.1
+    gamma = torch.rand(64, device=dev())
+    w1 = [torch.randn(64, 64, 1, 1, device=dev()) * 0.1 for _ in range(3)]
+    par = G(par_maps(33, h, w, 1.0 / 255.0, empty_rows=1))
+    flags = ops.par_tile_flags(par)
+    u, ug, up = ops.wino_image(ops.pack_conv3x3(wt)), ops.wino_image(ops.pack_conv3x3(wt), gamma), ops.wino_par_image(ops.pack_conv1x1(w1))
+    for kw in (dict(wino_w=u, bias=b, act=2), dict(wino_w=u, bias=b, residual=res), dict(wino_w=u),
+               dict(wino_w=ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, par_flags=flags, act=1),
+               dict(wino_w=ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, act=1),
+               dict(wino_w=ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, par_flags=flags, residual=res)):
+        assert torch.equal(ops.conv3x3_wino(x, units=True, **kw), ops.conv3x3_wino(x, **kw)), sorted(kw)
+
+
 @pytest.mark.parametrize('hw', [(16, 16), (40, 72), (37, 53), (128, 160)])
 @pytest.mark.parametrize('nwide', [1, 2, 3])
 def test_wino_input_conv_over_the_virtual_concat(hw, nwide):
@@ -301,13 +323,14 @@ def test_generator_winograd_vs_reference_golden(case):
     assert float(np.abs(run(m, clip).cpu().numpy() - ref).max()) < 5e-6
 
 
-def test_generator_winograd_auto_mode_leaves_small_frames_alone_and_takes_720p():
+def test_generator_winograd_auto_mode_takes_the_unit_kernel_on_small_frames_and_the_tile_kernel_at_720p():
     from pnp_vcve_amd import _native, synthetic as syn
     case = gu.GEN_CASES[0]
     cfg, sd_np, clip = gu.gen_case_inputs(case)
-    a = run(build(cfg, sd_np, 0), clip)
-    assert torch.equal(run(build(cfg, sd_np, 1), clip), a)                      # 24 tiles: below the 512-tile threshold, bit-identical
-    assert not torch.equal(run(build(cfg, sd_np, 2), clip), a)
+    a, b, c = (run(build(cfg, sd_np, o), clip) for o in (0, 1, 2))
+    # 24 tiles: auto = quadrant units for the block convs + direct input convs; 2 = tile kernel + multi-source input convs; 0 = direct
+    for u, v in ((a, b), (a, c), (b, c)):
+        assert 0 < float((u - v).abs().max()) < TOL_GEN
     cfg = dict(syn.DEFAULT_GENERATOR_CFG)
     sd = syn.make_state_dict(cfg, seed=2025)
     clip = syn.make_clip(seed=77, n=1, t=3, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)

@@ -177,7 +177,8 @@ def test_fp16_mirrors_are_scheduled_consistently(stub_run):
 
 def test_winograd_option_routes_the_single_source_64_channel_convs(stub_run):
     """PNP_OPT_WINOGRAD (fp32 only): both halves of every BAE block and conv_hr carry a Winograd image and take conv_wino.hip; input
-    convs and the RGB / pixel-shuffle heads never do; option 1 applies from 512 16x16 tiles on, option 2 everywhere; the stub's
+    convs and the RGB / pixel-shuffle heads never do; option 1 = quadrant units up to 128 16x16 tiles, the tile kernel above (multi-source
+    input convs from 512 on), option 2 = tile kernel everywhere; the stub's
     range bookkeeping (errors == []) proved that every image -- the per-frame ones of the expert-mixed convs included -- was written
     before it was read, in the workspace the scheduler advertised."""
     _, _, docs, _ = stub_run
@@ -192,7 +193,11 @@ def test_winograd_option_routes_the_single_source_64_channel_convs(stub_run):
     assert set(ref['conv_wino_ms']) == {0} and set(docs['f16_wino2_ibbbp_t7']['conv_wino_ms']) == {0}
     # one launch per branch and frame makes the 8 images of the expert-mixed convs: 14 more launches than the direct schedule
     assert d['launches_first_forward'] == ref['launches_first_forward'] + 14
-    assert set(docs['f32_wino1_ibbbp_t7']['conv_wino']) == {0}                   # 24 tiles: below the threshold
+    # auto mode (the default): a small frame (24 tiles) takes the quadrant-unit kernel on the same convs, its input convs stay direct;
+    # 720p takes the tile kernel, units nowhere
+    a = docs['f32_wino1_ibbbp_t7']
+    assert a['errors'] == [] and a['conv_wino'] == d['conv_wino'] and a['conv_wino_units'] == d['conv_wino'] and set(a['conv_wino_ms']) == {0}
+    assert set(d['conv_wino_units']) == {0} and set(docs['f32_wino1_p720_t2']['conv_wino_units']) == {0}
     p = docs['f32_wino1_p720_t2']
     assert p['errors'] == [] and sum(p['conv_wino']) == 2 * 2 * 16 + 2
     assert set(docs['f16_wino2_ibbbp_t7']['conv_wino']) == {0}                   # the option is an fp32-path switch

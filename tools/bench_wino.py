@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--w', type=int, default=1280)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--rounds', type=int, default=3)
+    ap.add_argument('--units', action='store_true', help='also time the quadrant-unit kernel (small frames)')
     args = ap.parse_args()
     h, w = args.h, args.w
     dev = torch.device('cuda:0')
@@ -63,6 +64,13 @@ def main():
                                                                                par_flags=flags, act=1)),
         ('front half  winograd (dense)', flop_front, lambda: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, act=1)),
     ]
+    if args.units:      # the small-frame form: one block per 8x8 quadrant unit
+        cases += [
+            ('back half   winograd units', flop_back, lambda: ops.conv3x3_wino(x, u, bias=b, residual=res, units=True)),
+            ('conv_hr     winograd units', flop_back, lambda: ops.conv3x3_wino(x, u, bias=b, act=2, units=True)),
+            ('front half  winograd units (flags)', flop_front, lambda: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par,
+                                                                                        par_flags=flags, act=1, units=True)),
+        ]
     print(f'{h}x{w}: {tiles} 16x16 tiles; algorithmic GFLOP back / front = {flop_back / 1e9:.2f} / {flop_front / 1e9:.2f}')
     for r in range(args.rounds):
         for name, flop, fn in cases:
