@@ -339,7 +339,9 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         kern = ('conv3x3_persist_kernel<PAR> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, persistent strips)'
                 if big else 'conv3x3_mfma_kernel<2,2,1,2> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, 4x16 tiles)')
         wopt = m.get_option(9)             # PNP_OPT_WINOGRAD
-        wino = wopt == 2 or (wopt == 1 and ((h + 15) // 16) * ((w + 15) // 16) >= 512)
+        tiles16 = ((h + 15) // 16) * ((w + 15) // 16)
+        wino = wopt >= 1                   # auto: quadrant units up to 128 tiles, the persistent tile kernel above; 2: the tile kernel everywhere
+        units = wopt == 1 and tiles16 <= 128
         if wino:
             # Winograd F(2x2,3x3) (csrc/conv_wino.hip): 16 transform positions per 2x2 output pixels instead of 36 taps -> the 3x3 part
             # executes 256/576 of the direct form's matrix FLOPs; the 1x1 branches run per 8x8-pixel quadrant (one wave), each wave
@@ -352,6 +354,9 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
             executed = ach * (1 - skipped_frac)
             kern = ('conv3x3_wino_kernel<PAR,RES> (the 64->64 BAE-block convs + conv_hr as Winograd F(2x2,3x3): fp32 MFMA 16x16x4, 16x16-pixel '
                     'block tiles on 256 persistent blocks, K-outer with in-place halo refill)')
+            if units:
+                kern = ('conv3x3_wino_quad_kernel<PAR,RES> (the 64->64 BAE-block convs + conv_hr as Winograd F(2x2,3x3): fp32 MFMA 16x16x4, one '
+                        'block per 8x8-pixel quadrant unit, the four waves split the output channels)')
         # roofline.achieved / frac price the FLOPs the kernel EXECUTES (what the matrix pipe really did per second);
         # algorithmic_* is the reference's dense count over the same time (what a user gets per second)
         r = {'kernel': kern, 'bound': 'mfma', 'achieved': executed, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -366,7 +371,8 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
                             'algorithmic_* = the dense reference count 2*K*64*H*W over the same time'),
              'winograd': bool(wino),
              'partition_branches_needed_per_tile': branches, 'partition_branch_chunks_run_per_tile': run,
-             'traffic': _launch_weighted_traffic(pmc, 'conv3x3_wino_kernel' if wino else 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>'),
+             'traffic': _launch_weighted_traffic(pmc, ('conv3x3_wino_quad_kernel' if units else 'conv3x3_wino_kernel') if wino
+                                                 else 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>'),
              'traffic_source': pmc_src,
              'launches': cb['launches'], 'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
              'all_convs_TFLOPs': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
