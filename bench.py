@@ -727,8 +727,10 @@ def north_star_128(sec):
     out = {'unit': 'frames/s', 'dtype': 'f32'}
     if one:
         out['clips_1'] = one['value']
-        out['frac_per_launch'] = one['roofline']['frac']
-        out['frac_wall'] = one['roofline'].get('frac_wall')
+        out['frac_per_launch'] = one['roofline']['frac']                    # executed FLOPs (Winograd: 256/576 of the 3x3 part) per launch time
+        out['algorithmic_frac_per_launch'] = one['roofline'].get('algorithmic_frac')
+        out['winograd'] = one['roofline'].get('winograd')
+        out['frac_wall'] = one['roofline'].get('frac_wall')                 # algorithmic FLOPs over wall time
         cb = one.get('cpu_baseline')
         if cb:
             out['cpu'] = cb['value']
