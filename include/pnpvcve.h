@@ -105,10 +105,12 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     neutral at 720p -- the back half writes 128 B per pixel more for what the front half reads less) */
 #define PNP_OPT_TILE_QUEUE 8     /* PNP_PREC_F16X3: the split conv kernel's blocks draw their tiles from a per-XCD queue in the workspace instead of
                                     walking a static share (tiles differ in cost and the two blocks of a CU in speed); results identical */
-#define PNP_OPT_WINOGRAD 9       /* PNP_PREC_F32: the single-source 64 -> 64 convs (both halves of a BAE block, conv_hr) in Winograd F(2x2,3x3) form
-                                    (conv_wino.hip): 2.25x fewer matrix FLOPs, still fp32 products and sums, NOT bit-identical to the direct
-                                    kernels (summation order + the +-1 input transform: ~1e-6 per conv on unit-scale maps; whole-clip
-                                    gates in tests/test_gpu_wino.py).  0 off | 1 (default) on frames with >= 512 16x16 tiles | 2 on every frame size */
+#define PNP_OPT_WINOGRAD 9       /* PNP_PREC_F32: the single-source 64 -> 64 convs (both halves of a BAE block, conv_hr) and the input convs over wide sources in
+                                    Winograd F(2x2,3x3) form (conv_wino.hip): 2.25x fewer matrix FLOPs, still fp32 products and sums, NOT bit-identical
+                                    to the direct kernels (summation order + the +-1 input transform: ~1e-6 per conv on unit-scale maps; whole-clip
+                                    gates in tests/test_gpu_wino.py).  0 off | 1 (default): frames of up to 128 16x16 tiles one block per 8x8 quadrant
+                                    unit, larger ones the persistent tile kernel (same values bit for bit), input convs from 512 tiles on | 2: the tile
+                                    kernel and the multi-source input convs at every frame size */
 #define PNP_OPT_COUNT 10
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
