@@ -19,10 +19,15 @@ constexpr int LDS_BYTES = PIX * PSTR * 16;
 constexpr int SIT = (PIX * 16 + 127) / 128;          // float4 halo loads per thread
 
 // wv: [9 taps][64 input channels][4] = (co 0, co 1, co 2, 0), made by pack_last_valu_kernel
-__global__ __launch_bounds__(128) void conv_last_valu_kernel(const ConvArgs a, const float* __restrict__ wv) {
+// KS = 1: one thread per pixel (128 threads).  KS = 4 (small frames: fewer tiles than CUs x 3, a block's 1728-FMA chain and its LDS
+// latency are the launch): 512 threads, thread group g = t >> 7 contracts input channels 16 g .. 16 g + 15 of every tap for pixel
+// t & 127 (the weights stay wave-uniform scalars), the four partial sums meet in LDS -- 16 -> 6 us per 128x128 frame; the
+// summation order differs from KS = 1 in the last bits (both are held to 2e-6 against the matrix-core form).
+template <int KS>
+__global__ __launch_bounds__(128 * KS) void conv_last_valu_kernel(const ConvArgs a, const float* __restrict__ wv) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f32x4* sA = reinterpret_cast<f32x4*>(smem_raw);
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 127, grp = threadIdx.x >> 7;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
     int tile;
@@ -38,6 +43,7 @@ __global__ __launch_bounds__(128) void conv_last_valu_kernel(const ConvArgs a, c
     f32x4 reg[SIT];
 #pragma unroll
     for (int k = 0; k < SIT; ++k) {
+        if (KS > 1 && (k & (KS - 1)) != grp) continue;          // (the groups share the halo loads)
         const int i = t + 128 * k;
         const int pix = (i >> 4) < PIX ? (i >> 4) : PIX - 1, c16 = i & 15;
         const int ry = pix / PW, rx = pix - ry * PW;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(128) void conv_last_valu_kernel(const ConvArgs a, c
 #pragma unroll
     for (int k = 0; k < SIT; ++k) {
         const int i = t + 128 * k;
-        if (i < PIX * 16) sA[(i >> 4) * PSTR + (i & 15)] = reg[k];
+        if ((KS == 1 || (k & (KS - 1)) == grp) && i < PIX * 16) sA[(i >> 4) * PSTR + (i & 15)] = reg[k];
     }
     __syncthreads();
 
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(128) void conv_last_valu_kernel(const ConvArgs a, c
         const int dy = tap / 3, dx = tap - dy * 3;
         const f32x4* xt = xp + (dy * PW + dx) * PSTR;
 #pragma unroll 4
-        for (int c4 = 0; c4 < 16; ++c4) {
+        for (int c4 = (16 / KS) * grp; c4 < (16 / KS) * (grp + 1); ++c4) {
             const f32x4 x = xt[c4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -101,6 +107,23 @@ __global__ __launch_bounds__(128) void conv_last_valu_kernel(const ConvArgs a, c
                 acc1 = __builtin_fmaf(x[j], wq[1], acc1);
                 acc2 = __builtin_fmaf(x[j], wq[2], acc2);
             }
+        }
+    }
+    if constexpr (KS > 1) {
+        __syncthreads();                                       // every group is done with the halo tile: its first bytes hold the partial sums
+        float* red = reinterpret_cast<float*>(smem_raw);
+        if (grp > 0) {
+            red[((grp - 1) * 128 + t) * 3 + 0] = acc0;
+            red[((grp - 1) * 128 + t) * 3 + 1] = acc1;
+            red[((grp - 1) * 128 + t) * 3 + 2] = acc2;
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 0; g < KS - 1; ++g) {
+            acc0 += red[(g * 128 + t) * 3 + 0];
+            acc1 += red[(g * 128 + t) * 3 + 1];
+            acc2 += red[(g * 128 + t) * 3 + 2];
         }
     }
     if (inb) {
@@ -138,6 +161,7 @@ bool conv_last_valu_eligible(const ConvArgs& a, int cfg, int grid_y) {
 
 int launch_conv_last_valu(const ConvArgs& a, hipStream_t stream) {
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-    hipLaunchKernelGGL(conv_last_valu_kernel, dim3(tiles), dim3(128), LDS_BYTES, stream, a, a.wvalu);
+    if (tiles < 768) hipLaunchKernelGGL(conv_last_valu_kernel<4>, dim3(tiles), dim3(512), LDS_BYTES, stream, a, a.wvalu);
+    else hipLaunchKernelGGL(conv_last_valu_kernel<1>, dim3(tiles), dim3(128), LDS_BYTES, stream, a, a.wvalu);
     return (int)hipGetLastError();
 }
