@@ -233,6 +233,8 @@ int64_t pnp_wino_rgb_image_floats(void);
 int pnp_wino_rgb_image_from_packed_f32(const float* packed_rgb_chunk_dev, float* dst_dev, void* stream);
 int pnp_conv3x3_wino_ms_f32(int nsrc, const float* const* srcs_dev, const float* const* wino_w_dev, const float* bias_dev,
                             int act, float* out_dev, int h, int w, void* stream);
+int pnp_conv3x3_wino_ms_units_f32(int nsrc, const float* const* srcs_dev, const float* const* wino_w_dev, const float* bias_dev,
+                                  int act, float* out_dev, int h, int w, void* stream);   /* one block per quadrant unit (small frames) */
 int pnp_conv3x3_wino_f32(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
                          const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
                          const float* residual_dev, int act, float* out_dev, int h, int w, void* stream);

@@ -83,6 +83,7 @@ SIGNATURES = {
     'pnp_wino_rgb_image_floats': (c_int64, []),
     'pnp_wino_rgb_image_from_packed_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
     'pnp_conv3x3_wino_ms_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'pnp_conv3x3_wino_ms_units_f32': (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'pnp_wino_image_from_packed_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'pnp_wino_par_image_from_packed_f32': (c_int, [c_void_p, c_void_p, c_void_p]),
     'pnp_conv3x3_wino_f32': (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -1016,6 +1016,155 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
     }
 }
 
+// The input conv over the virtual concat [frame, wide sources ...] as quadrant units (the multi-source kernel's arithmetic, block u =
+// quadrant u & 3 of tile u >> 2, wave w = output channels 16 w .. + 15): the frame's RGB0 halo and the first source's halo go to LDS,
+// the frame's one k-step starts the accumulators (bias at position (1,1)), then one 4-step pass per 64-channel source; the NEXT
+// source's halo is fetched into registers during a pass and lands in the other LDS buffer behind it.
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_ms_kernel(const WinoArgs a) {
+    constexpr int QSTR = 272, HB = 100 * QSTR;
+    __shared__ __attribute__((aligned(16))) char smem[2 * HB + 100 * 16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int tiles_x = (W + 15) >> 4;
+    const int qtile = blockIdx.x >> 2, qquad = blockIdx.x & 3;
+    const int qy0 = (qtile / tiles_x) * 16 + 8 * (qquad >> 1), qx0 = (qtile % tiles_x) * 16 + 8 * (qquad & 1);
+    if (qy0 >= H || qx0 >= W) return;
+    const __amdgpu_buffer_rsrc_t r_u = rsrc_of(a.ubase, OOBW);
+    const __amdgpu_buffer_rsrc_t r_urgb = rsrc_of(a.Urgb, 4u * 4096u);
+    const __amdgpu_buffer_rsrc_t r_out = rsrc_of(a.out, (unsigned)H * (unsigned)W * 256u);
+    const float act_lo = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    f32x4 hv[7];
+    auto halo_request = [&](const float* src) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int e = t + 256 * i, pe = e >> 4, ry = pe / 10, rx = pe - ry * 10, gy = qy0 - 1 + ry, gx = qx0 - 1 + rx;
+            hv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < 1600 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                hv[i] = *reinterpret_cast<const f32x4*>(src + ((long)gy * W + gx) * 64 + (e & 15) * 4);
+        }
+    };
+    auto halo_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int e = t + 256 * i;
+            if (e < 1600) *reinterpret_cast<f32x4*>(smem + buf * HB + (e >> 4) * QSTR + (e & 15) * 16) = hv[i];
+        }
+    };
+    halo_request(a.srcs[0]);
+    if (t < 100) {
+        const int ry = t / 10, rx = t - ry * 10, gy = qy0 - 1 + ry, gx = qx0 - 1 + rx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *reinterpret_cast<const f32x4*>(a.rgb + ((long)gy * W + gx) * 4);
+        *reinterpret_cast<f32x4*>(smem + 2 * HB + t * 16) = v;
+    }
+    const int tyq = m >> 2, txq = m & 3;
+    const unsigned wq16 = (unsigned)lane * 16u + (unsigned)wave * 1024u;
+    f32x4 Bq[2][16], Br[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) Br[p] = bload4(r_urgb, (unsigned)lane * 16u, (unsigned)((p >> 2) * 4096 + (p & 3) * 1024));
+#pragma unroll
+    for (int p = 0; p < 16; ++p) Bq[0][p] = bload4(r_u, wq16, a.u_off[0] + (unsigned)((p >> 2) * 16384 + (p & 3) * 4096));
+    halo_store(0);
+    const float bgq = a.bias ? a.bias[wave * 16 + m] : 0.f;
+    f32x4 acc[16], V[16];
+    lds_bar();
+    {   // the frame: channel kq of the lane's 4x4 patch, one float per position
+        float dr[16], tr[16], Vr[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dr[r * 4 + c] = *reinterpret_cast<const float*>(smem + 2 * HB + ((2 * tyq + r) * 10 + 2 * txq + c) * 16 + kq * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tr[0 * 4 + c] = dr[0 * 4 + c] - dr[2 * 4 + c];
+            tr[1 * 4 + c] = dr[1 * 4 + c] + dr[2 * 4 + c];
+            tr[2 * 4 + c] = dr[2 * 4 + c] - dr[1 * 4 + c];
+            tr[3 * 4 + c] = dr[1 * 4 + c] - dr[3 * 4 + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Vr[i * 4 + 0] = tr[i * 4 + 0] - tr[i * 4 + 2];
+            Vr[i * 4 + 1] = tr[i * 4 + 1] + tr[i * 4 + 2];
+            Vr[i * 4 + 2] = tr[i * 4 + 2] - tr[i * 4 + 1];
+            Vr[i * 4 + 3] = tr[i * 4 + 1] - tr[i * 4 + 3];
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const f32x4 c0 = p == 5 ? f32x4{bgq, bgq, bgq, bgq} : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float bw = wave == 0 ? Br[p][0] : (wave == 1 ? Br[p][1] : (wave == 2 ? Br[p][2] : Br[p][3]));
+            acc[p] = mfma16(Vr[p], bw, c0);
+        }
+    }
+    for (int ks = 0; ks < a.nsrc; ++ks) {
+        const bool more = ks + 1 < a.nsrc;
+        const int buf = ks & 1;
+        if (more) halo_request(a.srcs[ks + 1]);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (s4 < 3) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+                    Bq[(s4 + 1) & 1][p] = bload4(r_u, wq16, a.u_off[ks] + (unsigned)(((s4 + 1) * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
+            } else if (more) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) Bq[0][p] = bload4(r_u, wq16, a.u_off[ks + 1] + (unsigned)((p >> 2) * 16384 + (p & 3) * 4096));
+            }
+            f32x4 dq[4][4], tq4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    dq[r][c] = *reinterpret_cast<const f32x4*>(smem + buf * HB + ((2 * tyq + r) * 10 + 2 * txq + c) * QSTR + (16 * s4 + 4 * kq) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tq4[c] = i == 0 ? dq[0][c] - dq[2][c] : (i == 1 ? dq[1][c] + dq[2][c] : (i == 2 ? dq[2][c] - dq[1][c] : dq[1][c] - dq[3][c]));
+                V[4 * i + 0] = tq4[0] - tq4[2];
+                V[4 * i + 1] = tq4[1] + tq4[2];
+                V[4 * i + 2] = tq4[2] - tq4[1];
+                V[4 * i + 3] = tq4[1] - tq4[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(V[i]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int pc = 0; pc < 4; ++pc) {
+                        const int p = pr * 4 + pc;
+                        acc[p] = mfma16(V[p][k], Bq[s4 & 1][p][k], acc[p]);
+                    }
+        }
+        if (more) {
+            halo_store(buf ^ 1);       // (last read a whole pass ago: every wave is past the barrier behind that pass)
+            lds_bar();
+        }
+    }
+    f32x4 w0[4], w1[4], yq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w0[i] = acc[i * 4 + 0] + acc[i * 4 + 1] + acc[i * 4 + 2];
+        w1[i] = acc[i * 4 + 1] - acc[i * 4 + 2] - acc[i * 4 + 3];
+    }
+    yq[0] = w0[0] + w0[1] + w0[2];
+    yq[1] = w1[0] + w1[1] + w1[2];
+    yq[2] = w0[1] - w0[2] - w0[3];
+    yq[3] = w1[1] - w1[2] - w1[3];
+    const unsigned qo = (unsigned)((qy0 + 2 * kq) * W + qx0) * 256u + (unsigned)(wave * 16 + m) * 4u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        yq[q] = __builtin_elementwise_max(yq[q], act_lo * yq[q]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool inq = qy0 + 2 * kq + (q >> 1) < H && qx0 + 2 * r + (q & 1) < W;
+            bstore1(r_out, inq ? qo : OOBW, (unsigned)((q >> 1) * W + 2 * r + (q & 1)) * 256u, yq[q][r]);
+        }
+    }
+}
+
 // ---- weight images ------------------------------------------------------------------------------------------------------------
 // U = G g G^T per (output channel, input channel), times gamma[co] when given (see launch_wino_images), from a packed direct-conv
 // B image (common.h: 9 chunks, chunk = tap; float index ((q * 2 + nt32) * 64 + h * 32 + n32) * 4 + j  <->  ci = 8 q + 4 h + j,
@@ -1188,7 +1337,8 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         }
         w.rgb = a.src[0];
         w.Urgb = a.wwino_rgb;
-        hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+        if (a.wino_units) hipLaunchKernelGGL(conv3x3_wino_quad_ms_kernel, dim3(4 * ntiles), dim3(256), 0, stream, w);
+        else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     } else if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);

@@ -691,11 +691,12 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     const int wopt = g->prec == PNP_PREC_F32 ? g->opt[PNP_OPT_WINOGRAD] : 0;
     // 1: a frame of N 16x16 tiles takes the quadrant-unit kernel up to N = 128 (4 N blocks; 128x128: 12 us per conv against the direct
     // kernel's 15 and the tile kernel's 26 on 64 of 256 CUs) and the persistent tile kernel above (240 tiles: 31 us against 48 direct);
-    // the input convs keep the direct kernels below 512 tiles.  2 = the tile kernel at every size (tests)
+    // the input convs over wide sources likewise up to 128 tiles and from 512 on (direct kernels between).  2 = the tile kernels at
+    // every size (tests)
     auto ntiles16 = [](int hh, int ww) { return (int64_t)((hh + 15) / 16) * ((ww + 15) / 16); };
     auto wino_ok = [&](int hh, int ww) { return wopt == 2 || wopt == 1; };
     auto wino_units = [&](int hh, int ww) { return wopt == 1 && ntiles16(hh, ww) <= 128; };
-    auto wino_ms_ok = [&](int hh, int ww) { return wopt == 2 || (wopt == 1 && ntiles16(hh, ww) >= 512); };
+    auto wino_ms_ok = [&](int hh, int ww) { return wopt == 2 || (wopt == 1 && (ntiles16(hh, ww) >= 512 || ntiles16(hh, ww) <= 128)); };
     // every 64-channel map that is only read as an MFMA A operand gets an fp16 copy from its producer
     const bool mirrors = f16_maps && g->opt[PNP_OPT_F16_MIRRORS] && c.deform == 0 && W.x16 != nullptr;
     // ... and, optionally, the running map x INSIDE a branch too (input conv and every block write x16 next to x, every front
@@ -716,11 +717,11 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.wpar = q.wpar_;
         a.wwino = q.wino_;
         a.wwino_par = q.wino_par_;
-        a.wino_units = q.wino_ ? q.units_ : 0;
         if (q.nsrc >= 2 && q.sc[0] == 4 && q.wsrc_wino_[0]) {      // input conv with Winograd images on every member
             a.wwino_rgb = q.wsrc_wino_[0];
             for (int s = 1; s < q.nsrc; ++s) a.wwino_src[s] = q.wsrc_wino_[s];
         }
+        a.wino_units = (q.wino_ || a.wwino_rgb) ? q.units_ : 0;
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
@@ -919,7 +920,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             float* slot = W.slots + (int64_t)i * fm;
             // fp16 mirrors: the input conv writes x16 next to x when it runs on the fp16 kernels at all (an RGB-only one does not)
             const void* x16 = (chain16 && in.nsrc > 1) ? W.x16 : nullptr;
-            int r = conv(in.bias(flat + B.in_bias).act(2).to(W.tmp0).also16(const_cast<void*>(x16)));
+            int r = conv(in.bias(flat + B.in_bias).act(2).units(wino_units(h, w)).to(W.tmp0).also16(const_cast<void*>(x16)));
             if (r) return r;
             const float* x = W.tmp0;
             const bool wino = wino_ok(h, w), un = wino_units(h, w);
@@ -1289,8 +1290,21 @@ int pnp_wino_rgb_image_from_packed_f32(const float* packed_rgb_chunk, float* dst
     return launch_wino_rgb_image(packed_rgb_chunk, dst, (hipStream_t)st);
 }
 
+static int wino_ms_op(int nsrc, const float* const* srcs, const float* const* wino_w, const float* bias, int act, float* out,
+                      int h, int w, int units, void* st);
+
 int pnp_conv3x3_wino_ms_f32(int nsrc, const float* const* srcs, const float* const* wino_w, const float* bias, int act, float* out,
                             int h, int w, void* st) {
+    return wino_ms_op(nsrc, srcs, wino_w, bias, act, out, h, w, 0, st);
+}
+
+int pnp_conv3x3_wino_ms_units_f32(int nsrc, const float* const* srcs, const float* const* wino_w, const float* bias, int act,
+                                  float* out, int h, int w, void* st) {
+    return wino_ms_op(nsrc, srcs, wino_w, bias, act, out, h, w, 1, st);
+}
+
+static int wino_ms_op(int nsrc, const float* const* srcs, const float* const* wino_w, const float* bias, int act, float* out,
+                      int h, int w, int units, void* st) {
     if (nsrc < 2 || nsrc > 4 || !srcs || !wino_w || !out || act < 0 || act > 2) return PNP_ERR_BAD_ARG;
     if (!op_map_fits(h, w)) return PNP_ERR_UNSUPPORTED;
     ConvArgs a;
@@ -1308,6 +1322,7 @@ int pnp_conv3x3_wino_ms_f32(int nsrc, const float* const* srcs, const float* con
     a.H = h;
     a.W = w;
     a.act = act;
+    a.wino_units = units;
     if (!conv_wino_ms_eligible(a, CONV_CFG_BIG, 1)) return PNP_ERR_UNSUPPORTED;
     return launch_conv3x3_wino(a, (hipStream_t)st);
 }

@@ -362,7 +362,7 @@ def wino_rgb_image(packed_rgb):
 
 
 @_on_device_of_first_tensor
-def conv3x3_wino_ms(srcs, wino_ws, bias=None, act=0):
+def conv3x3_wino_ms(srcs, wino_ws, bias=None, act=0, units=False):
     """The input conv on conv_wino.hip: srcs = [(h,w,4) frame, (h,w,64) maps ...], wino_ws = [wino_rgb_image(...), wino_image(...) ...];
     the 64-channel sources' images must sit within 4 GiB of each other (slices of ONE tensor do)."""
     srcs = [_chk(x, 'src') for x in srcs]
@@ -374,8 +374,9 @@ def conv3x3_wino_ms(srcs, wino_ws, bias=None, act=0):
     out = torch.empty((h, w, 64), device=srcs[0].device, dtype=torch.float32)
     sp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in srcs])
     wp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in wino_ws])
-    _native.check(_native.lib().pnp_conv3x3_wino_ms_f32(n, sp, wp, _ptr(_chk(bias, 'bias')) if bias is not None else None, int(act),
-                                                        _ptr(out), h, w, _stream()), 'pnp_conv3x3_wino_ms_f32')
+    fn = _native.lib().pnp_conv3x3_wino_ms_units_f32 if units else _native.lib().pnp_conv3x3_wino_ms_f32
+    _native.check(fn(n, sp, wp, _ptr(_chk(bias, 'bias')) if bias is not None else None, int(act), _ptr(out), h, w, _stream()),
+                  'pnp_conv3x3_wino_ms_f32')
     return out
 
 

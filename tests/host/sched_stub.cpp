@@ -592,7 +592,7 @@ int run(const Scenario& sc) {
         conv_nsrc.push_back(c.a.nsrc);
         conv_wino.push_back((c.path == 0 && conv_wino_eligible(c.a, c.cfg, c.gy)) ? 1 : 0);
         conv_wino_ms.push_back((c.path == 0 && conv_wino_ms_eligible(c.a, c.cfg, c.gy)) ? 1 : 0);
-        conv_wino_units.push_back((c.path == 0 && conv_wino_eligible(c.a, c.cfg, c.gy) && c.a.wino_units) ? 1 : 0);
+        conv_wino_units.push_back((c.path == 0 && (conv_wino_eligible(c.a, c.cfg, c.gy) || conv_wino_ms_eligible(c.a, c.cfg, c.gy)) && c.a.wino_units) ? 1 : 0);
         conv_mask.push_back(c.a.src_f16 | (c.a.out_f16 ? 16 : 0) | (c.a.out16 ? 32 : 0));
         if (!(c.a.wpar || c.a.wpar_h)) continue;
         const size_t pl = (c.a.par - par) / (3 * hw);

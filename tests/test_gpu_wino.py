@@ -226,6 +226,29 @@ def test_wino_unit_kernel_equals_the_tile_kernel_bit_for_bit(hw):
         assert torch.equal(ops.conv3x3_wino(x, units=True, **kw), ops.conv3x3_wino(x, **kw)), sorted(kw)
 
 
+@pytest.mark.parametrize('hw', [(16, 16), (37, 53), (128, 128)])
+@pytest.mark.parametrize('nwide', [1, 2, 3])
+def test_wino_input_conv_unit_kernel_equals_the_tile_kernel_bit_for_bit(hw, nwide):
+    """the input conv over [frame, 1-3 wide sources] one block per quadrant unit (conv3x3_wino_quad_ms_kernel) against the persistent
+    multi-source kernel: same per-accumulator order (frame first, then source by source, step by step)"""
+    from pnp_vcve_amd import ops
+    h, w = hw
+    cin = 3 + 64 * nwide
+    lr4 = torch.zeros(h, w, 4, device=dev())
+    lr4[..., :3] = torch.rand(h, w, 3, device=dev())
+    wide = [torch.randn(h, w, 64, device=dev()) for _ in range(nwide)]
+    wt = torch.randn(64, cin, 3, 3, device=dev()) * 0.05
+    b = torch.randn(64, device=dev()) * 0.1
+    imgs = torch.empty(nwide, 65536, device=dev())
+    for k in range(nwide):
+        imgs[k] = ops.wino_image(ops.pack_conv3x3(wt, cbase=3 + 64 * k, csrc=64))
+    urgb = ops.wino_rgb_image(ops.pack_conv3x3(wt, cbase=0, csrc=3))
+    args = ([lr4] + wide, [urgb] + [imgs[k] for k in range(nwide)])
+    for act in (0, 2):
+        assert torch.equal(ops.conv3x3_wino_ms(*args, bias=b, act=act, units=True), ops.conv3x3_wino_ms(*args, bias=b, act=act))
+    assert torch.equal(ops.conv3x3_wino_ms(*args, units=True), ops.conv3x3_wino_ms(*args))
+
+
 @pytest.mark.parametrize('hw', [(16, 16), (40, 72), (37, 53), (128, 160)])
 @pytest.mark.parametrize('nwide', [1, 2, 3])
 def test_wino_input_conv_over_the_virtual_concat(hw, nwide):
@@ -328,9 +351,9 @@ def test_generator_winograd_auto_mode_takes_the_unit_kernel_on_small_frames_and_
     case = gu.GEN_CASES[0]
     cfg, sd_np, clip = gu.gen_case_inputs(case)
     a, b, c = (run(build(cfg, sd_np, o), clip) for o in (0, 1, 2))
-    # 24 tiles: auto = quadrant units for the block convs + direct input convs; 2 = tile kernel + multi-source input convs; 0 = direct
-    for u, v in ((a, b), (a, c), (b, c)):
-        assert 0 < float((u - v).abs().max()) < TOL_GEN
+    # 24 tiles: auto = quadrant units, 2 = the tile kernels: the same values bit for bit; 0 = direct kernels
+    assert torch.equal(b, c)
+    assert 0 < float((a - b).abs().max()) < TOL_GEN
     cfg = dict(syn.DEFAULT_GENERATOR_CFG)
     sd = syn.make_state_dict(cfg, seed=2025)
     clip = syn.make_clip(seed=77, n=1, t=3, h=720, w=1280, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)

@@ -193,10 +193,11 @@ def test_winograd_option_routes_the_single_source_64_channel_convs(stub_run):
     assert set(ref['conv_wino_ms']) == {0} and set(docs['f16_wino2_ibbbp_t7']['conv_wino_ms']) == {0}
     # one launch per branch and frame makes the 8 images of the expert-mixed convs: 14 more launches than the direct schedule
     assert d['launches_first_forward'] == ref['launches_first_forward'] + 14
-    # auto mode (the default): a small frame (24 tiles) takes the quadrant-unit kernel on the same convs, its input convs stay direct;
-    # 720p takes the tile kernel, units nowhere
+    # auto mode (the default): a small frame (24 tiles) takes the quadrant-unit kernels on the same convs; 720p takes the tile kernels,
+    # units nowhere
     a = docs['f32_wino1_ibbbp_t7']
-    assert a['errors'] == [] and a['conv_wino'] == d['conv_wino'] and a['conv_wino_units'] == d['conv_wino'] and set(a['conv_wino_ms']) == {0}
+    assert a['errors'] == [] and a['conv_wino'] == d['conv_wino'] and a['conv_wino_ms'] == d['conv_wino_ms']
+    assert a['conv_wino_units'] == [x | y for x, y in zip(d['conv_wino'], d['conv_wino_ms'])]      # both kinds as quadrant units
     assert set(d['conv_wino_units']) == {0} and set(docs['f32_wino1_p720_t2']['conv_wino_units']) == {0}
     p = docs['f32_wino1_p720_t2']
     assert p['errors'] == [] and sum(p['conv_wino']) == 2 * 2 * 16 + 2
