@@ -7,7 +7,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ('conv3x3_wino_quad_kernel', 'conv3x3_wino_kernel', 'conv3x3_persist_kernel', 'conv3x3_mfma_kernel', 'conv3x3_f16x3_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_f16_kernel', 'par_tile_flags_kernel', 'conv_last_valu_kernel', 'dcn_window_kernel',
+    for k in ('conv3x3_wino_quad_ms_kernel', 'conv3x3_wino_quad_kernel', 'conv3x3_wino_kernel', 'conv3x3_persist_kernel', 'conv3x3_mfma_kernel', 'conv3x3_f16x3_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_f16_kernel', 'par_tile_flags_kernel', 'conv_last_valu_kernel', 'dcn_window_kernel',
               'mv_warp_nhwc64_kernel', 'mv_warp_nhwc_kernel', 'psnr_sse_kernel', 'flow_warp_nchw_kernel', 'pack_weights_kernel',
               'pack_lr_kernel', 'caa_predict_kernel', 'mix_bias_kernel'):
         if k in name:
