@@ -27,7 +27,7 @@ template <int KS>
 __global__ __launch_bounds__(128 * KS) void conv_last_valu_kernel(const ConvArgs a, const float* __restrict__ wv) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     f32x4* sA = reinterpret_cast<f32x4*>(smem_raw);
-    const int t = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int t = KS == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 127), grp = KS == 1 ? 0 : (int)(threadIdx.x >> 7);      // (KS = 1: compile-time bounds below)
     const int H = a.H, W = a.W;
     const int tiles_x = (W + TW - 1) / TW;
     int tile;
