@@ -79,6 +79,12 @@ def test_winograd_kernel_is_built_without_packed_fp32_valu_ops(tmp_path):
     # memory (private_seg_size 1616: correct results, ten times slower) -- a few spill slots are tolerated
     sizes = [int(v) for v in re.findall(r'conv3x3_wino_kernel\w+\.private_seg_size, (\d+)', text)]
     assert len(sizes) == 5 and max(sizes) <= 512, sizes
+    # the quadrant-unit kernels of small frames (five instantiations): straight-line code, no spill slot at all, no packed fp32 either
+    units = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_quad' in fn.split('\n')[0]]
+    usizes = [int(v) for v in re.findall(r'conv3x3_wino_quad\w+\.private_seg_size, (\d+)', text)]
+    assert len(units) == 5 and len(usizes) == 5 and max(usizes) == 0, usizes
+    for fn in units:
+        assert fn.count('v_mfma_f32_16x16x4_f32') >= 256 and not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn)
     for fn in kernels:
         assert fn.count('v_mfma_f32_16x16x4_f32') >= 1024                           # the K loop is there ...
         assert not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn), fn.split('\n')[0]    # ... and no packed fp32 arithmetic beside it
