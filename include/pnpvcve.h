@@ -109,8 +109,8 @@ int pnp_generator_get_precision(const pnp_generator* g);
                                     Winograd F(2x2,3x3) form (conv_wino.hip): 2.25x fewer matrix FLOPs, still fp32 products and sums, NOT bit-identical
                                     to the direct kernels (summation order + the +-1 input transform: ~1e-6 per conv on unit-scale maps; whole-clip
                                     gates in tests/test_gpu_wino.py).  0 off | 1 (default): frames of up to 128 16x16 tiles one block per 8x8 quadrant
-                                    unit (input convs too), larger ones the persistent tile kernel (same values bit for bit; input convs from 512 tiles on) | 2: the tile
-                                    kernel and the multi-source input convs at every frame size */
+                                    unit, larger ones the persistent tile kernels (same values bit for bit) | 2: the tile
+                                    kernels at every frame size */
 #define PNP_OPT_COUNT 10
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);

@@ -691,12 +691,12 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     const int wopt = g->prec == PNP_PREC_F32 ? g->opt[PNP_OPT_WINOGRAD] : 0;
     // 1: a frame of N 16x16 tiles takes the quadrant-unit kernel up to N = 128 (4 N blocks; 128x128: 12 us per conv against the direct
     // kernel's 15 and the tile kernel's 26 on 64 of 256 CUs) and the persistent tile kernel above (240 tiles: 31 us against 48 direct);
-    // the input convs over wide sources likewise up to 128 tiles and from 512 on (direct kernels between).  2 = the tile kernels at
-    // every size (tests)
+    // the input convs over wide sources likewise (180x320, 240 tiles, fp32: 561 frames/s direct, 707 with the direct input convs kept,
+    // 712 with the multi-source tile kernel).  2 = the tile kernels at every size (tests)
     auto ntiles16 = [](int hh, int ww) { return (int64_t)((hh + 15) / 16) * ((ww + 15) / 16); };
     auto wino_ok = [&](int hh, int ww) { return wopt == 2 || wopt == 1; };
     auto wino_units = [&](int hh, int ww) { return wopt == 1 && ntiles16(hh, ww) <= 128; };
-    auto wino_ms_ok = [&](int hh, int ww) { return wopt == 2 || (wopt == 1 && (ntiles16(hh, ww) >= 512 || ntiles16(hh, ww) <= 128)); };
+    auto wino_ms_ok = [&](int hh, int ww) { return wopt == 2 || wopt == 1; };
     // every 64-channel map that is only read as an MFMA A operand gets an fp16 copy from its producer
     const bool mirrors = f16_maps && g->opt[PNP_OPT_F16_MIRRORS] && c.deform == 0 && W.x16 != nullptr;
     // ... and, optionally, the running map x INSIDE a branch too (input conv and every block write x16 next to x, every front

@@ -177,8 +177,7 @@ def test_fp16_mirrors_are_scheduled_consistently(stub_run):
 
 def test_winograd_option_routes_the_single_source_64_channel_convs(stub_run):
     """PNP_OPT_WINOGRAD (fp32 only): both halves of every BAE block and conv_hr carry a Winograd image and take conv_wino.hip; input
-    convs and the RGB / pixel-shuffle heads never do; option 1 = quadrant units up to 128 16x16 tiles, the tile kernel above (multi-source
-    input convs from 512 on), option 2 = tile kernel everywhere; the stub's
+    convs and the RGB / pixel-shuffle heads never do; option 1 = quadrant units up to 128 16x16 tiles, the tile kernels above, option 2 = tile kernels everywhere; the stub's
     range bookkeeping (errors == []) proved that every image -- the per-frame ones of the expert-mixed convs included -- was written
     before it was read, in the workspace the scheduler advertised."""
     _, _, docs, _ = stub_run
