@@ -900,6 +900,10 @@ def secondary_workloads(dev, T, no_cpu_baseline=False):
              steps=2, warmup=1, frames=100),
         dict(name='7x3x720x1280 fp32 with PNP_OPT_WINOGRAD = 0: the direct implicit-GEMM kernels of rounds 1-4 (exact fp32 MFMA 32x32x2), '
                   'same session as the headline', workload='720p', precision='fp32', vsr=False, clips=1, steps=3, warmup=1, winograd=0),
+        dict(name='7x3x180x320 fp32, 1 clip (240 16x16 tiles: the mid-size range, persistent Winograd tile kernels on less than one '
+                  'round of tiles)', workload='lr180', precision='fp32', vsr=False, clips=1, steps=5, warmup=2),
+        dict(name='7x3x180x320 fp32 with PNP_OPT_WINOGRAD = 0, same session', workload='lr180', precision='fp32', vsr=False, clips=1,
+             steps=5, warmup=2, winograd=0),
     ]
     cpu128 = None if no_cpu_baseline else cpu_baseline_128(T)
     for sp in specs:

@@ -192,15 +192,17 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
     assert full['value'] == d['value'] or abs(full['value'] - d['value']) < 1e-4 * d['value']
     assert 'definition' in full['roofline'] and 'device_ms_per_step' in full['roofline']      # the prose lives here, not on stdout
     sec = full['secondary']
-    assert len(sec) == 13 and sec[8]['clips_per_step'] == 2 and sec[8]['workload'] == '720p' and sec[8]['roofline']['per_launch_frac'] > 0
+    assert len(sec) == 15 and sec[8]['clips_per_step'] == 2 and sec[8]['workload'] == '720p' and sec[8]['roofline']['per_launch_frac'] > 0
     assert sec[9]['clips_per_step'] == 2 and sec[9]['precision'] == 'f16x3'
     # the reference configs' real clip length, and the direct kernels of rounds 1-4 in the same session
     assert sec[10]['workload'] == '720p' and '100x3x720x1280' in sec[10]['name'] and 0.9 * d['value'] < sec[10]['value'] < 1.05 * d['value']
     assert 'PNP_OPT_WINOGRAD = 0' in sec[11]['name'] and 0.55 * d['value'] < sec[11]['value'] < 0.85 * d['value']
-    e2e = sec[12]                                   # the whole tools/test.py loop on an on-disk tree
+    # mid-size frames (240 tiles): the tile kernels against the direct ones, same session
+    assert sec[12]['workload'] == 'lr180' and sec[13]['workload'] == 'lr180' and sec[12]['value'] > 1.1 * sec[13]['value'] > 0
+    e2e = sec[14]                                   # the whole tools/test.py loop on an on-disk tree
     assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
     assert e2e['seconds_total'] >= e2e['seconds_generator_forward'] > 0
-    for e in sec[:12]:
+    for e in sec[:14]:
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
             rf = e['roofline']
