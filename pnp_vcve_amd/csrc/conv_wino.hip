@@ -1,4 +1,4 @@
-// Winograd F(2x2,3x3) form of the 64 -> 64 channel 3x3 convs (BAE block halves, conv_hr) on the fp32 matrix pipe of gfx950.
+// Winograd F(2x2,3x3) form of the 64 -> 64 channel 3x3 convs (BAE block halves, conv_hr, input convs) on the fp32 matrix pipe of gfx950.
 //
 // Why: the direct implicit-GEMM kernels (conv_mfma.hip / conv_persist.hip) keep the chip inside fp32 MFMAs for > 99 % of a 720p clip
 // at 0.80 of the (power-limited) matrix peak -- the only lever left is fewer MFMAs per output pixel.  F(2x2,3x3) computes a 2x2
@@ -17,8 +17,10 @@
 //   * K outermost: 4 steps of 16 input channels (lane: channels 16 s + 4 kq + j, j = the four MFMA k-steps).  Per step a lane reads
 //     its 4x4 patch (16 ds_read_b128), forms V = B^T d B with 32 float4 adds -- rolled over the step's chunks, row i of V being
 //     rewritten for step s+1 right after chunk i of step s has consumed it -- and issues 16 positions x 4 N tiles x 4 = 256 MFMAs.
-//     fp32 MFMAs execute on the vector ALUs: every VALU instruction costs ~7 matrix cycles, so addresses are buffer descriptors +
-//     scalar offsets + immediates, and accumulators start from an inline-constant zero C operand instead of being cleared.
+//     fp32 MFMAs execute on the vector ALUs: a gap between two MFMAs that holds any VALU instruction costs ~9 cycles of matrix time
+//     + 4 per instruction, LDS / buffer / scalar instructions nothing (tools/ubench/ub_valu_gap.hip), so addresses are buffer
+//     descriptors + scalar offsets + immediates, accumulators start from an inline-constant zero C operand instead of being cleared,
+//     and products / transforms are lumped into few gaps where the register budget allows.
 //   * transformed weights (256 KB per conv; gamma of a dynamic conv folded in per frame, see launch_wino_images) stream L2 -> registers
 //     -> a 4-slot LDS ring in 16 chunks of 16 KB (chunk = step s, position row i), requested three chunks ahead; B fragments are read
 //     one position ahead of the MFMAs, across chunk seams too (chunk c+1 is visible since the barrier at the top of chunk c).
@@ -32,6 +34,11 @@
 //     map each wave runs ONE branch: which, it decides itself from the values it loaded (a zero plane adds exact zeros).
 //   * epilogue: Y = A^T M A in registers, + bias (* gamma), activation; one N tile at a time through 4 KiB of LDS per wave (the ring
 //     slot the tile's last chunk has just left) so that residual loads and stores move 16 B per lane (64-B channel runs per pixel).
+//   * quadrant units: the tiles beyond an XCD band's whole rounds are cut into four 8x8 units, one per block, the four waves splitting
+//     the output channels (the kernel's tail); conv3x3_wino_quad_kernel / _quad_ms_kernel run whole small frames that way.  Same
+//     arithmetic in the same order per accumulator: a pixel's value does not depend on the form that computed it.
+//   * the input convs over the virtual concat [frame, wide sources ...] are the MS instantiation (frame = one k-step, then one
+//     16-chunk segment per source into the same accumulators).
 #include "conv_mfma.h"
 #include <cstring>
 #include <type_traits>
