@@ -348,8 +348,14 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
             # only the planes that are nonzero on its pixels
             par = a['partitions'][0]                                    # (T,3,h,w)
             blk = torch.nn.functional.max_pool2d((par != 0).float(), 8, ceil_mode=True)     # (T,3,h/8,w/8): plane live on the block
-            run = blk.sum(1).mean().item()                              # branches run per wave quadrant (no dummy chunk)
-            branches = run
+            branches = blk.sum(1).mean().item()                         # planes live per wave quadrant
+            # a quadrant with ONE live plane that is constant on it needs no branch MFMAs at all: the plane is folded into the B
+            # fragments of four positions (64 FMAs per step; conv_wino.hip, pv_finish)
+            hi = torch.nn.functional.max_pool2d(par, 8, ceil_mode=True)
+            lo = -torch.nn.functional.max_pool2d(-par, 8, ceil_mode=True)
+            const = ((hi == lo) | (blk == 0)).all(1)                    # every plane constant (or dead) on the block
+            folded = const & (blk.sum(1) == 1)
+            run = (blk.sum(1) * (~folded).float()).mean().item()        # branches run as MFMAs per wave quadrant
             skipped_frac = 1 - (nb * (2 * 256 + 64 * run) + 256) / dense
             executed = ach * (1 - skipped_frac)
             kern = ('conv3x3_wino_kernel<PAR,RES> (the 64->64 BAE-block convs + conv_hr as Winograd F(2x2,3x3): fp32 MFMA 16x16x4, 16x16-pixel '

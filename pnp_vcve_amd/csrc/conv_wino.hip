@@ -52,10 +52,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int HP = 18, NPX = HP * HP;
 constexpr int SLAB_B = NPX * 64;              // bytes per 16-channel slab of the halo tile
 constexpr int RING_B = 4 * 16384;             // four 16-KiB weight chunks
-constexpr int PV_B = RING_B + 4 * SLAB_B;      // per thread 3 float4: the partition values of its tile's 4 pixels, signed (PAR)
+constexpr int PV_B = RING_B + 4 * SLAB_B;      // [plane j][thread] float4: the partition values of the thread's 4 pixels, signed (PAR); 3 x 4 KiB
 constexpr int BG_B = PV_B + 256 * 48;         // 64 floats: bias * gamma
 constexpr int WINO_LDS = BG_B + 256;          // 161024
 constexpr unsigned OOBW = 0xFFFFFFF0u;
+#ifndef WINO_FOLD
+#define WINO_FOLD 1       // A/B switch: a wave-uniform partition plane folded into the B fragments instead of run as MFMAs
+#endif
 #ifndef WINO_QUAD
 #define WINO_QUAD 1      // A/B switch of the quadrant units (conv3x3_wino_kernel's tail)
 #endif
@@ -212,7 +215,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     // decision whether the WAVE needs each branch at all (pv_finish).  The next tile's values are requested at the top of the epilogue and
     // finished behind it: inside the K loop their twelve registers tipped the branch kernels into scratch spills, and a spill reload is
     // an s_waitcnt vmcnt(0) -- it waits for every weight / halo request in flight
-    int need_next = 0;
+    int need_next = 0, fold_next = -1;
+    float foldc_next = 0.f;
     f32x4 pvr[3];
     auto pv_request = [&](int tq_, int y0, int x0) {
         if constexpr (PAR) {
@@ -230,15 +234,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     auto pv_finish = [&](int tq_) {
         if constexpr (PAR) {
             need_next = 0;
+            int uni = 0;               // bit j: plane j has ONE value on all 64 pixels of the wave
+            float uval[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 f32x4 v = pvr[j];
                 // which branches this WAVE needs: a plane that is zero on all of its 8x8 pixels contributes exact zeros
                 const bool nz = v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f;
                 if (__builtin_amdgcn_ballot_w64(nz) != 0) need_next |= 1 << j;
+                uval[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0])));
+                const bool same = v[0] == uval[j] && v[1] == uval[j] && v[2] == uval[j] && v[3] == uval[j];
+                if (__builtin_amdgcn_ballot_w64(!same) == 0) uni |= 1 << j;
                 v[1] = -v[1];                                     // positions (0,3) and (3,0) enter the output transform negated
                 v[2] = -v[2];
-                *reinterpret_cast<f32x4*>(smem + PV_B + tq_ * 48 + j * 16) = v;
+                *reinterpret_cast<f32x4*>(smem + PV_B + j * 4096 + tq_ * 16) = v;
+            }
+            // A one-hot map with one value per codec block (the loader's): exactly one plane is live on the wave's quadrant and constant
+            // there.  Its branch  p * conv1x1_j(x(centre))  is the 3x3 conv with the centre tap p w_j, whose Winograd image is
+            // p w_j / 4 * [+ -; - +] on positions (1,1) (1,2) (2,1) (2,2): the wave adds that to the B fragments of these four positions
+            // (64 FMAs per step) instead of running 64 more MFMAs per step.
+            fold_next = -1;
+            foldc_next = 0.f;
+            if (WINO_FOLD) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (need_next == (1 << j) && (uni >> j & 1)) {
+                        fold_next = j;
+                        foldc_next = 0.25f * uval[j];
+                    }
             }
         }
     };
@@ -350,11 +373,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         // tile's last one (then the next chunks are the next tile's RGB chunks), and the tile origin of the slabs it refills
         unsigned u_so = 0, u_so_next = 0, ref_so = nso;
         bool last_seg = true;
-        int need = 7;
+        int need = 7, fold = -1;
+        float foldc = 0.f;
+        f32x4 wj3, wjt[3];      // the folded plane's fragments: N tile 3 in registers, 0-2 parked in the wave's own partition-value rows of LDS
         if constexpr (PAR) {
             // par_flags != nullptr only ENABLES branch skipping here (the caller's PNP_OPT_PAR_SKIP switch): the decision is per wave,
             // taken from the values themselves when they were loaded (load_pv), not per 8x16 tile
             if (a.par_flags) need = __builtin_amdgcn_readfirstlane(need_next);
+            fold = __builtin_amdgcn_readfirstlane(fold_next);
+            foldc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, foldc_next)));
+            if (fold >= 0) need = 0;      // (the other two planes are zero on the whole quadrant: they would add exact zeros -- and the wave's
+                                          //  partition-value rows are about to hold fragments instead)
+            wj3 = f32x4{0.f, 0.f, 0.f, 0.f};
             // the four accumulators the branches add into start from zero (the others from an inline-constant zero C operand)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[0][n] = acc[3][n] = acc[12][n] = acc[15][n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -387,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     //  the first fragments of the chunk behind)
 #pragma unroll
                     for (int n = 0; n < 4; ++n) bf[1][n] = lds4((C & 3) * 16384 + (J * 4 + n) * 1024 + bl);
-                    const f32x4 pv = lds4(PV_B + tq * 48 + J * 16);
+                    const f32x4 pv = lds4(PV_B + J * 4096 + tq16);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -408,6 +438,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 if (need & 1) branch(I<0>{});
                 if (need & 2) branch(I<1>{});
                 if (need & 4) branch(I<2>{});
+                if (fold >= 0) {
+                    // the folded plane's 1x1 fragments of this step, wanted again in position rows 1 and 2 (the ring slot is gone by then):
+                    // N tiles 0-2 move to the wave's own partition-value rows (three 1-KiB pieces, unused while its plane is folded; the
+                    // address is the thread's ring offset + a constant), N tile 3 stays here
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) wjt[n] = lds4((C & 3) * 16384 + (unsigned)fold * 4096u + n * 1024 + bl);
+                    wj3 = lds4((C & 3) * 16384 + (unsigned)fold * 4096u + 3 * 1024 + bl);
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(smem + PV_B + n * 4096 + tq16) = wjt[n];
+                }
             }
             if constexpr (KIND == 0) {
                 // ---- position row PG of step S: 64 MFMAs, and between them -- ONE thing per MFMA gap, in this order, pinned with a
@@ -517,6 +557,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         if (g >= 40 && g < 44) {                 // ... then the column combination
                             const int c = g - 40;
                             V[4 * TR + c] = c == 0 ? sub4(tt[0], tt[2]) : (c == 1 ? add4(tt[1], tt[2]) : (c == 2 ? sub4(tt[2], tt[1]) : sub4(tt[1], tt[3])));
+                        }
+                    }
+                    if constexpr (PAR) {
+                        if ((PG == 1 || PG == 2) && (g == 11 || g == 12 || g == 13 || g == 27 || g == 28 || g == 29)) {
+                            // (unconditional, like the FMAs below with a zero factor when nothing is folded: a branch per gap costs the
+                            //  K loop its straight-line schedule; the rows hold finite partition values then)
+                            wjt[(g & 15) - 11] = lds4(PV_B + ((g & 15) - 11) * 4096 + tq16);
+                        }
+                        if ((PG == 1 || PG == 2) && (g == 15 || g == 31)) {
+                            // positions (1,1) (1,2) | (2,1) (2,2) are next: their fragments (read a position ago) take the folded plane
+                            {
+                                const int pjn = (g + 1) >> 4;
+                                const float cs = ((PG == 1) == (pjn == 1)) ? foldc : -foldc;
+                                const f32x4 c4 = {cs, cs, cs, cs};
+#pragma unroll
+                                for (int n = 0; n < 3; ++n) bf[pjn & 1][n] = __builtin_elementwise_fma(c4, wjt[n], bf[pjn & 1][n]);
+                                bf[pjn & 1][3] = __builtin_elementwise_fma(c4, wj3, bf[pjn & 1][3]);
+                            }
                         }
                     }
                     if (g >= 52 && g < 52 + NRING) {
@@ -747,7 +805,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             if (a.dbg) dbg_q1 = __builtin_amdgcn_s_memtime();
             // the partition values and the branch decision of this quadrant came through the tile pipeline (pv_request / pv_finish with
             // every wave on quadrant qquad)
-            const int needq = (PAR && a.par_flags) ? __builtin_amdgcn_readfirstlane(need_next) : 7;
+            int needq = (PAR && a.par_flags) ? __builtin_amdgcn_readfirstlane(need_next) : 7;
+            // (a folded plane as in the tiles: the same FMAs on the same fragments, so the values stay the tile form's bit for bit)
+            const int foldq = PAR ? __builtin_amdgcn_readfirstlane(fold_next) : -1;
+            const float foldcq = PAR ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, foldc_next))) : 0.f;
+            if (foldq >= 0) needq = 0;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if (s4 < 3) {
@@ -781,7 +843,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 if constexpr (PAR) {
                     auto qbranch = [&](auto j_c) {
                         constexpr int J = decltype(j_c)::value;
-                        const f32x4 pv = lds4(PV_B + (unsigned)((qquad << 6) | lane) * 48 + J * 16);
+                        const f32x4 pv = lds4(PV_B + J * 4096 + (unsigned)((qquad << 6) | lane) * 16);
                         f32x4 ax[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -801,6 +863,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     if (needq & 1) qbranch(I<0>{});
                     if (needq & 2) qbranch(I<1>{});
                     if (needq & 4) qbranch(I<2>{});
+                    if (foldq >= 0) {
+                        const f32x4 wq = foldq == 0 ? Bp[s4 & 1][0] : (foldq == 1 ? Bp[s4 & 1][1] : Bp[s4 & 1][2]);
+                        const f32x4 cp = {foldcq, foldcq, foldcq, foldcq}, cm = {-foldcq, -foldcq, -foldcq, -foldcq};
+                        Bq[s4 & 1][5] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][5]);
+                        Bq[s4 & 1][6] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][6]);
+                        Bq[s4 & 1][9] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][9]);
+                        Bq[s4 & 1][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][10]);
+                    }
                 }
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr)
@@ -904,7 +974,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
     // partition values of the lane's tile, signed as the output transform wants them (positions (0,3), (3,0) negated), and the branches
     // the unit needs at all (a plane that is zero on all 64 pixels adds exact zeros)
     float pq[3][4];
-    int needq = 7;
+    int needq = 7, foldq = -1;
+    float foldcq = 0.f;
     if constexpr (PAR) {
         int nz_any = 0;
 #pragma unroll
@@ -920,6 +991,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             if (__builtin_amdgcn_ballot_w64(nz) != 0) nz_any |= 1 << j;
         }
         if (a.par_flags) needq = __builtin_amdgcn_readfirstlane(nz_any);
+        // exactly one plane live on the unit and constant there: folded into the B fragments of positions (1,1) (1,2) (2,1) (2,2), as in
+        // the tile kernel (pv_finish there)
+        if (WINO_FOLD) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float uv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pq[j][0])));
+                const bool same = pq[j][0] == uv && -pq[j][1] == uv && -pq[j][2] == uv && pq[j][3] == uv;
+                if (nz_any == (1 << j) && __builtin_amdgcn_ballot_w64(!same) == 0) {
+                    foldq = j;
+                    foldcq = 0.25f * uv;
+                }
+            }
+            if (foldq >= 0) needq = 0;
+        }
     }
     const unsigned qo = (unsigned)((qy0 + 2 * kq) * W + qx0) * 256u + (unsigned)(wave * 16 + m) * 4u;
     float resq[16];
@@ -987,6 +1072,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             if (needq & 1) qbranch(I<0>{});
             if (needq & 2) qbranch(I<1>{});
             if (needq & 4) qbranch(I<2>{});
+            if (foldq >= 0) {
+                const f32x4 wq = foldq == 0 ? Bp[s4 & 1][0] : (foldq == 1 ? Bp[s4 & 1][1] : Bp[s4 & 1][2]);
+                const f32x4 cp = {foldcq, foldcq, foldcq, foldcq}, cm = {-foldcq, -foldcq, -foldcq, -foldcq};
+                Bq[s4 & 1][5] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][5]);
+                Bq[s4 & 1][6] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][6]);
+                Bq[s4 & 1][9] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][9]);
+                Bq[s4 & 1][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][10]);
+            }
         }
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr)

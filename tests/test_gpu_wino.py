@@ -125,6 +125,31 @@ def test_wino_front_half_with_partition_branches(hw, scale):
     assert d < TOL_OP * max(1.0, mag)
 
 
+@pytest.mark.parametrize('block', [4, 8, 16])
+def test_wino_front_half_folds_a_block_constant_plane_into_the_weights(block):
+    """a wave whose 8x8 quadrant sees ONE live partition plane with ONE value (the loader's one-hot / 255 maps on 8x8 or larger codec
+    blocks) adds  p w_j / 4 [+ -; - +]  to the B fragments of positions (1,1) (1,2) (2,1) (2,2) instead of running the branch as MFMAs; 4x4
+    blocks straddle every quadrant (nothing folds); all against fp64, tile kernel and unit kernel bit for bit the same"""
+    from pnp_vcve_amd import ops
+    h, w = 72, 88
+    x = gu.syn.uniform(19, 'x', (1, 64, h, w), -1, 1)
+    wt = gu.syn.uniform(19, 'w', (64, 64, 3, 3), -0.06, 0.06)
+    b = gu.syn.uniform(19, 'b', (64,), -0.1, 0.1)
+    gamma = gu.syn.uniform(19, 'g', (64,), 0.0, 1.0)
+    w1 = [gu.syn.uniform(19, f'w1{j}', (64, 64, 1, 1), -0.3, 0.3) * 25.5 for j in range(3)]
+    par = par_maps(23, h, w, 1.0 / 255.0, block=block, empty_rows=1)
+    ref = ref_conv(x, wt, b, gamma, w1, par, act=1)
+    u = ops.wino_image(ops.pack_conv3x3(G(wt)), G(gamma))
+    up = ops.wino_par_image(ops.pack_conv1x1([G(v) for v in w1]))
+    kw = dict(bias=G(b), gamma=G(gamma), wino_w1x1=up, par=G(par), act=1)
+    out = ops.conv3x3_wino(nhwc(x), u, par_flags=ops.par_tile_flags(G(par)), **kw)
+    assert torch.equal(out, ops.conv3x3_wino(nhwc(x), u, **kw))                       # with / without branch skipping
+    assert torch.equal(out, ops.conv3x3_wino(nhwc(x), u, units=True, **kw))           # tile kernel / unit kernel
+    d = float((nchw(out).double() - ref).abs().max())
+    print(block, 'max|winograd - fp64| =', d, 'max|ref| =', float(ref.abs().max()))
+    assert d < TOL_OP * max(1.0, float(ref.abs().max()))
+
+
 def test_wino_back_half_with_residual_and_branches_with_residual():
     """x + conv1(o) + b (sr_backbone_utils.py:313,329) and the channel-last order (branches AND residual in one launch, :314-327)"""
     from pnp_vcve_amd import ops
@@ -194,8 +219,11 @@ def test_wino_quadrant_units_equal_whole_tiles_bit_for_bit():
             for band in (0, 3, 7):
                 t0 = band * 450 + 448                               # the band's first unit tile (the second one is its right neighbour or wraps)
                 ty, tx = t0 // tiles_x, t0 % tiles_x
-                y0, x0 = max(0, 16 * ty - 16), max(0, min(16 * tx - 32, w - 128))      # (even offsets: the same 2x2 output tiles)
-                y1, x1 = min(h, y0 + 64), min(w, x0 + 128)
+                # (offsets are multiples of 8: the same 2x2 output tiles AND the same 8x8 quadrants, i.e. the same waves fold their
+                #  partition plane into the weights -- a quadrant that straddles two codec blocks runs the branch as MFMAs instead, which
+                #  differs in the last bits)
+                y0, x0 = max(0, 16 * ty - 16), max(0, min(16 * tx - 32, (w - 128) // 8 * 8))
+                y1, x1 = min(h, y0 + 64), min(w, x0 + 136)
                 xc, rc, pc = x[y0:y1, x0:x1].contiguous(), res[y0:y1, x0:x1].contiguous(), par[:, y0:y1, x0:x1].contiguous()
                 crop = fn(xc, rc, pc, ops.par_tile_flags(pc))
                 # interior of the crop (its border row / column sees zeros where the frame has pixels), frame borders included
