@@ -14,6 +14,9 @@ struct ConvArgs {
     const float* wwino_par; // ... and of wpar (launch_wino_par_image; 12288 floats); required with wwino when wpar is set
     const float* wwino_src[4]; // the input conv in Winograd form (source 0 the RGB frame, then 1..3 64-channel sources): the image of
     const float* wwino_rgb;    // wsrc[s] for s >= 1 (launch_wino_images) and of the frame's chunk wsrc[0] (launch_wino_rgb_image)
+    const int* par_any;        // with wwino + wpar (tile kernel): one word, != 0 iff the frame's partition map has a nonzero value anywhere
+                               // (launch_par_frame_any).  The conv is then launched twice behind a device-side gate: as a plain conv (runs iff
+                               // the word is 0: a frame without partition records, 1.3x faster) and with the branches (runs iff != 0)
     int wino_units;            // with wwino: one block per 8x8 quadrant unit (conv3x3_wino_quad_kernel: frames too small to fill the chip with 16x16 tiles)
     const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
     const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo
@@ -123,6 +126,7 @@ int launch_conv3x3_f16x3(const ConvArgs& a, int cfg, hipStream_t stream);
 // bits 0..2: plane j has a nonzero value in the tile; bits 3..5: every value of plane j in the tile is 0 or PNP_PAR_UNIT
 // frames consecutive (3, H, W) maps -> frames consecutive flag arrays
 int launch_par_tile_flags(const float* par, long par_plane, int* flags, int frames, int H, int W, hipStream_t stream);
+int launch_par_frame_any(const int* flags, int* any, int frames, int H, int W, hipStream_t stream);
 
 // conv_last on the vector ALUs (conv_last.hip): OIHW (3,64,3,3) -> [9][64][4]; 2304 floats
 int launch_pack_last_valu(const float* w_oihw, float* dst, hipStream_t stream);

@@ -425,6 +425,22 @@ __global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __rest
 }
 }  // namespace
 
+namespace {
+// any[f] = OR of frame f's tile flags (bits 0-2: a plane is nonzero somewhere in the frame): one block per frame
+__global__ __launch_bounds__(256) void par_frame_any_kernel(const int* __restrict__ flags, int* __restrict__ any, int tiles) {
+    int bits = 0;
+    for (int i = threadIdx.x; i < tiles; i += 256) bits |= flags[(long)blockIdx.x * tiles + i] & 7;
+    const int b0 = __syncthreads_or(bits & 1), b1 = __syncthreads_or(bits & 2), b2 = __syncthreads_or(bits & 4);
+    if (threadIdx.x == 0) any[blockIdx.x] = (b0 ? 1 : 0) | (b1 ? 2 : 0) | (b2 ? 4 : 0);
+}
+}  // namespace
+
+int launch_par_frame_any(const int* flags, int* any, int frames, int H, int W, hipStream_t stream) {
+    const int tiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    hipLaunchKernelGGL(par_frame_any_kernel, dim3(frames), dim3(256), 0, stream, flags, any, tiles);
+    return (int)hipGetLastError();
+}
+
 int launch_par_tile_flags(const float* par, long par_plane, int* flags, int frames, int H, int W, hipStream_t stream) {
     const int tiles_x = (W + TW - 1) / TW, tiles = tiles_x * ((H + TH - 1) / TH);
     hipLaunchKernelGGL(par_tile_flags_kernel, dim3(tiles, frames), dim3(128), 0, stream, par, par_plane, flags, H, W, tiles_x);

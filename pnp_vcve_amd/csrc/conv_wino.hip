@@ -106,6 +106,8 @@ struct WinoArgs {
     int nsrc;               // 1..3
     const float* rgb;       // the frame as (H,W,4) RGB0
     const float* Urgb;      // launch_wino_rgb_image: 4 chunks of 4 KiB
+    const int* gate;        // nullptr, or one word: the launch runs iff (*gate != 0) == (gate_mode == 2)  (ConvArgs::par_any)
+    int gate_mode;
     int quad;               // the tiles beyond an XCD band's whole rounds are worked on as four 8x8 quadrants by four blocks (see the kernel's tail)
 };
 
@@ -117,6 +119,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const int m = lane & 15, kq = lane >> 4;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + 15) >> 4, ntiles = tiles_x * ((H + 15) >> 4);
+    if (a.gate) {      // (block-uniform: a scalar load)
+        const int gv = __builtin_nontemporal_load(a.gate);
+        if ((gv != 0) != (a.gate_mode == 2)) return;
+    }
 
     // ---- strip of tiles: XCD x owns a contiguous band, dealt round-robin to its resident blocks (neighbouring halos share its L2)
     int tile, tstep, tend, qtile = -1, qquad = 0;
@@ -1439,6 +1445,25 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         w.Urgb = a.wwino_rgb;
         if (a.wino_units) hipLaunchKernelGGL(conv3x3_wino_quad_ms_kernel, dim3(4 * ntiles), dim3(256), 0, stream, w);
         else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    } else if (a.wpar && a.par_any) {
+        // a frame that MAY carry no partition record (the scheduler asks for this on I frames): the plain conv behind the gate "the
+        // frame's map is all zero", the branch kernel behind "it is not" -- one of the two returns at once (bit-identical results: a
+        // zero map adds exact zeros).  The branch kernel's structure costs 1.3x a plain conv even when no wave runs a branch.
+        WinoArgs p = w;
+        p.Upar = nullptr;
+        p.par = nullptr;
+        p.par_flags = nullptr;
+        p.gate = a.par_any;
+        p.gate_mode = 1;
+        w.gate = a.par_any;
+        w.gate_mode = 2;
+        if (a.residual) {
+            hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, p);
+            hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+        } else {
+            hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, p);
+            hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+        }
     } else if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);

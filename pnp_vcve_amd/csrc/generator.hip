@@ -358,6 +358,8 @@ struct ConvCall {
     ConvCall& bias(const float* b, int ystride = 0) { bias_ = b; bias_ystride_ = ystride; return *this; }
     ConvCall& gamma(const float* g) { gamma_ = g; return *this; }
     const int* par_flags_ = nullptr;
+    const int* par_any_ = nullptr;
+    ConvCall& gate(const int* frame_any) { par_any_ = frame_any; return *this; }       // see ConvArgs::par_any
     ConvCall& partition(const float* w1x1, const float* par, const int* tile_flags = nullptr) {
         wpar_ = w1x1;
         par_ = par;
@@ -398,6 +400,7 @@ struct Workspace {
     // PNP_PREC_F16 + mirrors: fp16 NHWC64 copies of the running map of a branch (x16) and of every frame's slot (slots16);
     // the MV-aligned key frame is then fp16 only and lives in kw
     uint16_t *x16, *slots16;
+    int* parany;      // per frame: OR of its tile flags (ConvArgs::par_any)
     int* parflags;    // per frame, per 8x16 tile: which partition planes are nonzero there (ConvArgs::par_flags)
     float* wino;      // PNP_PREC_F32: Winograd images of one branch's dynamic convs for the frame in flight (2 per block; gain folded in)
     int* queue;       // PNP_PREC_F16X3: the split kernel's tile queue (ConvArgs::tile_queue), 16 ints, zero between launches
@@ -455,6 +458,7 @@ Workspace carve(const pnp_generator* g, char* base, int t, int h, int w) {
     const bool mir = g->prec == PNP_PREC_F16 && g->cfg.deform == 0;      // sized whether or not PNP_OPT_F16_MIRRORS is on
     W.x16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32)) : nullptr;
     W.slots16 = mir ? reinterpret_cast<uint16_t*>(take(hw * 32 * t)) : nullptr;
+    W.parany = reinterpret_cast<int*>(take(t));        // (not last: the harness shrinks the workspace and expects the last region to be touched)
     W.parflags = reinterpret_cast<int*>(take((int64_t)t * ((w + 15) / 16) * ((h + 7) / 8)));
     W.queue = g->prec == PNP_PREC_F16X3 ? reinterpret_cast<int*>(take(16)) : nullptr;
     W.bytes = off;
@@ -722,6 +726,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             for (int s = 1; s < q.nsrc; ++s) a.wwino_src[s] = q.wsrc_wino_[s];
         }
         a.wino_units = (q.wino_ || a.wwino_rgb) ? q.units_ : 0;
+        a.par_any = (q.wino_ && q.wpar_ && !a.wino_units) ? q.par_any_ : nullptr;
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
@@ -823,6 +828,8 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         if (par_skip) {
             rc = launch_par_tile_flags(par_b, hw, W.parflags, t, h, w, st);
             if (rc) return rc;
+            if (wopt >= 1) rc = launch_par_frame_any(W.parflags, W.parany, t, h, w, st);      // (for the I frames' gated front halves)
+            if (rc) return rc;
         }
         // ---- CAA hyper-network (iconvsr_ipb_par.py:45-48)
         for (int t0 = 0; t0 < t; t0 += 32) {
@@ -916,6 +923,9 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const float* gam = (c.with_bias && c.with_se) ? W.gamma + (int64_t)i * 64 : nullptr;
             const float* parp = par_b + (int64_t)i * 3 * hw;
             const int* pflags = par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
+            // an I frame usually carries no partition record at all: its front halves are launched twice behind a device-side gate, as a
+            // plain conv (runs when the frame's map is all zero) and with the branches (runs otherwise)
+            const int* pany = (par_skip && wopt >= 1 && sl[i] == 73.0f) ? W.parany + i : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
             // fp16 mirrors: the input conv writes x16 next to x when it runs on the fp16 kernels at all (an RGB-only one does not)
@@ -959,7 +969,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
                     r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(g2)
-                                 .partition(packed + K.w1x1, parp, pflags).wino(u2, up).units(un).act(1).to(W.tmp1).f16_map(o16));
+                                 .partition(packed + K.w1x1, parp, pflags).gate(pany).wino(u2, up).units(un).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).wino(u1).units(un).residual(x).to(dst)
                                      .f16_map(s16).also16(dst16));
@@ -968,7 +978,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                                  .f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(g2)
-                                     .partition(packed + K.w1x1, parp, pflags).wino(u2, up).units(un).residual(x).to(dst).f16_map(s16).also16(dst16));
+                                     .partition(packed + K.w1x1, parp, pflags).gate(pany).wino(u2, up).units(un).residual(x).to(dst).f16_map(s16).also16(dst16));
                 }
                 if (r) return r;
                 x = dst;

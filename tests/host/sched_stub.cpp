@@ -215,6 +215,7 @@ static void conv_touch(const ConvArgs& a, int cfg, int gy, int path) {
         else RD("the 1x1 weight images", a.wpar, 3 * 4096 * 4);
         RD("the partition planes", a.par, (size_t)(2 * a.par_plane + hw) * 4);
         if (a.par_flags) RD("the partition tile flags", a.par_flags, (size_t)((a.W + 15) / 16) * ((a.H + 7) / 8) * 4);
+        if (a.par_any) RD("the frame's partition-record word", a.par_any, 4);
     }
     if (path == 0 && conv_wino_ms_eligible(a, cfg, gy) && !a.wwino) {
         RD("the frame's Winograd weight image", a.wwino_rgb, (size_t)PNP_WINO_RGB_FLOATS * 4);
@@ -331,6 +332,13 @@ int launch_par_tile_flags(const float* par, long plane, int* flags, int frames, 
     stub::note_launch(s);
     stub::RD("partition maps", par, (size_t)frames * 3 * plane * 4);
     stub::WR("partition tile flags", flags, (size_t)frames * ((W + 15) / 16) * ((H + 7) / 8) * 4);
+    return 0;
+}
+int launch_par_frame_any(const int* flags, int* any, int frames, int H, int W, hipStream_t s) {
+    stub::cur = "launch_par_frame_any";
+    stub::note_launch(s);
+    stub::RD("partition tile flags", flags, (size_t)frames * ((W + 15) / 16) * ((H + 7) / 8) * 4);
+    stub::WR("per-frame partition-record words", any, (size_t)frames * 4);
     return 0;
 }
 int launch_pack_last_valu(const float* w, float* dst, hipStream_t s) {

@@ -397,6 +397,28 @@ def test_generator_winograd_auto_mode_takes_the_unit_kernel_on_small_frames_and_
     assert torch.equal(run(m, clip), w1)                                        # branch skipping adds exact zeros here too
 
 
+def test_generator_i_frame_front_halves_behind_the_device_side_gate():
+    """I frames usually carry no partition record: their front halves are launched twice behind a device-side gate (plain conv iff the
+    frame's map is all zero, branch kernel otherwise; PNP_OPT_PAR_SKIP on, tile kernels).  Same bits as the ungated schedule for an I
+    frame without records, for an I frame WITH records (the gate then picks the branch kernel) and with channel-last blocks
+    (branches + residual)"""
+    from pnp_vcve_amd import _native, synthetic as syn
+    for extra in ({}, {'channel_first': False}):
+        cfg = dict(syn.DEFAULT_GENERATOR_CFG)
+        cfg.update(extra)
+        sd = syn.make_state_dict(cfg, seed=2025)
+        clip = syn.make_clip(seed=99, n=1, t=4, h=192, w=256, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)    # 192 tiles: tile kernels
+        assert float(np.abs(clip['partitions'][0, 0]).max()) == 0.0 and float(np.abs(clip['partitions'][0, 1]).max()) > 0.0
+        m = build(cfg, sd, 1)
+        for with_records in (False, True):
+            if with_records:
+                clip['partitions'][0, 0] = clip['partitions'][0, 1]         # an I frame that does carry records
+            m.set_option(_native.OPT_PAR_SKIP, 1)
+            gated = run(m, clip)
+            m.set_option(_native.OPT_PAR_SKIP, 0)                           # no tile flags, no gate: the branch kernel on every frame
+            assert torch.equal(run(m, clip), gated), (extra, with_records)
+
+
 def test_generator_winograd_720p_vs_oracle():
     """the headline shape against the oracle itself: 2 x 3 x 720 x 1280 (I then P: MV alignment, partition branches, both sweeps)"""
     from oracle import cpu_ref
