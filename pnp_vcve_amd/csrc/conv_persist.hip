@@ -421,17 +421,49 @@ __global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __rest
         // 1/255 at pack time and a MASKED A operand instead of re-splitting par_j(pixel) * x per fragment (conv_f16x3.hip).
         if (__syncthreads_and(v == 0.f || v == PNP_PAR_UNIT)) bits |= 8 << j;
     }
+    // bit 6: each 8x8 half of the tile (a wave's quadrant in the Winograd kernels) lies inside the image and is all zero, or has exactly
+    // ONE live plane that is constant on it -- what a one-hot map on >= 8x8 codec blocks gives; conv_wino.hip then folds the plane into
+    // its weights (launch_par_frame_any ANDs this over the frame: the fold-only kernel's gate)
+    {
+        __shared__ float first[2][3];
+        const int half = (threadIdx.x & 15) >> 3;
+        float vv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            vv[j] = in ? par[j * plane + (long)gy * W + gx] : 0.f;
+            if ((threadIdx.x & 7) == 0 && (threadIdx.x >> 4) == 0) first[half][j] = vv[j];
+        }
+        __syncthreads();
+        bool ok = ty * TH + TH <= H && tx * TW + TW <= W;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            int live = 0, varies = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (__syncthreads_or(half == h2 && vv[j] != 0.f)) ++live;
+                if (__syncthreads_or(half == h2 && vv[j] != first[h2][j])) ++varies;
+            }
+            ok = ok && (live == 0 || (live == 1 && varies == 0));
+        }
+        if (ok) bits |= 64;
+    }
     if (threadIdx.x == 0) flags[tile] = bits;
 }
 }  // namespace
 
 namespace {
-// any[f] = OR of frame f's tile flags (bits 0-2: a plane is nonzero somewhere in the frame): one block per frame
+// any[f]: frame f's tile flags reduced (one block per frame)
 __global__ __launch_bounds__(256) void par_frame_any_kernel(const int* __restrict__ flags, int* __restrict__ any, int tiles) {
-    int bits = 0;
-    for (int i = threadIdx.x; i < tiles; i += 256) bits |= flags[(long)blockIdx.x * tiles + i] & 7;
+    int bits = 0, notfold = 0;
+    for (int i = threadIdx.x; i < tiles; i += 256) {
+        const int f = flags[(long)blockIdx.x * tiles + i];
+        bits |= f & 7;
+        notfold |= !(f & 64);
+    }
     const int b0 = __syncthreads_or(bits & 1), b1 = __syncthreads_or(bits & 2), b2 = __syncthreads_or(bits & 4);
-    if (threadIdx.x == 0) any[blockIdx.x] = (b0 ? 1 : 0) | (b1 ? 2 : 0) | (b2 ? 4 : 0);
+    const int nf = __syncthreads_or(notfold);
+    // bits 0-2: a plane is nonzero somewhere in the frame; bit 3: every 8x8 quadrant of the frame is all zero or carries one constant plane
+    if (threadIdx.x == 0) any[blockIdx.x] = (b0 ? 1 : 0) | (b1 ? 2 : 0) | (b2 ? 4 : 0) | (nf ? 0 : 8);
 }
 }  // namespace
 

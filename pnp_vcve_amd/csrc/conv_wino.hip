@@ -106,8 +106,8 @@ struct WinoArgs {
     int nsrc;               // 1..3
     const float* rgb;       // the frame as (H,W,4) RGB0
     const float* Urgb;      // launch_wino_rgb_image: 4 chunks of 4 KiB
-    const int* gate;        // nullptr, or one word: the launch runs iff (*gate != 0) == (gate_mode == 2)  (ConvArgs::par_any)
-    int gate_mode;
+    const int* gate;        // nullptr, or one word (ConvArgs::par_any): the launch runs iff ((*gate & gate_mask) != 0) == (gate_want != 0)
+    int gate_mask, gate_want;
     int quad;               // the tiles beyond an XCD band's whole rounds are worked on as four 8x8 quadrants by four blocks (see the kernel's tail)
 };
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const int tiles_x = (W + 15) >> 4, ntiles = tiles_x * ((H + 15) >> 4);
     if (a.gate) {      // (block-uniform: a scalar load)
         const int gv = __builtin_nontemporal_load(a.gate);
-        if ((gv != 0) != (a.gate_mode == 2)) return;
+        if (((gv & a.gate_mask) != 0) != (a.gate_want != 0)) return;
     }
 
     // ---- strip of tiles: XCD x owns a contiguous band, dealt round-robin to its resident blocks (neighbouring halos share its L2)
@@ -1453,10 +1453,10 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         p.Upar = nullptr;
         p.par = nullptr;
         p.par_flags = nullptr;
-        p.gate = a.par_any;
-        p.gate_mode = 1;
-        w.gate = a.par_any;
-        w.gate_mode = 2;
+        p.gate = w.gate = a.par_any;
+        p.gate_mask = w.gate_mask = 7;       // "a plane is nonzero somewhere in the frame"
+        p.gate_want = 0;
+        w.gate_want = 1;
         if (a.residual) {
             hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, p);
             hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
