@@ -111,9 +111,15 @@ struct WinoArgs {
     int quad;               // the tiles beyond an XCD band's whole rounds are worked on as four 8x8 quadrants by four blocks (see the kernel's tail)
 };
 
-template <bool PAR, bool RES, bool MS>
+// FO ("fold only"): the front half of a frame whose EVERY 8x8 quadrant is all zero or carries one constant partition plane (the gate
+// of launch_conv3x3_wino: par_frame_any's bit 3): the plain kernel's chunk structure -- no branch chunks, no branch MFMAs, accumulators
+// from an inline zero -- plus, per step, the quadrant's plane folded into the B fragments of positions (1,1) (1,2) (2,1) (2,2) exactly
+// as the branch kernel does it for such a wave (same FMAs, same MFMA order: bit-identical values).  The plane and its value come from
+// one pixel of the quadrant; its 1x1 fragments straight from L2.
+template <bool PAR, bool RES, bool MS, bool FO = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) {
     static_assert(!MS || (!PAR && !RES), "the multi-source form is the input conv: no branches, no residual");
+    static_assert(!FO || (!PAR && !MS), "fold-only is the plain structure");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     const __amdgpu_buffer_rsrc_t r_u = rsrc_of(MS ? a.ubase : a.U, MS ? OOBW : 16u * 16384u);
     const __amdgpu_buffer_rsrc_t r_urgb = rsrc_of(MS ? a.Urgb : a.U, 4u * 4096u);
     const __amdgpu_buffer_rsrc_t r_rgb = rsrc_of(reinterpret_cast<const char*>(MS ? a.rgb : a.src) - ((long)W + 1) * 16, OOBW);
-    const __amdgpu_buffer_rsrc_t r_up = rsrc_of(PAR ? a.Upar : a.U, 4u * 12288u);
+    const __amdgpu_buffer_rsrc_t r_up = rsrc_of((PAR || FO) ? a.Upar : a.U, 4u * 12288u);
     const __amdgpu_buffer_rsrc_t r_out = rsrc_of(a.out, map_bytes);
     const __amdgpu_buffer_rsrc_t r_res = rsrc_of(RES ? a.residual : a.src, RES ? map_bytes : 0u);
     const __amdgpu_buffer_rsrc_t r_par = rsrc_of(a.par, PAR ? (unsigned)(3 * a.par_plane * 4) : 0u);
@@ -271,6 +277,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             }
         }
     };
+    // FO: plane and factor of the wave's quadrant of the tile at (y0, x0), from its first pixel (the frame passed the gate: the quadrant
+    // is all zero or one constant plane); requested at the top of an epilogue, finished behind it
+    float fov[3] = {0.f, 0.f, 0.f};
+    int fo_next = -1;
+    float foc_next = 0.f;
+    auto fo_request = [&](int y0, int x0, int quadrant) {       // quadrant < 0: the wave's own
+        if constexpr (FO) {
+            const int wv = quadrant >= 0 ? quadrant : __builtin_amdgcn_readfirstlane(t >> 6);
+            const int gy = y0 + 8 * (wv >> 1), gx = x0 + 8 * (wv & 1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fov[j] = (gy < H && gx < W) ? a.par[(long)j * a.par_plane + (long)gy * W + gx] : 0.f;
+        }
+    };
+    auto fo_finish = [&]() {
+        if constexpr (FO) {
+            fo_next = -1;
+            foc_next = 0.f;
+#pragma unroll
+            for (int j = 2; j >= 0; --j)
+                if (fov[j] != 0.f) {
+                    fo_next = j;
+                    foc_next = 0.25f * fov[j];
+                }
+        }
+    };
     // MS: the frame's halo (18 x 18 pixels x RGB0 = 5 KiB) lives where the branch kernels keep their partition values; pixel order as in
     // the slabs (even columns of a row first).  Thread t moves pixels t and t + 256 (clamped to 323: duplicates rewrite the same value)
     f32x4 rgbreg[2];
@@ -337,6 +368,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         rgb_store(t);
         pv_request(t, ty0, tx0);
         pv_finish(t);
+        fo_request(ty0, tx0, -1);
+        fo_finish();
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -382,6 +415,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         int need = 7, fold = -1;
         float foldc = 0.f;
         f32x4 wj3, wjt[3];      // the folded plane's fragments: N tile 3 in registers, 0-2 parked in the wave's own partition-value rows of LDS
+        f32x4 wjl[4];           // FO: the fragments on their way from L2
+        unsigned fo_so = 0;
+        if constexpr (FO) {
+            fold = __builtin_amdgcn_readfirstlane(fo_next);
+            foldc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, foc_next)));
+            fo_so = (unsigned)(fold > 0 ? fold : 0) * 4096u;
+            wj3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if constexpr (PAR) {
             // par_flags != nullptr only ENABLES branch skipping here (the caller's PNP_OPT_PAR_SKIP switch): the decision is per wave,
             // taken from the values themselves when they were loaded (load_pv), not per 8x16 tile
@@ -565,7 +606,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                             V[4 * TR + c] = c == 0 ? sub4(tt[0], tt[2]) : (c == 1 ? add4(tt[1], tt[2]) : (c == 2 ? sub4(tt[2], tt[1]) : sub4(tt[1], tt[3])));
                         }
                     }
-                    if constexpr (PAR) {
+                    if constexpr (FO) {
+                        // the plane's 1x1 fragments of this step: requested in position row 0, parked (N tiles 0-2) / kept (3) in row 1
+                        if (PG == 0 && g >= 14 && g < 18) wjl[g - 14] = bload4(r_up, bl, fo_so + S * 12288 + (g - 14) * 1024);
+                        if (PG == 1 && g >= 2 && g < 5) *reinterpret_cast<f32x4*>(smem + PV_B + (g - 2) * 4096 + tq16) = wjl[g - 2];
+                        if (PG == 1 && g == 5) wj3 = wjl[3];
+                    }
+                    if constexpr (PAR || FO) {
                         if ((PG == 1 || PG == 2) && (g == 11 || g == 12 || g == 13 || g == 27 || g == 28 || g == 29)) {
                             // (unconditional, like the FMAs below with a zero factor when nothing is folded: a branch per gap costs the
                             //  K loop its straight-line schedule; the rows hold finite partition values then)
@@ -704,6 +751,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         // (next = the block's quadrant unit: every wave fetches quadrant qquad's values)
         const int tqp = (!has_next && qtile >= 0) ? ((qquad << 6) | (tq & 63)) : tq;
         pv_request(tqp, nty0, ntx0);
+        fo_request(nty0, ntx0, (!has_next && qtile >= 0) ? qquad : -1);
         auto epilogue = [&](auto partial_c) {
             constexpr bool PARTIAL = decltype(partial_c)::value;
             const int lq = tq & 63, wq = tq >> 6, kqq = lq >> 4, mq = lq & 15;
@@ -762,6 +810,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         if (partial) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         pv_finish(tqp);
+        fo_finish();
         ++dbg_n;
         if (a.dbg) dbg_e += __builtin_amdgcn_s_memtime() - dbg_b;
         if (!has_next) break;
@@ -790,6 +839,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 #pragma unroll
                 for (int j = 0; j < 3; ++j) Bp[0][j] = bload4(r_up, wq16, (unsigned)(j * 4096));
             }
+            // FO: the unit's quadrant is all zero or one constant plane (fo_request looked at quadrant qquad for every wave)
+            f32x4 Bf[2];
+            const int foq = FO ? __builtin_amdgcn_readfirstlane(fo_next) : -1;
+            const unsigned foq_so = (unsigned)(foq > 0 ? foq : 0) * 4096u;
+            if constexpr (FO) Bf[0] = bload4(r_up, wq16, foq_so);
             // output offsets of the lane's 16 values: value (q = 2 a + b, r) is pixel (2 kq + a, 2 r + b) of the quadrant, channel 16 w + m
             const unsigned qo = (unsigned)((qy0 + 2 * kq) * W + qx0) * 256u + (unsigned)(wave * 16 + m) * 4u;
             float resq[16];
@@ -814,7 +868,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             int needq = (PAR && a.par_flags) ? __builtin_amdgcn_readfirstlane(need_next) : 7;
             // (a folded plane as in the tiles: the same FMAs on the same fragments, so the values stay the tile form's bit for bit)
             const int foldq = PAR ? __builtin_amdgcn_readfirstlane(fold_next) : -1;
-            const float foldcq = PAR ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, foldc_next))) : 0.f;
+            const float foldcq = PAR ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, foldc_next)))
+                                     : (FO ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, foc_next))) : 0.f);
             if (foldq >= 0) needq = 0;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
@@ -825,6 +880,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 #pragma unroll
                         for (int j = 0; j < 3; ++j) Bp[(s4 + 1) & 1][j] = bload4(r_up, wq16, (unsigned)((s4 + 1) * 12288 + j * 4096));
                     }
+                    if constexpr (FO) Bf[(s4 + 1) & 1] = bload4(r_up, wq16, (unsigned)((s4 + 1) * 12288) + foq_so);
                 }
                 f32x4 dq[4][4], tq4[4];
 #pragma unroll
@@ -877,6 +933,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         Bq[s4 & 1][9] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][9]);
                         Bq[s4 & 1][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][10]);
                     }
+                }
+                if constexpr (FO) {
+                    const f32x4 wq = Bf[s4 & 1];
+                    const f32x4 cp = {foldcq, foldcq, foldcq, foldcq}, cm = {-foldcq, -foldcq, -foldcq, -foldcq};
+                    Bq[s4 & 1][5] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][5]);
+                    Bq[s4 & 1][6] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][6]);
+                    Bq[s4 & 1][9] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][9]);
+                    Bq[s4 & 1][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][10]);
                 }
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr)
@@ -1389,6 +1453,8 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
     int cus = 256;
     const hipError_t attr_err = once.run([](int dev, int& g) {
         hipError_t e = hipSuccess;
+        const void* fo = reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false, true>);
+        e = hipFuncSetAttribute(fo, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
         const void* fns[5] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false>),
                               reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false>),
                               reinterpret_cast<const void*>(conv3x3_wino_kernel<true, false, false>),
@@ -1445,10 +1511,22 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         w.Urgb = a.wwino_rgb;
         if (a.wino_units) hipLaunchKernelGGL(conv3x3_wino_quad_ms_kernel, dim3(4 * ntiles), dim3(256), 0, stream, w);
         else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-    } else if (a.wpar && a.par_any) {
-        // a frame that MAY carry no partition record (the scheduler asks for this on I frames): the plain conv behind the gate "the
-        // frame's map is all zero", the branch kernel behind "it is not" -- one of the two returns at once (bit-identical results: a
-        // zero map adds exact zeros).  The branch kernel's structure costs 1.3x a plain conv even when no wave runs a branch.
+    } else if (a.wpar && a.par_any && !a.residual) {
+        // Two launches behind a device-side gate on the frame's partition word (launch_par_frame_any), one of which returns at once:
+        // the fold-only kernel when EVERY 8x8 quadrant of the frame is all zero or carries one constant plane (one-hot maps on >= 8x8
+        // codec blocks, frames without records), the branch kernel otherwise.  Bit-identical results either way.
+        WinoArgs f = w;
+        f.par_flags = nullptr;
+        f.gate = w.gate = a.par_any;
+        f.gate_mask = w.gate_mask = 8;
+        f.gate_want = 1;
+        w.gate_want = 0;
+        hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, f);
+        hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    } else if (a.wpar && a.par_any && a.par_iframe) {
+        // branches + residual in one launch (channel-last blocks), a frame that MAY carry no partition record (I frames): the plain conv
+        // behind the gate "the frame's map is all zero", the branch kernel behind "it is not" (bit-identical: a zero map adds exact
+        // zeros).  The branch kernel's structure costs 1.3x a plain conv even when no wave runs a branch.
         WinoArgs p = w;
         p.Upar = nullptr;
         p.par = nullptr;

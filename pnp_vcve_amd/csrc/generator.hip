@@ -359,7 +359,8 @@ struct ConvCall {
     ConvCall& gamma(const float* g) { gamma_ = g; return *this; }
     const int* par_flags_ = nullptr;
     const int* par_any_ = nullptr;
-    ConvCall& gate(const int* frame_any) { par_any_ = frame_any; return *this; }       // see ConvArgs::par_any
+    int iframe_ = 0;
+    ConvCall& gate(const int* frame_any, bool iframe) { par_any_ = frame_any; iframe_ = iframe ? 1 : 0; return *this; }       // see ConvArgs::par_any
     ConvCall& partition(const float* w1x1, const float* par, const int* tile_flags = nullptr) {
         wpar_ = w1x1;
         par_ = par;
@@ -727,6 +728,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         }
         a.wino_units = (q.wino_ || a.wwino_rgb) ? q.units_ : 0;
         a.par_any = (q.wino_ && q.wpar_ && !a.wino_units) ? q.par_any_ : nullptr;
+        a.par_iframe = q.iframe_;
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
@@ -923,9 +925,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const float* gam = (c.with_bias && c.with_se) ? W.gamma + (int64_t)i * 64 : nullptr;
             const float* parp = par_b + (int64_t)i * 3 * hw;
             const int* pflags = par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
-            // an I frame usually carries no partition record at all: its front halves are launched twice behind a device-side gate, as a
-            // plain conv (runs when the frame's map is all zero) and with the branches (runs otherwise)
-            const int* pany = (par_skip && wopt >= 1 && sl[i] == 73.0f) ? W.parany + i : nullptr;
+            // the frame's partition word (launch_par_frame_any) gates the front halves on the device: fold-only kernel / branch kernel
+            // (launch_conv3x3_wino); an I frame usually carries no record at all (its word is then 8: all quadrants zero)
+            const int* pany = (par_skip && wopt >= 1) ? W.parany + i : nullptr;
+            const bool ifr = sl[i] == 73.0f;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
             // fp16 mirrors: the input conv writes x16 next to x when it runs on the fp16 kernels at all (an RGB-only one does not)
@@ -969,7 +972,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
                     r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(g2)
-                                 .partition(packed + K.w1x1, parp, pflags).gate(pany).wino(u2, up).units(un).act(1).to(W.tmp1).f16_map(o16));
+                                 .partition(packed + K.w1x1, parp, pflags).gate(pany, ifr).wino(u2, up).units(un).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).wino(u1).units(un).residual(x).to(dst)
                                      .f16_map(s16).also16(dst16));
@@ -978,7 +981,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                                  .f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(g2)
-                                     .partition(packed + K.w1x1, parp, pflags).gate(pany).wino(u2, up).units(un).residual(x).to(dst).f16_map(s16).also16(dst16));
+                                     .partition(packed + K.w1x1, parp, pflags).gate(pany, ifr).wino(u2, up).units(un).residual(x).to(dst).f16_map(s16).also16(dst16));
                 }
                 if (r) return r;
                 x = dst;

@@ -398,10 +398,11 @@ def test_generator_winograd_auto_mode_takes_the_unit_kernel_on_small_frames_and_
 
 
 def test_generator_i_frame_front_halves_behind_the_device_side_gate():
-    """I frames usually carry no partition record: their front halves are launched twice behind a device-side gate (plain conv iff the
-    frame's map is all zero, branch kernel otherwise; PNP_OPT_PAR_SKIP on, tile kernels).  Same bits as the ungated schedule for an I
-    frame without records, for an I frame WITH records (the gate then picks the branch kernel) and with channel-last blocks
-    (branches + residual)"""
+    """front halves on the tile kernels are launched twice behind a device-side gate on the frame's partition word: the fold-only kernel
+    iff every 8x8 quadrant of the frame is all zero or one constant plane, the branch kernel otherwise (channel-last blocks, branches +
+    residual in one launch: plain conv iff an I frame's map is all zero, branch kernel otherwise).  Same bits as the ungated schedule
+    (PNP_OPT_PAR_SKIP off: the branch kernel everywhere) for an I frame without records, one WITH records, and a frame whose quadrants
+    straddle the codec blocks"""
     from pnp_vcve_amd import _native, synthetic as syn
     for extra in ({}, {'channel_first': False}):
         cfg = dict(syn.DEFAULT_GENERATOR_CFG)
@@ -410,9 +411,11 @@ def test_generator_i_frame_front_halves_behind_the_device_side_gate():
         clip = syn.make_clip(seed=99, n=1, t=4, h=192, w=256, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)    # 192 tiles: tile kernels
         assert float(np.abs(clip['partitions'][0, 0]).max()) == 0.0 and float(np.abs(clip['partitions'][0, 1]).max()) > 0.0
         m = build(cfg, sd, 1)
-        for with_records in (False, True):
-            if with_records:
+        for with_records in (False, True, 'straddling'):
+            if with_records is True:
                 clip['partitions'][0, 0] = clip['partitions'][0, 1]         # an I frame that does carry records
+            if with_records == 'straddling':                                # a frame whose quadrants straddle codec blocks: not foldable,
+                clip['partitions'][0, 2] = np.roll(clip['partitions'][0, 2], 4, axis=-1)      # the gate picks the branch kernel
             m.set_option(_native.OPT_PAR_SKIP, 1)
             gated = run(m, clip)
             m.set_option(_native.OPT_PAR_SKIP, 0)                           # no tile flags, no gate: the branch kernel on every frame
