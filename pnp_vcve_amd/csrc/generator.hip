@@ -927,8 +927,11 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const int* pflags = par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
             // the frame's partition word (launch_par_frame_any) gates the front halves on the device: fold-only kernel / branch kernel
             // (launch_conv3x3_wino); an I frame usually carries no record at all (its word is then 8: all quadrants zero)
-            const int* pany = (par_skip && wopt >= 1) ? W.parany + i : nullptr;
+            // (asked for where one of the two can run at all: the fold-only kernel wants whole 8x8 quadrants everywhere -- 180x320 has a
+            //  ragged last row of them and would only pay the 5-us return per launch --, channel-last blocks have the I-frame gate only)
             const bool ifr = sl[i] == 73.0f;
+            const bool gate_pays = c.channel_first ? (h % 8 == 0 && w % 8 == 0) : ifr;
+            const int* pany = (par_skip && wopt >= 1 && gate_pays) ? W.parany + i : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
             // fp16 mirrors: the input conv writes x16 next to x when it runs on the fp16 kernels at all (an RGB-only one does not)
