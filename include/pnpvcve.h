@@ -90,7 +90,8 @@ int pnp_generator_get_precision(const pnp_generator* g);
  * value 0/1 (PNP_OPT_WINOGRAD: 0/1/2); all default to 1 except PNP_OPT_F16_CHAIN_MIRRORS.  State lives in the handle. */
 #define PNP_OPT_F16_MAPS 0       /* PNP_PREC_F16: the map between the two halves of a BAE block / behind conv_hr is stored fp16 */
 #define PNP_OPT_PAR_SKIP 1       /* skip 1x1 partition branches whose plane is all zero on a tile (exact zeros); on I frames (no partition
-                                    record as a rule) also launch the front halves as plain convs behind a device-side "map is all zero" gate */
+                                    record as a rule) / frames whose every 8x8 quadrant is zero or one constant plane also launch the front halves in a cheaper
+                                    form behind a device-side gate on the frame's partition word (bit-identical results) */
 #define PNP_OPT_CONV_LAST_VALU 2 /* conv_last on the vector ALUs (<= 2e-6 from the MFMA kernel: other summation order) */
 #define PNP_OPT_PERSIST 3        /* persistent strip kernel for the 64->64 convs on frames with >= 1024 tiles */
 #define PNP_OPT_SMALL_F16 4      /* PNP_PREC_F16: tile-per-block fp16 kernel for the 64->64 convs on frames with < 1024 tiles */
