@@ -930,7 +930,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             // (asked for where one of the two can run at all: the fold-only kernel wants whole 8x8 quadrants everywhere -- 180x320 has a
             //  ragged last row of them and would only pay the 5-us return per launch --, channel-last blocks have the I-frame gate only)
             const bool ifr = sl[i] == 73.0f;
-            const bool gate_pays = c.channel_first ? (h % 8 == 0 && w % 8 == 0) : ifr;
+            const bool gate_pays = c.channel_first ? (h % 8 == 0 && w % 16 == 0) : ifr;      // (the flag tiles are 8 x 16 and must lie inside)
             const int* pany = (par_skip && wopt >= 1 && gate_pays) ? W.parany + i : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
