@@ -18,6 +18,7 @@ struct ConvArgs {
                                // (launch_par_frame_any).  The conv is then launched twice behind a device-side gate: as a plain conv (runs iff
                                // the word is 0: a frame without partition records, 1.3x faster) and with the branches (runs iff != 0)
     int par_iframe;            // with par_any: the frame's slice type is I (no partition record as a rule)
+    int par_iframe_only;       // with par_any: the frame has ragged 8x8 quadrants -- only the I-frame gate (plain conv / branch kernel) applies
     int wino_units;            // with wwino: one block per 8x8 quadrant unit (conv3x3_wino_quad_kernel: frames too small to fill the chip with 16x16 tiles)
     const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
     const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo

@@ -1455,6 +1455,8 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         hipError_t e = hipSuccess;
         const void* fo = reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false, true>);
         e = hipFuncSetAttribute(fo, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
+        const void* fo_res = reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false, true>);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fo_res, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
         const void* fns[5] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false>),
                               reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false>),
                               reinterpret_cast<const void*>(conv3x3_wino_kernel<true, false, false>),
@@ -1511,7 +1513,7 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         w.Urgb = a.wwino_rgb;
         if (a.wino_units) hipLaunchKernelGGL(conv3x3_wino_quad_ms_kernel, dim3(4 * ntiles), dim3(256), 0, stream, w);
         else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-    } else if (a.wpar && a.par_any && !a.residual) {
+    } else if (a.wpar && a.par_any && !a.par_iframe_only) {
         // Two launches behind a device-side gate on the frame's partition word (launch_par_frame_any), one of which returns at once:
         // the fold-only kernel when EVERY 8x8 quadrant of the frame is all zero or carries one constant plane (one-hot maps on >= 8x8
         // codec blocks, frames without records), the branch kernel otherwise.  Bit-identical results either way.
@@ -1521,12 +1523,17 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         f.gate_mask = w.gate_mask = 8;
         f.gate_want = 1;
         w.gate_want = 0;
-        hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, f);
-        hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+        if (a.residual) {        // channel-last blocks: branches + residual in one launch
+            hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, f);
+            hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+        } else {
+            hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, f);
+            hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+        }
     } else if (a.wpar && a.par_any && a.par_iframe) {
-        // branches + residual in one launch (channel-last blocks), a frame that MAY carry no partition record (I frames): the plain conv
-        // behind the gate "the frame's map is all zero", the branch kernel behind "it is not" (bit-identical: a zero map adds exact
-        // zeros).  The branch kernel's structure costs 1.3x a plain conv even when no wave runs a branch.
+        // a frame with ragged quadrants that MAY carry no partition record (I frames): the plain conv behind the gate "the frame's map
+        // is all zero", the branch kernel behind "it is not" (bit-identical: a zero map adds exact zeros).  The branch kernel's
+        // structure costs 1.3x a plain conv even when no wave runs a branch.
         WinoArgs p = w;
         p.Upar = nullptr;
         p.par = nullptr;

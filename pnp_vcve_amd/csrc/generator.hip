@@ -729,6 +729,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         a.wino_units = (q.wino_ || a.wwino_rgb) ? q.units_ : 0;
         a.par_any = (q.wino_ && q.wpar_ && !a.wino_units) ? q.par_any_ : nullptr;
         a.par_iframe = q.iframe_;
+        a.par_iframe_only = (q.H % 8 != 0 || q.W % 16 != 0) ? 1 : 0;
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
@@ -928,9 +929,10 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             // the frame's partition word (launch_par_frame_any) gates the front halves on the device: fold-only kernel / branch kernel
             // (launch_conv3x3_wino); an I frame usually carries no record at all (its word is then 8: all quadrants zero)
             // (asked for where one of the two can run at all: the fold-only kernel wants whole 8x8 quadrants everywhere -- 180x320 has a
-            //  ragged last row of them and would only pay the 5-us return per launch --, channel-last blocks have the I-frame gate only)
+            //  ragged last row of them and would only pay the 5-us return per launch: there only I frames are gated, plain conv / branch kernel)
             const bool ifr = sl[i] == 73.0f;
-            const bool gate_pays = c.channel_first ? (h % 8 == 0 && w % 16 == 0) : ifr;      // (the flag tiles are 8 x 16 and must lie inside)
+            const bool whole_q = h % 8 == 0 && w % 16 == 0;       // (the flag tiles are 8 x 16 and must lie inside)
+            const bool gate_pays = whole_q || ifr;
             const int* pany = (par_skip && wopt >= 1 && gate_pays) ? W.parany + i : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;

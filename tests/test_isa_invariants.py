@@ -74,11 +74,11 @@ def test_winograd_kernel_is_built_without_packed_fp32_valu_ops(tmp_path):
                           os.path.join(ROOT, 'pnp_vcve_amd', 'csrc', 'conv_wino.hip')], stderr=subprocess.DEVNULL)
     text = asm.read_text()
     kernels = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_kernel' in fn.split('\n')[0]]
-    assert len(kernels) == 6                                   # {plain, residual, branches, branches + residual, multi-source, fold-only}
+    assert len(kernels) == 7                                   # {plain, residual, branches, branches + residual, multi-source, fold-only (+ residual)}
     # the accumulators and the transformed patch live in REGISTERS: a source order hipcc does not like once put both arrays into scratch
     # memory (private_seg_size 1616: correct results, ten times slower) -- a few spill slots are tolerated
     sizes = [int(v) for v in re.findall(r'conv3x3_wino_kernel\w+\.private_seg_size, (\d+)', text)]
-    assert len(sizes) == 6 and max(sizes) <= 512, sizes
+    assert len(sizes) == 7 and max(sizes) <= 512, sizes
     # the quadrant-unit kernels of small frames (five instantiations): straight-line code, no spill slot at all, no packed fp32 either
     units = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_quad' in fn.split('\n')[0]]
     usizes = [int(v) for v in re.findall(r'conv3x3_wino_quad\w+\.private_seg_size, (\d+)', text)]
