@@ -63,8 +63,9 @@ def parse_args(argv=None):
                     help='fp16 path A/B: 0 no fp16 mirrors (r02 schedule), 1 frame slots + aligned key frame (default), 2 also the '
                          'running map inside a branch (PNP_OPT_F16_CHAIN_MIRRORS)')
     ap.add_argument('--winograd', type=int, default=None, choices=[0, 1, 2],
-                    help='PNP_OPT_WINOGRAD of the fp32 path: 0 direct kernels, 1 Winograd F(2x2,3x3) for the 64->64 convs on frames '
-                         'with >= 512 16x16 tiles, 2 on every frame size (default: the library default)')
+                    help='PNP_OPT_WINOGRAD of the fp32 path (include/pnpvcve.h): 0 direct kernels, 1 Winograd F(2x2,3x3) -- quadrant-unit '
+                         'kernels on frames of up to 128 16x16 tiles, persistent tile kernels above, 2 the tile kernels at every frame '
+                         'size (default: the library default)')
     ap.add_argument('--tile-queue', type=int, default=None, choices=[0, 1],
                     help='split-fp16 path A/B: 0 = every block walks a static share of the tiles, 1 (default) = per-XCD tile queue '
                          '(PNP_OPT_TILE_QUEUE)')
@@ -122,14 +123,42 @@ def committed_pmc_traffic(tag):
         return json.load(fh), os.path.relpath(f, ROOT)
 
 
-def _launch_weighted_traffic(pmc, prefix):
-    """launch-weighted mean HBM bytes per launch over the kernel variants whose summarised name starts with `prefix`"""
-    # (conv3x3_wino_kernel<PAR,RES,MS>: the multi-source instantiation is the input conv, not a block conv)
-    ks = [v for k, v in pmc.items() if (k.startswith(prefix) or '::' + prefix in k) and 'hbm_bytes_per_launch' in v
-          and not (prefix == 'conv3x3_wino_kernel' and k.replace(' ', '').endswith(',true>'))]
+def _wino_flags(name):
+    """(PAR, RES, MS, FO) of a summarised `conv3x3_wino_kernel<...>` name, None for anything else"""
+    import re
+    m = re.search(r'conv3x3_wino_kernel<\s*(true|false)\s*,\s*(true|false)\s*,\s*(true|false)\s*,\s*(true|false)\s*>', name)
+    return tuple(x == 'true' for x in m.groups()) if m else None
+
+
+def _launch_weighted_traffic(pmc, prefix, min_bytes=0.0):
+    """launch-weighted mean HBM bytes per launch over the kernel variants whose summarised name starts with `prefix`.
+
+    `conv3x3_wino_kernel<PAR,RES,MS,FO>` is several kernels under one symbol: the roofline of the block convs counts exactly the
+    single-source instantiations (MS = false: plain = conv_hr, RES = back halves, FO / PAR = front halves) -- the multi-source one
+    is the input conv -- and among those only launches that worked: a front half is launched twice behind a device-side gate and one
+    of the two returns after reading the frame's partition word (a few KB; `min_bytes` drops those variants)."""
+    ks = []
+    for k, v in pmc.items():
+        if not (k.startswith(prefix) or '::' + prefix in k) or 'hbm_bytes_per_launch' not in v:
+            continue
+        if prefix == 'conv3x3_wino_kernel':
+            f = _wino_flags(k)
+            if f is None or f[2]:
+                continue
+        if v['hbm_bytes_per_launch'] < min_bytes:
+            continue
+        ks.append(v)
     if not ks:
         return None
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
+
+
+def block_conv_algorithmic_bytes(h, w, num_blocks):
+    """algorithmic HBM bytes per launch of the fp32 block convs (launch-weighted over a frame's 2 x num_blocks halves of both
+    sweeps + conv_hr), fp32 pixel-major maps of 256 B per pixel: front half = read x + 3 partition planes + write o = 524 B / px,
+    back half = read o + residual x + write = 768 B / px, conv_hr = read + write = 512 B / px"""
+    nb = 2 * num_blocks
+    return (nb * 524 + nb * 768 + 512) / (2 * nb + 1) * h * w
 
 
 MAX_LINE_BYTES = 4096
@@ -155,7 +184,7 @@ def strict(obj, digits=6):
 # what the single stdout line keeps of a roofline object (the full objects, with their prose, go to bench_secondary.json)
 ROOFLINE_KEEP = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_us', 'frac_wall',
                  'algorithmic_frac', 'algorithmic_TFLOPs', 'winograd', 'frac_dense_par', 'hbm_frac', 'algorithmic_bytes_per_launch',
-                 'traffic_source')
+                 'traffic_ratio', 'traffic_source')
 
 
 def bounded_line(res):
@@ -338,10 +367,9 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
         executed = ach * (1 - skipped_frac)
         kern = ('conv3x3_persist_kernel<PAR> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, persistent strips)'
                 if big else 'conv3x3_mfma_kernel<2,2,1,2> (the 64->64 BAE-block convs + conv_hr; fp32 MFMA 32x32x2, 4x16 tiles)')
-        wopt = m.get_option(9)             # PNP_OPT_WINOGRAD
-        tiles16 = ((h + 15) // 16) * ((w + 15) // 16)
-        wino = wopt >= 1                   # auto: quadrant units up to 128 tiles, the persistent tile kernel above; 2: the tile kernel everywhere
-        units = wopt == 1 and tiles16 <= 128
+        from pnp_vcve_amd import _native
+        form = _native.wino_kernel_form(h, w, m.get_option(_native.OPT_WINOGRAD))      # the header's rule, stated once
+        wino, units = form is not None, form == 'units'
         if wino:
             # Winograd F(2x2,3x3) (csrc/conv_wino.hip): 16 transform positions per 2x2 output pixels instead of 36 taps -> the 3x3 part
             # executes 256/576 of the direct form's matrix FLOPs; the 1x1 branches run per 8x8-pixel quadrant (one wave), each wave
@@ -378,11 +406,14 @@ def rooflines(m, prof, cfg, a, T, h, w, steps, precision, vsr, pmc, pmc_src, den
              'winograd': bool(wino),
              'partition_branches_needed_per_tile': branches, 'partition_branch_chunks_run_per_tile': run,
              'traffic': _launch_weighted_traffic(pmc, ('conv3x3_wino_quad_kernel' if units else 'conv3x3_wino_kernel') if wino
-                                                 else 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>'),
+                                                 else 'conv3x3_persist_kernel' if big else 'conv3x3_mfma_kernel<2,2,1,2>',
+                                                 min_bytes=0.01 * 512 * h * w),      # (a gated return reads a few KB)
+             'algorithmic_bytes_per_launch': block_conv_algorithmic_bytes(h, w, cfg['num_blocks']),
              'traffic_source': pmc_src,
              'launches': cb['launches'], 'avg_launch_us': 1e3 * cb['ms'] / max(cb['launches'], 1),
              'all_convs_TFLOPs': conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
              'device_ms_per_step': dev_ms}
+        r['traffic_ratio'] = (r['traffic'] / r['algorithmic_bytes_per_launch']) if r['traffic'] else None
         if dense_prof is not None and dense_prof['conv_block']['ms'] > 0:
             d = dense_prof['conv_block']
             dach = d['work'] / (d['ms'] * 1e-3) / 1e12

@@ -89,9 +89,10 @@ int pnp_generator_get_precision(const pnp_generator* g);
 /* Per-generator execution switches (A/B and diagnostic; results are bit-identical either way unless stated).
  * value 0/1 (PNP_OPT_WINOGRAD: 0/1/2); all default to 1 except PNP_OPT_F16_CHAIN_MIRRORS.  State lives in the handle. */
 #define PNP_OPT_F16_MAPS 0       /* PNP_PREC_F16: the map between the two halves of a BAE block / behind conv_hr is stored fp16 */
-#define PNP_OPT_PAR_SKIP 1       /* skip 1x1 partition branches whose plane is all zero on a tile (exact zeros); on I frames (no partition
-                                    record as a rule) / frames whose every 8x8 quadrant is zero or one constant plane also launch the front halves in a cheaper
-                                    form behind a device-side gate on the frame's partition word (bit-identical results) */
+#define PNP_OPT_PAR_SKIP 1       /* skip 1x1 partition branches whose plane is all zero on a tile (exact zeros); on frames whose every 8x8
+                                    quadrant is zero or one constant plane on its pixels inside the image (any frame size) also launch the
+                                    front halves in a cheaper form behind a device-side gate on the frame's partition word (bit-identical
+                                    results) */
 #define PNP_OPT_CONV_LAST_VALU 2 /* conv_last on the vector ALUs (<= 2e-6 from the MFMA kernel: other summation order) */
 #define PNP_OPT_PERSIST 3        /* persistent strip kernel for the 64->64 convs on frames with >= 1024 tiles */
 #define PNP_OPT_SMALL_F16 4      /* PNP_PREC_F16: tile-per-block fp16 kernel for the 64->64 convs on frames with < 1024 tiles */
@@ -110,9 +111,10 @@ int pnp_generator_get_precision(const pnp_generator* g);
 #define PNP_OPT_WINOGRAD 9       /* PNP_PREC_F32: the single-source 64 -> 64 convs (both halves of a BAE block, conv_hr) and the input convs over wide sources in
                                     Winograd F(2x2,3x3) form (conv_wino.hip): 2.25x fewer matrix FLOPs, still fp32 products and sums, NOT bit-identical
                                     to the direct kernels (summation order + the +-1 input transform: ~1e-6 per conv on unit-scale maps; whole-clip
-                                    gates in tests/test_gpu_wino.py).  0 off | 1 (default): frames of up to 128 16x16 tiles one block per 8x8 quadrant
-                                    unit, larger ones the persistent tile kernels (same values bit for bit) | 2: the tile
-                                    kernels at every frame size */
+                                    gates in tests/test_gpu_wino.py).  0 off | 1 (default): frames of up to PNP_WINO_UNITS_MAX_TILES 16x16 tiles
+                                    one block per 8x8 quadrant unit, larger ones the persistent tile kernels (same values bit for bit) |
+                                    2: the tile kernels at every frame size.  This is the ONE statement of the rule */
+#define PNP_WINO_UNITS_MAX_TILES 128   /* ceil(h/16) * ceil(w/16) up to which PNP_OPT_WINOGRAD = 1 takes the quadrant-unit kernels */
 #define PNP_OPT_COUNT 10
 int pnp_generator_set_option(pnp_generator* g, int option, int value);
 int pnp_generator_get_option(const pnp_generator* g, int option);
@@ -241,7 +243,7 @@ int pnp_conv3x3_wino_f32(const float* src_dev, const float* wino_w_dev, const fl
                          const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
                          const float* residual_dev, int act, float* out_dev, int h, int w, void* stream);
 /* The same conv with one block per 8x8 QUADRANT of a 16x16 tile (four waves = four 16-channel slices of the output): what
- * pnp_generator_forward uses on frames too small to fill the chip with whole tiles (< 512 of them; PNP_OPT_WINOGRAD = 1).  Same
+ * pnp_generator_forward uses on frames too small to fill the chip with whole tiles (<= PNP_WINO_UNITS_MAX_TILES of them; PNP_OPT_WINOGRAD = 1).  Same
  * arguments, same values bit for bit. */
 int pnp_conv3x3_wino_units_f32(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
                                const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,

@@ -119,6 +119,15 @@ DEBUG_SIGNATURES['pnp_mv_warp_nhwc_f16out'] = (c_int, [c_void_p, c_void_p, c_voi
 (OPT_F16_MAPS, OPT_PAR_SKIP, OPT_CONV_LAST_VALU, OPT_PERSIST, OPT_SMALL_F16, OPT_SPARSE_EVAL, OPT_F16_MIRRORS, OPT_F16_CHAIN_MIRRORS,
  OPT_TILE_QUEUE, OPT_WINOGRAD) = range(10)
 CONV_AUTO, CONV_TILE, CONV_TILE_BIG = range(3)
+WINO_UNITS_MAX_TILES = 128      # PNP_WINO_UNITS_MAX_TILES (checked against the header by tests/test_native_abi.py)
+
+
+def wino_kernel_form(h, w, wopt):
+    """which Winograd kernels PNP_OPT_WINOGRAD = wopt takes on h x w frames: None (direct kernels), 'units' or 'tiles' (pnpvcve.h)"""
+    if wopt <= 0:
+        return None
+    tiles = ((h + 15) // 16) * ((w + 15) // 16)
+    return 'units' if wopt == 1 and tiles <= WINO_UNITS_MAX_TILES else 'tiles'
 
 _lib = None
 

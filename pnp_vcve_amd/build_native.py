@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libpnpvcve_hip.so')
-SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_wino.hip', 'conv_f16.hip', 'conv_f16x3.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
+SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_wino.hip', 'conv_wino_ms.hip', 'conv_f16.hip', 'conv_f16x3.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # per-source extras.  dcn.hip: hipcc's SLP vectoriser packs the scalar coordinate / weight arithmetic of the deformable gather into
 # v_pk_*_f32 pairs; every build with that packing gave wrong, run-to-run varying samples in the fp16 instantiation under some
@@ -25,7 +25,18 @@ EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize'],
                #   and lands in scratch MEMORY (private_segment 1616 B, results right, ten times slower).  That is what "source orders
                #   hipcc does not like" were in DESIGN.md 8; with the limit out of the way partial effects go too (22 -> 13, 65 -> 46
                #   spill slots in the residual kernels)
-               'conv_wino.hip': ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops', '-mllvm', '-pragma-unroll-threshold=1000000']}
+               'conv_wino.hip': None, 'conv_wino_ms.hip': None}
+_WINO = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops', '-mllvm', '-pragma-unroll-threshold=1000000']
+# conv_wino.hip (r06): the straight-line tile kernels keep all 64 accumulator quads in AGPRs only if the allocator does not park some of
+# them in arch VGPRs between uses: with LLVM's default local assignment order a tile's K loop holds ~100 v_accvgpr_read + ~70
+# v_accvgpr_write (each one a vector-ALU instruction in an MFMA gap, the reads behind an s_nop); -greedy-reverse-local-assignment leaves
+# ~30 reads and no write (tools/isa_chunks.py; block convs 333 -> 329 us).  The multi-source instantiation (conv_wino_ms.hip = the same
+# source, WINO_MS_TU) carries its accumulators around a run-time loop over the sources and LOSES with that flag (more spill slots,
+# 79.1 -> 77.3 frames/s when everything was built with it): hence two translation units.
+EXTRA_FLAGS['conv_wino.hip'] = _WINO + ['-mllvm', '-greedy-reverse-local-assignment']
+EXTRA_FLAGS['conv_wino_ms.hip'] = list(_WINO)
+# sources a translation unit #includes (beyond the headers)
+INCLUDES = {'conv_wino_ms.hip': ['conv_wino.hip']}
 
 
 def _stale(target, deps):
@@ -47,7 +58,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _stale(o, [s, os.path.abspath(__file__)] + headers):
+        if force or _stale(o, [s, os.path.abspath(__file__)] + headers + [os.path.join(CSRC, i) for i in INCLUDES.get(src, [])]):
             cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)

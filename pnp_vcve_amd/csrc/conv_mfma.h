@@ -14,11 +14,9 @@ struct ConvArgs {
     const float* wwino_par; // ... and of wpar (launch_wino_par_image; 12288 floats); required with wwino when wpar is set
     const float* wwino_src[4]; // the input conv in Winograd form (source 0 the RGB frame, then 1..3 64-channel sources): the image of
     const float* wwino_rgb;    // wsrc[s] for s >= 1 (launch_wino_images) and of the frame's chunk wsrc[0] (launch_wino_rgb_image)
-    const int* par_any;        // with wwino + wpar (tile kernel): one word, != 0 iff the frame's partition map has a nonzero value anywhere
-                               // (launch_par_frame_any).  The conv is then launched twice behind a device-side gate: as a plain conv (runs iff
-                               // the word is 0: a frame without partition records, 1.3x faster) and with the branches (runs iff != 0)
-    int par_iframe;            // with par_any: the frame's slice type is I (no partition record as a rule)
-    int par_iframe_only;       // with par_any: the frame has ragged 8x8 quadrants -- only the I-frame gate (plain conv / branch kernel) applies
+    const int* par_any;        // with wwino + wpar (tile kernel): the frame's partition word (launch_par_frame_any; bit 3 = every 8x8 quadrant of
+                               // the frame is all zero or carries one constant plane).  The conv is then launched twice behind a device-side
+                               // gate: the fold-only kernel (runs iff bit 3 is set) and the branch kernel (iff not); any frame size
     int wino_units;            // with wwino: one block per 8x8 quadrant unit (conv3x3_wino_quad_kernel: frames too small to fill the chip with 16x16 tiles)
     const float* wvalu;     // conv_last only: [9][64][4] weights for the vector-ALU kernel (conv_last.hip), or nullptr
     const void* wsrc_h[4];  // prec == 1: fp16 twins of wsrc / wpar (conv_f16.hip); prec == 2: their split images (hi and lo

@@ -421,9 +421,11 @@ __global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __rest
         // 1/255 at pack time and a MASKED A operand instead of re-splitting par_j(pixel) * x per fragment (conv_f16x3.hip).
         if (__syncthreads_and(v == 0.f || v == PNP_PAR_UNIT)) bits |= 8 << j;
     }
-    // bit 6: each 8x8 half of the tile (a wave's quadrant in the Winograd kernels) lies inside the image and is all zero, or has exactly
-    // ONE live plane that is constant on it -- what a one-hot map on >= 8x8 codec blocks gives; conv_wino.hip then folds the plane into
-    // its weights (launch_par_frame_any ANDs this over the frame: the fold-only kernel's gate)
+    // bit 6: each 8x8 half of the tile (a wave's quadrant in the Winograd kernels) is, ON ITS PIXELS INSIDE THE IMAGE, all zero or has
+    // exactly ONE live plane that is constant there -- what a one-hot map on >= 8x8 codec blocks gives; conv_wino.hip then folds the plane
+    // into its weights (launch_par_frame_any ANDs this over the frame: the fold-only kernel's gate).  A half cut by the frame's edge
+    // (180x320: the last row of quadrants is 4 pixels high) counts with the pixels it has, one wholly outside counts as empty: the
+    // Winograd kernels read the values of outside pixels from the nearest inside one (pv_request's clamp), so they decide alike
     {
         __shared__ float first[2][3];
         const int half = (threadIdx.x & 15) >> 3;
@@ -431,17 +433,17 @@ __global__ __launch_bounds__(128) void par_tile_flags_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             vv[j] = in ? par[j * plane + (long)gy * W + gx] : 0.f;
-            if ((threadIdx.x & 7) == 0 && (threadIdx.x >> 4) == 0) first[half][j] = vv[j];
+            if ((threadIdx.x & 7) == 0 && (threadIdx.x >> 4) == 0) first[half][j] = vv[j];       // (row 0 of a tile is inside the image)
         }
         __syncthreads();
-        bool ok = ty * TH + TH <= H && tx * TW + TW <= W;
+        bool ok = true;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             int live = 0, varies = 0;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (__syncthreads_or(half == h2 && vv[j] != 0.f)) ++live;
-                if (__syncthreads_or(half == h2 && vv[j] != first[h2][j])) ++varies;
+                if (__syncthreads_or(half == h2 && in && vv[j] != first[h2][j])) ++varies;
             }
             ok = ok && (live == 0 || (live == 1 && varies == 0));
         }

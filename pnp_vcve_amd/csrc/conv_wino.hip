@@ -59,6 +59,15 @@ constexpr unsigned OOBW = 0xFFFFFFF0u;
 #ifndef WINO_FOLD
 #define WINO_FOLD 1       // A/B switch: a wave-uniform partition plane folded into the B fragments instead of run as MFMAs
 #endif
+#ifndef WINO_JIT_ROWS
+#define WINO_JIT_ROWS 1   // A/B switch: the two patch rows a V row needs are read from the slab in the chunk that transforms them (32 transient
+#endif                    // registers) instead of living in four row arrays across the K loop and the epilogue (48-64 registers)
+#ifndef WINO_MS_FLAT
+#define WINO_MS_FLAT 0    // A/B switch (MS): 1 = no run-time `last source?` branch inside a chunk (descriptor / strides of the next segment as per-segment
+#endif                    // scalars, the RGB halo re-fetched by every segment); 0 = round 5's branches
+#ifndef WINO_MS_LAUNDER
+#define WINO_MS_LAUNDER 1 // A/B switch (MS): the thread id laundered per segment for the halo offsets (2: for every per-lane constant of the chunks)
+#endif
 #ifndef WINO_QUAD
 #define WINO_QUAD 1      // A/B switch of the quadrant units (conv3x3_wino_kernel's tail)
 #endif
@@ -236,8 +245,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             const int py = y0 + 2 * (4 * (wq_ >> 1) + (mq >> 2)), px = x0 + 2 * (4 * (wq_ & 1) + (mq & 3));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int gy = py + (q >> 1), gx = px + (q & 1);
-                const unsigned po = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOBW;
+                // (a pixel outside the image takes the value of the nearest one inside: its own product is with x = 0 and its output is
+                //  never stored, but a quadrant cut by the frame's edge then looks as constant to the wave as its inside part is -- and
+                //  folds, like in the fold-only kernel and in par_tile_flags' bit 6)
+                const int gy = min(py + (q >> 1), H - 1), gx = min(px + (q & 1), W - 1);
+                const unsigned po = (unsigned)(gy * W + gx) * 4u;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) pvr[j][q] = bload1(r_par, po, (unsigned)(j * a.par_plane * 4));
             }
@@ -407,11 +419,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         const int nty0 = (ptile / tiles_x) * 16, ntx0 = (ptile % tiles_x) * 16;
         const unsigned nso = (unsigned)(nty0 * W + ntx0) * 256u;
         if constexpr (!MS) halo_offsets(tq, nty0, ntx0);
-        const unsigned tq16 = (unsigned)tq * 16u;
+        unsigned tq16 = (unsigned)tq * 16u;
+        int tqk = tq;            // the thread id the chunks derive their per-lane constants from (MS: laundered once more per segment)
         // MS: per segment (= one 64-channel source): where its weight image starts, where the next segment's does, whether it is the
         // tile's last one (then the next chunks are the next tile's RGB chunks), and the tile origin of the slabs it refills
-        unsigned u_so = 0, u_so_next = 0, ref_so = nso;
+        unsigned u_so = 0, ref_so = nso, nx_base = 0, nx_cs = 16384, nx_ps = 4096;
         bool last_seg = true;
+        __amdgpu_buffer_rsrc_t r_nx = r_u;
         int need = 7, fold = -1;
         float foldc = 0.f;
         f32x4 wj3, wjt[3];      // the folded plane's fragments: N tile 3 in registers, 0-2 parked in the wave's own partition-value rows of LDS
@@ -458,6 +472,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 // first the fragments of the following position chunk (visible since the previous barrier)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) bf[0][n] = lds4(((C + 1) & 3) * 16384 + bl + n * 1024);
+                // (WINO_JIT_ROWS: the patch centre of step S straight from slab S -- its refill starts in position chunk 1 of this step)
+                f32x4 xc[4];
+                if (WINO_JIT_ROWS && need != 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xc[q] = patch(s_c, 1 + (q >> 1), 1 + (q & 1));
+                }
                 auto branch = [&](auto j_c) {
                     constexpr int J = decltype(j_c)::value;
                     // (the branch's B fragments go where position 3 of the chunk in front kept its own: bf[1] is free, bf[0] holds
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         __builtin_amdgcn_sched_barrier(0);
-                        f32x4 ax = (q == 0 ? d1[1] : (q == 1 ? d1[2] : (q == 2 ? d2[1] : d2[2]))) * pv[q];
+                        f32x4 ax = (WINO_JIT_ROWS ? xc[q] : (q == 0 ? d1[1] : (q == 1 ? d1[2] : (q == 2 ? d2[1] : d2[2])))) * pv[q];
                         // (all four products in ONE gap: left alone each v_mul sits in front of its first MFMA, and a gap with any VALU
                         //  instruction costs ~20 cycles of matrix time before the 4 per instruction)
                         asm volatile("" : "+v"(ax));
@@ -508,6 +528,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 constexpr int NRING = NBR ? 3 : 4;
                 constexpr bool NEXT_IS_BR = PAR && PG == 3;      // the next chunk is a branch chunk: it reads its own fragments
                 constexpr int TR = PG == 0 ? 3 : PG - 1;         // the V row rewritten in this chunk (row 3 of step S, or row PG - 1 of S + 1)
+                // WINO_JIT_ROWS: V row TR = column transform of (patch row RA -/+ patch row RB): row 3 = d1 - d3 of step S (slab S is refilled from
+                // position chunk 1 of step S on: still this tile's here), rows 0 / 1 / 2 = d0 - d2 / d1 + d2 / d2 - d1 of step S + 1.  Both rows are
+                // read in this chunk and dead behind the transform: no patch row lives across a chunk, the epilogue or the tile seam
+                using SR = I<PG == 0 ? S : ((S + 1) & 3)>;
+                constexpr int RA = PG == 0 ? 1 : (PG == 1 ? 0 : (PG == 2 ? 1 : 2)), RB = PG == 0 ? 3 : (PG == 1 ? 2 : (PG == 2 ? 2 : 1));
+                f32x4 da[4], db[4];
                 f32x4 bgv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 64; ++g) {
@@ -526,33 +552,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         *reinterpret_cast<f32x4*>(smem + (NCB & 3) * 16384 + g * 4096 + tq16) = breg[g];
                     }
                     if ((g & 15) < 4 && !(pj == 3 && NEXT_IS_BR)) {
-                        // (MS, the tile's last chunk: the next one is an RGB chunk of the next tile, which reads its own fragments)
-                        if (!(MS && C == 15 && pj == 3 && last_seg)) {
+                        // (MS, the tile's last chunk: the next one is an RGB chunk of the next tile, which reads its own fragments -- the read
+                        //  here is then of no use, and harmless; a run-time `if (last_seg)` per gap would cut the straight-line schedule)
+                        if (WINO_MS_FLAT || !(MS && C == 15 && pj == 3 && last_seg)) {
                             const unsigned nb = pj < 3 ? (C & 3) * 16384 + (pj + 1) * 4096 : ((C + 1) & 3) * 16384;
                             bf[(pj + 1) & 1][g & 3] = lds4(nb + bl + (g & 3) * 1024);
                         }
                     }
                     if constexpr (MS) {
                         // the chunk three ahead: this source's, the next source's first chunks, or (last source) the next tile's RGB chunks,
-                        // which are one 4-KiB piece each
+                        // which are one 4-KiB piece each.  Branch-free: descriptor, base, chunk and piece stride of "the next segment" are
+                        // per-segment scalars (last source: the RGB image with piece stride 0 -- its one piece is fetched four times and lands
+                        // in all four quarters of the ring slot, of which an RGB chunk reads the first)
                         if (g >= 4 && g < 8) {
                             if (C < 13) breg[g - 4] = bload4(r_u, tq16, u_so + (C + 3) * 16384 + (g - 4) * 4096);
-                            else if (!last_seg) breg[g - 4] = bload4(r_u, tq16, u_so_next + (C - 13) * 16384 + (g - 4) * 4096);
+                            else if (WINO_MS_FLAT) breg[g - 4] = bload4(r_nx, tq16, nx_base + (C - 13) * nx_cs + (g - 4) * nx_ps);
+                            else if (!last_seg) breg[g - 4] = bload4(r_u, tq16, nx_base + (C - 13) * 16384 + (g - 4) * 4096);
                             else if (g == 4) breg[0] = bload4(r_urgb, tq16, (C - 13) * 4096);
                         }
                     } else if (g >= 4 && g < 4 + NRING)
                         breg[g - 4] = NBR ? bload4(r_up, tq16, NSTEP * 12288 + (g - 4) * 4096) : bload4(r_u, tq16, (NSTEP * 4 + NPG) * 16384 + (g - 4) * 4096);
-                    if (S == 0 && PG == 1 && g == 7) bgv = *reinterpret_cast<const f32x4*>(smem + BG_B + (tq & 15) * 16);
+                    if (S == 0 && PG == 1 && g == 7) bgv = *reinterpret_cast<const f32x4*>(smem + BG_B + (tqk & 15) * 16);
                     if ((PG == 1 || PG == 2) && g >= 8 && g < 11) {        // (before this chunk's own halo requests reuse the registers)
-                        int e = tq + 256 * (g - 8 + 3 * (PG - 1));
+                        int e = tqk + 256 * (g - 8 + 3 * (PG - 1));
                         e = e < NPX * 4 ? e : NPX * 4 - 1;
                         *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[g - 8];
                     }
                     if ((PG == 0 || PG == 1) && g >= 11 && g < 14) hreg[g - 11] = bload4(r_src, hoff[g - 11 + 3 * PG], ref_so + S * 64);
                     // MS, last source: the next tile's RGB halo, requested in step 1 and stored a chunk later (this tile's RGB patch was read
                     // before its first chunk)
-                    if (MS && S == 1 && PG == 0 && g == 14 && last_seg) rgb_request(tq, nty0, ntx0);
-                    if (MS && S == 1 && PG == 1 && g == 14 && last_seg) rgb_store(tq);
+                    // (every segment does it: the same pixels again, but no run-time branch in the chunk and no value that lives across one)
+                    if (MS && S == 1 && PG == 0 && g == 14 && (WINO_MS_FLAT || last_seg)) rgb_request(tqk, nty0, ntx0);
+                    if (MS && S == 1 && PG == 1 && g == 14 && (WINO_MS_FLAT || last_seg)) rgb_store(tqk);
                     if (RES && S == 3 && PG == 0 && g == 16 && !(ty0 + 16 > H || tx0 + 16 > W)) {
                         // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (8 rows x
                         // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
@@ -571,9 +602,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     // cycles of matrix time before the 4 per instruction (tools/ubench/ub_valu_gap.hip; front half 427 -> 423 us).  The
                     // plain kernels keep one float4 per gap: lumped, the residual kernel spills 22 instead of 13 registers (+3 %).
                     if constexpr (PAR) {
+                        if (WINO_JIT_ROWS && g >= 8 && g < 16) {   // (beside the halo pieces: LDS reads cost the matrix pipe nothing)
+                            const int c = g & 3;
+                            if (g < 12) da[c] = patch(SR{}, RA, c);
+                            else db[c] = patch(SR{}, RB, c);
+                        }
                         if (g == 16) {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) tt[c] = TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
+                            for (int c = 0; c < 4; ++c)
+                                tt[c] = WINO_JIT_ROWS ? (TR == 1 ? da[c] + db[c] : da[c] - db[c])
+                                                      : TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
                         }
                         if (g == 17) {
 #pragma unroll
@@ -582,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                                 asm volatile("" : "+v"(V[4 * TR + c]));
                             }
                         }
-                        if (g >= 28 && g < 36) {                 // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
+                        if (!WINO_JIT_ROWS && g >= 28 && g < 36) {                 // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
                             const int c = (g - 28) & 3;
                             if (PG == 0 && g < 32) d0[c] = patch(SN{}, 0, c);
                             if (PG == 0 && g >= 32) d2[c] = patch(SN{}, 2, c);
@@ -590,7 +628,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                             if (PG == 2 && g < 32) d3[c] = patch(SN{}, 3, c);
                         }
                     } else {
-                        if (g >= 20 && g < 28) {                 // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
+                        if (WINO_JIT_ROWS && g >= 20 && g < 28) {
+                            const int c = (g - 20) & 3;
+                            if (g < 24) da[c] = patch(SR{}, RA, c);
+                            else db[c] = patch(SR{}, RB, c);
+                        }
+                        if (!WINO_JIT_ROWS && g >= 20 && g < 28) {                 // patch rows of step S + 1: rows 0, 2 | 1 | 3 | none
                             const int c = (g - 20) & 3;
                             if (PG == 0 && g < 24) d0[c] = patch(SN{}, 0, c);
                             if (PG == 0 && g >= 24) d2[c] = patch(SN{}, 2, c);
@@ -599,7 +642,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         }
                         if (g >= 36 && g < 40) {                 // first the row combination ...
                             const int c = g - 36;
-                            tt[c] = TR == 0 ? sub4(d0[c], d2[c]) : (TR == 1 ? add4(d1[c], d2[c]) : (TR == 2 ? sub4(d2[c], d1[c]) : sub4(d1[c], d3[c])));
+                            tt[c] = WINO_JIT_ROWS ? (TR == 1 ? add4(da[c], db[c]) : sub4(da[c], db[c]))
+                                                  : TR == 0 ? sub4(d0[c], d2[c]) : (TR == 1 ? add4(d1[c], d2[c]) : (TR == 2 ? sub4(d2[c], d1[c]) : sub4(d1[c], d3[c])));
                         }
                         if (g >= 40 && g < 44) {                 // ... then the column combination
                             const int c = g - 40;
@@ -631,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                         }
                     }
                     if (g >= 52 && g < 52 + NRING) {
-                        if (!(MS && C >= 13 && last_seg && g > 52)) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
+                        if (WINO_MS_FLAT || !(MS && C >= 13 && last_seg && g > 52)) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -721,11 +765,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             for (int ks = 0; ks < nw; ++ks) {
                 last_seg = ks + 1 >= nw;
                 u_so = a.u_off[ks];
-                u_so_next = a.u_off[last_seg ? 0 : ks + 1];
+                if (WINO_MS_FLAT) r_nx = rsrc_of(last_seg ? a.Urgb : a.ubase, last_seg ? 4u * 4096u : OOBW);
+                nx_base = (WINO_MS_FLAT && last_seg) ? 0u : a.u_off[last_seg ? 0 : ks + 1];
+                nx_cs = (WINO_MS_FLAT && last_seg) ? 4096u : 16384u;
+                nx_ps = (WINO_MS_FLAT && last_seg) ? 0u : 4096u;
                 // the slabs this segment refills belong to the next source of this tile, or to the first source of the next tile
                 r_src = rsrc_of(reinterpret_cast<const char*>(a.srcs[last_seg ? 0 : ks + 1]) - ((long)W + 1) * 256, OOBW);
                 ref_so = last_seg ? nso : (unsigned)(ty0 * W + tx0) * 256u;
-                halo_offsets(tq, last_seg ? nty0 : ty0, last_seg ? ntx0 : tx0);
+                // (the thread id laundered per segment: the eighteen per-lane constants behind the six offsets are recomputed here instead
+                //  of living -- seven of them in scratch, each reload an s_waitcnt vmcnt(0) -- across the whole tile)
+                int tqs = tq;
+                if (WINO_MS_LAUNDER >= 1) asm volatile("" : "+v"(tqs));
+                if (WINO_MS_LAUNDER >= 2) {
+                    tqk = tqs;
+                    tq16 = (unsigned)tqs * 16u;
+                }
+                halo_offsets(tqs, last_seg ? nty0 : ty0, last_seg ? ntx0 : tx0);
                 step(I<0>{});
                 step(I<1>{});
                 step(I<2>{});
@@ -754,7 +809,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         fo_request(nty0, ntx0, (!has_next && qtile >= 0) ? qquad : -1);
         auto epilogue = [&](auto partial_c) {
             constexpr bool PARTIAL = decltype(partial_c)::value;
-            const int lq = tq & 63, wq = tq >> 6, kqq = lq >> 4, mq = lq & 15;
+            // (the thread id laundered once more: everything the epilogue derives from it is computed HERE -- hoisted to the top of the
+            //  tile it lives through the K loop at the register limit, i.e. in scratch, and each reload is an s_waitcnt vmcnt(0))
+            int te = tq;
+            asm volatile("" : "+v"(te));
+            const int lq = te & 63, wq = te >> 6, kqq = lq >> 4, mq = lq & 15;
             char* tr = smem + 3 * 16384 + wq * 4096;
             // write side: accumulator register r of this lane is tile (row kq, column r) of the wave's 4x4 tiles; value (q = 2 a + b, r)
             // is pixel (row 2 kq + a, column 2 r + b) of its 8x8 block, channel m
@@ -1000,6 +1059,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 // 8x8 pixels, the four waves splitting the output channels -- the arithmetic of the big kernel's tail units (bit for bit the same
 // values as a whole tile), as a kernel of its own: the 10x10x64 halo goes to LDS first, the B fragments come straight from L2 a step
 // ahead, 2.25x fewer matrix FLOPs than the direct form and four times as many blocks.
+#ifndef WINO_MS_TU
 template <bool PAR, bool RES>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArgs a) {
     constexpr int QSTR = 272;                                // bytes per halo pixel in LDS (64 channels + 16: patch reads spread over banks)
@@ -1053,8 +1113,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             bool nz = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int gy = qy0 + 2 * tyq + (q >> 1), gx = qx0 + 2 * txq + (q & 1);
-                const float v = (gy < H && gx < W) ? a.par[(long)j * a.par_plane + (long)gy * W + gx] : 0.f;
+                const int gy = min(qy0 + 2 * tyq + (q >> 1), H - 1), gx = min(qx0 + 2 * txq + (q & 1), W - 1);      // (clamped: see pv_request)
+                const float v = a.par[(long)j * a.par_plane + (long)gy * W + gx];
                 nz = nz || v != 0.f;
                 pq[j][q] = (q == 1 || q == 2) ? -v : v;
             }
@@ -1185,6 +1245,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
         }
     }
 }
+#endif      // !WINO_MS_TU
+#ifdef WINO_MS_TU
 
 // The input conv over the virtual concat [frame, wide sources ...] as quadrant units (the multi-source kernel's arithmetic, block u =
 // quadrant u & 3 of tile u >> 2, wave w = output channels 16 w .. + 15): the frame's RGB0 halo and the first source's halo go to LDS,
@@ -1334,6 +1396,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_ms_kernel(const Wino
         }
     }
 }
+#endif      // WINO_MS_TU
+#ifndef WINO_MS_TU
 
 // ---- weight images ------------------------------------------------------------------------------------------------------------
 // U = G g G^T per (output channel, input channel), times gamma[co] when given (see launch_wino_images), from a packed direct-conv
@@ -1407,7 +1471,30 @@ __global__ __launch_bounds__(256) void wino_rgb_image_kernel(const float* __rest
     }
 }
 
+#endif      // !WINO_MS_TU
 }  // namespace
+
+// The multi-source instantiation (the input convs) is its own translation unit, conv_wino_ms.hip = this file with WINO_MS_TU defined:
+// its K loop is a run-time loop over the sources with all 64 accumulator quads carried around it, and the register-allocation flag that
+// pays for the straight-line kernels (build_native.py: -greedy-reverse-local-assignment, fewer accumulator quads parked in arch VGPRs)
+// costs it spill slots.  WinoArgs is the same struct in both units (same source); it crosses the boundary as an opaque pointer.
+int launch_conv3x3_wino_ms_raw(const void* wino_args, int grid, int units, int ntiles, hipStream_t stream);
+
+#ifdef WINO_MS_TU
+int launch_conv3x3_wino_ms_raw(const void* wino_args, int grid, int units, int ntiles, hipStream_t stream) {
+    static PnpPerDevice once;
+    int unused = 0;
+    const hipError_t attr_err = once.run([](int, int&) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
+    }, &unused);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const WinoArgs& w = *static_cast<const WinoArgs*>(wino_args);
+    if (units) hipLaunchKernelGGL(conv3x3_wino_quad_ms_kernel, dim3(4 * ntiles), dim3(256), 0, stream, w);
+    else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
+    return (int)hipGetLastError();
+}
+#else
 
 int launch_wino_rgb_image(const float* src, float* dst, hipStream_t stream) {
     hipLaunchKernelGGL(wino_rgb_image_kernel, dim3(1), dim3(256), 0, stream, src, dst);
@@ -1457,12 +1544,11 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         e = hipFuncSetAttribute(fo, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
         const void* fo_res = reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false, true>);
         if (e == hipSuccess) e = hipFuncSetAttribute(fo_res, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
-        const void* fns[5] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false>),
+        const void* fns[4] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false>),
                               reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false>),
                               reinterpret_cast<const void*>(conv3x3_wino_kernel<true, false, false>),
-                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, true, false>),
-                              reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, true>)};
-        for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
+                              reinterpret_cast<const void*>(conv3x3_wino_kernel<true, true, false>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
         g = 256;
         (void)hipDeviceGetAttribute(&g, hipDeviceAttributeMultiprocessorCount, dev);
         return e;
@@ -1511,9 +1597,8 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         }
         w.rgb = a.src[0];
         w.Urgb = a.wwino_rgb;
-        if (a.wino_units) hipLaunchKernelGGL(conv3x3_wino_quad_ms_kernel, dim3(4 * ntiles), dim3(256), 0, stream, w);
-        else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-    } else if (a.wpar && a.par_any && !a.par_iframe_only) {
+        return launch_conv3x3_wino_ms_raw(&w, grid, a.wino_units ? 1 : 0, ntiles, stream);
+    } else if (a.wpar && a.par_any) {
         // Two launches behind a device-side gate on the frame's partition word (launch_par_frame_any), one of which returns at once:
         // the fold-only kernel when EVERY 8x8 quadrant of the frame is all zero or carries one constant plane (one-hot maps on >= 8x8
         // codec blocks, frames without records), the branch kernel otherwise.  Bit-identical results either way.
@@ -1530,28 +1615,10 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, f);
             hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
         }
-    } else if (a.wpar && a.par_any && a.par_iframe) {
-        // a frame with ragged quadrants that MAY carry no partition record (I frames): the plain conv behind the gate "the frame's map
-        // is all zero", the branch kernel behind "it is not" (bit-identical: a zero map adds exact zeros).  The branch kernel's
-        // structure costs 1.3x a plain conv even when no wave runs a branch.
-        WinoArgs p = w;
-        p.Upar = nullptr;
-        p.par = nullptr;
-        p.par_flags = nullptr;
-        p.gate = w.gate = a.par_any;
-        p.gate_mask = w.gate_mask = 7;       // "a plane is nonzero somewhere in the frame"
-        p.gate_want = 0;
-        w.gate_want = 1;
-        if (a.residual) {
-            hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, p);
-            hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-        } else {
-            hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, p);
-            hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-        }
     } else if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     return (int)hipGetLastError();
 }
+#endif      // !WINO_MS_TU

@@ -359,8 +359,7 @@ struct ConvCall {
     ConvCall& gamma(const float* g) { gamma_ = g; return *this; }
     const int* par_flags_ = nullptr;
     const int* par_any_ = nullptr;
-    int iframe_ = 0;
-    ConvCall& gate(const int* frame_any, bool iframe) { par_any_ = frame_any; iframe_ = iframe ? 1 : 0; return *this; }       // see ConvArgs::par_any
+    ConvCall& gate(const int* frame_any) { par_any_ = frame_any; return *this; }       // see ConvArgs::par_any
     ConvCall& partition(const float* w1x1, const float* par, const int* tile_flags = nullptr) {
         wpar_ = w1x1;
         par_ = par;
@@ -700,7 +699,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
     // 712 with the multi-source tile kernel).  2 = the tile kernels at every size (tests)
     auto ntiles16 = [](int hh, int ww) { return (int64_t)((hh + 15) / 16) * ((ww + 15) / 16); };
     auto wino_ok = [&](int hh, int ww) { return wopt == 2 || wopt == 1; };
-    auto wino_units = [&](int hh, int ww) { return wopt == 1 && ntiles16(hh, ww) <= 128; };
+    auto wino_units = [&](int hh, int ww) { return wopt == 1 && ntiles16(hh, ww) <= PNP_WINO_UNITS_MAX_TILES; };
     auto wino_ms_ok = [&](int hh, int ww) { return wopt == 2 || wopt == 1; };
     // every 64-channel map that is only read as an MFMA A operand gets an fp16 copy from its producer
     const bool mirrors = f16_maps && g->opt[PNP_OPT_F16_MIRRORS] && c.deform == 0 && W.x16 != nullptr;
@@ -728,8 +727,6 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
         }
         a.wino_units = (q.wino_ || a.wwino_rgb) ? q.units_ : 0;
         a.par_any = (q.wino_ && q.wpar_ && !a.wino_units) ? q.par_any_ : nullptr;
-        a.par_iframe = q.iframe_;
-        a.par_iframe_only = (q.H % 8 != 0 || q.W % 16 != 0) ? 1 : 0;
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;
@@ -928,12 +925,9 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             const int* pflags = par_skip ? W.parflags + (int64_t)i * ((w + 15) / 16) * ((h + 7) / 8) : nullptr;
             // the frame's partition word (launch_par_frame_any) gates the front halves on the device: fold-only kernel / branch kernel
             // (launch_conv3x3_wino); an I frame usually carries no record at all (its word is then 8: all quadrants zero)
-            // (asked for where one of the two can run at all: the fold-only kernel wants whole 8x8 quadrants everywhere -- 180x320 has a
-            //  ragged last row of them and would only pay the 5-us return per launch: there only I frames are gated, plain conv / branch kernel)
-            const bool ifr = sl[i] == 73.0f;
-            const bool whole_q = h % 8 == 0 && w % 16 == 0;       // (the flag tiles are 8 x 16 and must lie inside)
-            const bool gate_pays = whole_q || ifr;
-            const int* pany = (par_skip && wopt >= 1 && gate_pays) ? W.parany + i : nullptr;
+            // (any frame size: a quadrant cut by the frame's edge -- 180x320 has a last row of them 4 pixels high -- counts with the pixels
+            //  it has, in the flags and in the kernels alike)
+            const int* pany = (par_skip && wopt >= 1) ? W.parany + i : nullptr;
             const int u = uidx[i];
             float* slot = W.slots + (int64_t)i * fm;
             // fp16 mirrors: the input conv writes x16 next to x when it runs on the fp16 kernels at all (an RGB-only one does not)
@@ -977,7 +971,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                 const int o16 = f16_maps ? 1 : 0, s16 = f16_maps ? 2 : 0;
                 if (c.channel_first) {   // sr_backbone_utils.py:305-313
                     r = conv(ConvCall(h, w, cfg_lr).source(x, 64, w2).mirror16(x16).bias(b2).gamma(g2)
-                                 .partition(packed + K.w1x1, parp, pflags).gate(pany, ifr).wino(u2, up).units(un).act(1).to(W.tmp1).f16_map(o16));
+                                 .partition(packed + K.w1x1, parp, pflags).gate(pany).wino(u2, up).units(un).act(1).to(W.tmp1).f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w1).bias(b1).gamma(g1).wino(u1).units(un).residual(x).to(dst)
                                      .f16_map(s16).also16(dst16));
@@ -986,7 +980,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
                                  .f16_map(o16));
                     if (!r)
                         r = conv(ConvCall(h, w, cfg_lr).source(W.tmp1, 64, w2).bias(b2).gamma(g2)
-                                     .partition(packed + K.w1x1, parp, pflags).gate(pany, ifr).wino(u2, up).units(un).residual(x).to(dst).f16_map(s16).also16(dst16));
+                                     .partition(packed + K.w1x1, parp, pflags).gate(pany).wino(u2, up).units(un).residual(x).to(dst).f16_map(s16).also16(dst16));
                 }
                 if (r) return r;
                 x = dst;

@@ -185,8 +185,9 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
     assert 'cpu' not in ns                                      # --no-cpu-baseline covers the 128x128 CPU leg too
     assert d['secondary_file'] == 'bench_secondary.json'
     oi = d['opt_in_720p']                                       # the opt-in arithmetics at the headline shape, compact
-    assert oi['fp32_two_clips_interleaved'] > 1.005 * d['value'] and oi['f16x3_two_clips_interleaved'] > 0.9 * oi['f16x3']      # (split fp16: +2..4 % or noise, 3 short steps)
-    assert oi['f16x3'] > 1.5 * d['value'] and oi['fp16'] > 2.8 * d['value'] and oi['f16x3_bound'] == 'mfma' and oi['fp16_bound'] == 'hbm'
+    # structure only: no rate is compared with another rate in the parity suite (tests/test_gpu_zz_perf.py holds those)
+    assert oi['fp32_two_clips_interleaved'] > 0 and oi['f16x3_two_clips_interleaved'] > 0
+    assert oi['f16x3'] > 0 and oi['fp16'] > 0 and oi['f16x3_bound'] == 'mfma' and oi['fp16_bound'] == 'hbm'
     with open(side) as fh:
         full = json.load(fh, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
     assert full['value'] == d['value'] or abs(full['value'] - d['value']) < 1e-4 * d['value']
@@ -195,10 +196,10 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
     assert len(sec) == 15 and sec[8]['clips_per_step'] == 2 and sec[8]['workload'] == '720p' and sec[8]['roofline']['per_launch_frac'] > 0
     assert sec[9]['clips_per_step'] == 2 and sec[9]['precision'] == 'f16x3'
     # the reference configs' real clip length, and the direct kernels of rounds 1-4 in the same session
-    assert sec[10]['workload'] == '720p' and '100x3x720x1280' in sec[10]['name'] and 0.9 * d['value'] < sec[10]['value'] < 1.05 * d['value']
-    assert 'PNP_OPT_WINOGRAD = 0' in sec[11]['name'] and 0.55 * d['value'] < sec[11]['value'] < 0.85 * d['value']
-    # mid-size frames (240 tiles): the tile kernels against the direct ones, same session
-    assert sec[12]['workload'] == 'lr180' and sec[13]['workload'] == 'lr180' and sec[12]['value'] > 1.1 * sec[13]['value'] > 0
+    assert sec[10]['workload'] == '720p' and '100x3x720x1280' in sec[10]['name'] and sec[10]['value'] > 0
+    assert 'PNP_OPT_WINOGRAD = 0' in sec[11]['name'] and sec[11]['value'] > 0
+    # mid-size frames (240 tiles): the tile kernels and the direct ones, same session
+    assert sec[12]['workload'] == 'lr180' and sec[13]['workload'] == 'lr180' and sec[12]['value'] > 0 and sec[13]['value'] > 0
     e2e = sec[14]                                   # the whole tools/test.py loop on an on-disk tree
     assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
     assert e2e['seconds_total'] >= e2e['seconds_generator_forward'] > 0
@@ -219,10 +220,10 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
                 assert abs(rf['achieved'] - rf['achieved_wall']) < 1e-9
     assert sec[0]['roofline']['bound'] == 'mfma' and sec[3]['roofline']['bound'] == 'hbm' and sec[5]['roofline']['bound'] == 'hbm'
     assert sec[2]['hip_graphs'] is True and sec[6]['vsr_x4_heads'] is True
-    assert sec[3]['value'] > 2.8 * d['value']     # fp16 operands at the headline shape: ~3x the (Winograd) fp32 rate
+    assert sec[3]['value'] > 0                     # fp16 operands at the headline shape
     # split fp16 (fp32-level results, three fp16 MFMAs per product): priced on the matrix pipe, executed = 3 x algorithmic
     x3 = sec[4]
-    assert x3['dtype'].startswith('split f16') and x3['roofline']['bound'] == 'mfma' and x3['value'] > 1.5 * d['value']
+    assert x3['dtype'].startswith('split f16') and x3['roofline']['bound'] == 'mfma' and x3['value'] > 0
     assert x3['roofline']['achieved'] <= 3 * x3['roofline']['algorithmic_TFLOPs'] * 1.001
     assert abs(x3['psnr'] - d['psnr_per_rank'][0]) < 1e-3      # same clip, same weights: the fp32 headline's PSNR
     assert sec[7]['dtype'].startswith('split f16') and sec[7]['roofline']['bound'] == 'mfma' and abs(sec[7]['psnr'] - sec[0]['psnr']) < 1e-3

@@ -405,11 +405,15 @@ def test_generator_i_frame_front_halves_behind_the_device_side_gate():
     (PNP_OPT_PAR_SKIP off: the branch kernel everywhere) for an I frame without records, one WITH records, and a frame whose quadrants
     straddle the codec blocks"""
     from pnp_vcve_amd import _native, synthetic as syn
-    for extra in ({}, {'channel_first': False}):
+    # 192x256: whole quadrants everywhere; 180x320 (the reference's third config, HR_davis_LR_128x128_IPB_LR_test.py:43-47): a last row of
+    # quadrants 4 pixels high; 148x216: ragged in both directions and a flag tile whose right half lies outside.  A quadrant cut by the
+    # frame's edge counts with the pixels it has -- in par_tile_flags' bit 6, in the fold-only kernel and in the branch kernel's own
+    # per-wave decision (pixels outside take the nearest inside value) alike, so the gate stays bit-neutral
+    for extra, (h, w) in (({}, (192, 256)), ({'channel_first': False}, (192, 256)), ({}, (180, 320)), ({'channel_first': False}, (148, 216))):
         cfg = dict(syn.DEFAULT_GENERATOR_CFG)
         cfg.update(extra)
         sd = syn.make_state_dict(cfg, seed=2025)
-        clip = syn.make_clip(seed=99, n=1, t=4, h=192, w=256, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)    # 192 tiles: tile kernels
+        clip = syn.make_clip(seed=99, n=1, t=4, h=h, w=w, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)    # > 128 tiles: tile kernels
         assert float(np.abs(clip['partitions'][0, 0]).max()) == 0.0 and float(np.abs(clip['partitions'][0, 1]).max()) > 0.0
         m = build(cfg, sd, 1)
         for with_records in (False, True, 'straddling'):
@@ -420,7 +424,7 @@ def test_generator_i_frame_front_halves_behind_the_device_side_gate():
             m.set_option(_native.OPT_PAR_SKIP, 1)
             gated = run(m, clip)
             m.set_option(_native.OPT_PAR_SKIP, 0)                           # no tile flags, no gate: the branch kernel on every frame
-            assert torch.equal(run(m, clip), gated), (extra, with_records)
+            assert torch.equal(run(m, clip), gated), (extra, h, w, with_records)
 
 
 def test_generator_winograd_720p_vs_oracle():
@@ -438,4 +442,30 @@ def test_generator_winograd_720p_vs_oracle():
                                         c['partitions'])
     d = float((out - ref).abs().max())
     print('720p winograd vs oracle:', d)
+    assert d < TOL_GEN
+
+
+@pytest.mark.parametrize('hw', [(192, 256), (180, 320)])
+@pytest.mark.parametrize('channel_first', [True, False])
+def test_generator_gated_front_halves_vs_oracle(channel_first, hw):
+    """a frame size that takes the TILE kernels behind the device-side gate (192x256 = 192 tiles, whole 8x8 quadrants everywhere),
+    against the oracle itself: channel-first blocks run the fold-only kernel conv3x3_wino_kernel<false,false,false,true>, channel-last
+    blocks (sr_backbone_utils.py:314-327: branches AND residual in one launch) the fold-only + residual instantiation
+    <false,true,false,true>; a P frame whose quadrants straddle the codec blocks takes the branch kernels <true,*,false,false>"""
+    from oracle import cpu_ref
+    from pnp_vcve_amd import _native, synthetic as syn
+    cfg = dict(syn.DEFAULT_GENERATOR_CFG, channel_first=channel_first)
+    sd = syn.make_state_dict(cfg, seed=2025)
+    h, w = hw              # (180x320: configs[4]'s own frame size, a ragged last row of quadrants -- folded since round 6)
+    clip = syn.make_clip(seed=606, n=1, t=4, h=h, w=w, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)
+    clip['partitions'][0, 2] = np.roll(clip['partitions'][0, 2], 4, axis=-1)        # frame 2: not foldable -> branch kernel
+    m = build(cfg, sd, 1)
+    assert m.get_option(_native.OPT_PAR_SKIP) == 1                                  # the gate is on by default
+    out = run(m, clip).cpu()
+    c = {k: torch.from_numpy(v) for k, v in clip.items()}
+    with torch.no_grad():
+        ref = cpu_ref.generator_forward(cpu_ref.to_torch_state(sd), cfg, c['lq'], c['QPs'], c['slices'], c['mvs'], c['base_QPs'],
+                                        c['partitions'])
+    d = float((out - ref).abs().max())
+    print(hw, 'gated, channel_first =', channel_first, ': max|hip - oracle| =', d)
     assert d < TOL_GEN

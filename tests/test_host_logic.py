@@ -468,3 +468,39 @@ def test_folder_dataset_decode_pool_survives_pickling_and_is_per_process(tmp_pat
     assert not hasattr(ds2, '_decode_pool') and torch.equal(ds2[0]['lq'], a['lq'])
     ds._decode_pool = (ds._decode_pool[0] + 1, ds._decode_pool[1])      # as seen from a forked child: another pid
     assert torch.equal(ds[0]['lq'], a['lq']) and ds._decode_pool[0] == os.getpid()
+
+
+def test_roofline_traffic_counts_exactly_the_block_conv_launches_of_the_committed_profile():
+    """bench.py's roofline.traffic: launch-weighted (2 x FETCH + WRITE) over conv3x3_wino_kernel<PAR,RES,MS,FO> with MS = false (plain =
+    conv_hr, RES = back halves, FO = fold-only front halves) -- not the multi-source input conv, not the 336 gated returns of the
+    branch kernel (21 KB each).  r05's committed PMC passes: (21 x 596.5 + 336 x 618.6 + 336 x 952.3) / 693 = 779.7 MB per launch against
+    591.6 MB algorithmic (round 5's line said 539.7: the filter predated the fourth template flag)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, 'profiles', 'r05_pmc.json')) as fh:
+        pmc = json.load(fh)
+    t = bench._launch_weighted_traffic(pmc, 'conv3x3_wino_kernel', min_bytes=0.01 * 512 * 720 * 1280)
+    by_hand = (21 * 596475739.4 + 336 * 618621092.6 + 336 * 952330097.9) / 693
+    assert abs(t - by_hand) < 1.0 and abs(t / 1e6 - 779.7) < 0.1
+    alg = bench.block_conv_algorithmic_bytes(720, 1280, 8)
+    assert abs(alg / 1e6 - 591.6) < 0.1 and abs(t / alg - 1.318) < 0.002
+    assert bench._wino_flags('conv3x3_wino_kernel<false, true, false, true>') == (False, True, False, True)
+    assert bench._wino_flags('conv3x3_wino_quad_kernel<false,true>') is None
+    # without the floor the gated returns dilute the mean; the input conv never enters
+    assert bench._launch_weighted_traffic(pmc, 'conv3x3_wino_kernel') < t
+    assert 'traffic_ratio' in bench.ROOFLINE_KEEP and 'algorithmic_bytes_per_launch' in bench.ROOFLINE_KEEP
+
+
+def test_winograd_routing_rule_is_stated_once():
+    """PNP_OPT_WINOGRAD = 1: quadrant units up to PNP_WINO_UNITS_MAX_TILES 16x16 tiles, tile kernels above (include/pnpvcve.h);
+    _native.wino_kernel_form is that rule for bench.py, generator.hip uses the header's constant"""
+    import re
+    from pnp_vcve_amd import _native
+    hdr = open(os.path.join(ROOT, 'include', 'pnpvcve.h')).read()
+    assert int(re.search(r'#define PNP_WINO_UNITS_MAX_TILES (\d+)', hdr).group(1)) == _native.WINO_UNITS_MAX_TILES
+    src = open(os.path.join(ROOT, 'pnp_vcve_amd', 'csrc', 'generator.hip')).read()
+    assert 'ntiles16(hh, ww) <= PNP_WINO_UNITS_MAX_TILES' in src and '< 512' not in hdr
+    assert _native.wino_kernel_form(128, 128, 1) == 'units' and _native.wino_kernel_form(128, 128, 2) == 'tiles'
+    assert _native.wino_kernel_form(180, 320, 1) == 'tiles' and _native.wino_kernel_form(720, 1280, 0) is None
+    assert _native.wino_kernel_form(128, 256, 1) == 'units' and _native.wino_kernel_form(128, 272, 1) == 'tiles'

@@ -63,28 +63,75 @@ def test_f16x3_counted_chunk_barrier_still_covers_the_ring_write(tmp_path):
     assert all(min(v) == 0 for v in slack.values())
 
 
+def _wino_asm(tmp_path, src):
+    asm = tmp_path / (src + '.s')
+    flags = build_native.FLAGS + build_native.EXTRA_FLAGS[src]
+    subprocess.check_call([HIPCC] + [f for f in flags if f != '-Wall'] + ['-S', '--cuda-device-only', '-o', str(asm),
+                          os.path.join(ROOT, 'pnp_vcve_amd', 'csrc', src)], stderr=subprocess.DEVNULL)
+    return asm.read_text()
+
+
+def _tile_loop(fn, tail_mfmas):
+    """the lines of one tile's K loop: first MFMA .. last MFMA in front of the quadrant-unit tail (its `tail_mfmas` last ones)"""
+    lines = fn.split('\n')
+    mf = [i for i, l in enumerate(lines) if 'v_mfma_f32_16x16x4_f32' in l]
+    return lines[mf[0]:mf[len(mf) - tail_mfmas - 1]]
+
+
 def test_winograd_kernel_is_built_without_packed_fp32_valu_ops(tmp_path):
     """csrc/conv_wino.hip with v_pk_{add,mul}_f32 in its code object gave wrong values in fixed (lane, register) slots that moved with
     unrelated code motion (profiles/r05_wino_packed_f32_hazard.txt) -- the third appearance of that signature (DCN r03, split-fp16
-    r04).  The file is compiled with the packed-fp32 target feature off; this fails if the flag is dropped or stops working."""
-    assert '-packed-fp32-ops' in build_native.EXTRA_FLAGS['conv_wino.hip']
-    asm = tmp_path / 'conv_wino.s'
-    flags = build_native.FLAGS + build_native.EXTRA_FLAGS['conv_wino.hip']
-    subprocess.check_call([HIPCC] + [f for f in flags if f != '-Wall'] + ['-S', '--cuda-device-only', '-o', str(asm),
-                          os.path.join(ROOT, 'pnp_vcve_amd', 'csrc', 'conv_wino.hip')], stderr=subprocess.DEVNULL)
-    text = asm.read_text()
-    kernels = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_kernel' in fn.split('\n')[0]]
-    assert len(kernels) == 7                                   # {plain, residual, branches, branches + residual, multi-source, fold-only (+ residual)}
+    r04).  Both translation units are compiled with the packed-fp32 target feature off; this fails if the flag is dropped or stops
+    working.  Also bounded here, on the compiler's own output: the spill slots of every instantiation and the scratch traffic INSIDE the
+    K loop of the default path's kernels (a spill reload is an s_waitcnt vmcnt(0): it drains the weight / halo requests in flight)."""
+    for src in ('conv_wino.hip', 'conv_wino_ms.hip'):
+        assert '-packed-fp32-ops' in build_native.EXTRA_FLAGS[src] and '-pragma-unroll-threshold=1000000' in build_native.EXTRA_FLAGS[src]
+    text = _wino_asm(tmp_path, 'conv_wino.hip')
+    kernels = {re.search(r'kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)E', fn.split('\n')[0]).groups(): fn
+               for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_kernel' in fn.split('\n')[0]}
+    # {plain, residual, branches, branches + residual, fold-only (+ residual)}; the multi-source one lives in conv_wino_ms.hip
+    assert sorted(kernels) == sorted([('0', '0', '0', '0'), ('0', '1', '0', '0'), ('1', '0', '0', '0'), ('1', '1', '0', '0'),
+                                      ('0', '0', '0', '1'), ('0', '1', '0', '1')])
     # the accumulators and the transformed patch live in REGISTERS: a source order hipcc does not like once put both arrays into scratch
-    # memory (private_seg_size 1616: correct results, ten times slower; DESIGN.md section 8) -- a few spill slots are tolerated
-    sizes = [int(v) for v in re.findall(r'conv3x3_wino_kernel\w+\.private_seg_size, (\d+)', text)]
-    assert len(sizes) == 7 and max(sizes) <= 512, sizes
-    # the quadrant-unit kernels of small frames (five instantiations): straight-line code, no spill slot at all, no packed fp32 either
+    # memory (private_seg_size 1616: correct results, ten times slower; DESIGN.md section 8).  Round 6 (patch rows read where they are
+    # transformed): 40-52 B for the kernels of the default path (r05: 84-176), <= 128 B for the branch kernels (208-236)
+    sizes = {tuple(k): int(v) for *k, v in re.findall(r'conv3x3_wino_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)E\w+\.private_seg_size, (\d+)', text)}
+    assert len(sizes) == 6
+    for k, v in sizes.items():
+        assert v <= (64 if k[0] == '0' else 160), (k, v)
+    for k, fn in kernels.items():
+        assert fn.count('v_mfma_f32_16x16x4_f32') >= 1024                           # the K loop is there ...
+        assert not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn), k                  # ... and no packed fp32 arithmetic beside it
+        if k[0] == '0':
+            # plain / residual / fold-only: at most a handful of scratch instructions between a tile's first and last MFMA (r05: up to 18)
+            loop = _tile_loop(fn, 256)
+            n = sum(1 for l in loop if 'scratch_' in l)
+            assert n <= 4, (k, n)
+            # ... and few accumulator quads parked in arch VGPRs (r05: ~100 v_accvgpr_read + ~70 v_accvgpr_write per tile)
+            assert sum(1 for l in loop if 'v_accvgpr_write' in l) <= 16 and sum(1 for l in loop if 'v_accvgpr_read' in l) <= 48, k
+    # the quadrant-unit kernels of small frames: straight-line code, no spill slot at all, no packed fp32 either
     units = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_quad' in fn.split('\n')[0]]
     usizes = [int(v) for v in re.findall(r'conv3x3_wino_quad\w+\.private_seg_size, (\d+)', text)]
-    assert len(units) == 5 and len(usizes) == 5 and max(usizes) == 0, usizes
+    assert len(units) == 4 and len(usizes) == 4 and max(usizes) == 0, usizes
     for fn in units:
         assert fn.count('v_mfma_f32_16x16x4_f32') >= 256 and not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn)
-    for fn in kernels:
-        assert fn.count('v_mfma_f32_16x16x4_f32') >= 1024                           # the K loop is there ...
-        assert not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn), fn.split('\n')[0]    # ... and no packed fp32 arithmetic beside it
+
+
+def test_winograd_multi_source_unit_is_its_own_translation_unit(tmp_path):
+    """conv_wino_ms.hip = conv_wino.hip with WINO_MS_TU: exactly the multi-source tile kernel and its quadrant-unit twin, built WITHOUT
+    the register-allocation flag of the straight-line kernels (it costs this one spill slots), without packed fp32; its segment loop
+    holds a bounded number of scratch instructions (r05: 31 reloads + 32 stores per segment; r06: 3, on the last segment only)"""
+    assert '-greedy-reverse-local-assignment' in build_native.EXTRA_FLAGS['conv_wino.hip']
+    assert '-greedy-reverse-local-assignment' not in build_native.EXTRA_FLAGS['conv_wino_ms.hip']
+    text = _wino_asm(tmp_path, 'conv_wino_ms.hip')
+    fns = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino' in fn.split('\n')[0]]
+    names = sorted(fn.split('\n')[0] for fn in fns)
+    assert len(fns) == 2 and 'quad_ms_kernel' in names[1] and 'kernelILb0ELb0ELb1ELb0E' in names[0], names
+    sizes = dict(re.findall(r'(conv3x3_wino\w+)\.private_seg_size, (\d+)', text))
+    assert all(int(v) <= (96 if 'quad' not in k else 0) for k, v in sizes.items()), sizes
+    ms = [fn for fn in fns if 'quad' not in fn.split('\n')[0]][0]
+    assert ms.count('v_mfma_f32_16x16x4_f32') >= 1024 + 64 and not re.search(r'\bv_pk_(add|mul|fma)_f32\b', text)
+    lines = ms.split('\n')
+    mf = [i for i, l in enumerate(lines) if 'v_mfma_f32_16x16x4_f32' in l]
+    seg = lines[mf[64]:mf[-1]]                      # behind the 64 MFMAs of the frame's RGB chunks: one source's 16 chunks
+    assert sum(1 for l in seg if 'scratch_' in l) <= 6, sum(1 for l in seg if 'scratch_' in l)
