@@ -221,8 +221,10 @@ int pnp_pixel_shuffle_conv_f32(const float* x_dev, const float* packed_dev, int 
 
 /* The single-source 64 -> 64 form of pnp_conv3x3_f32 as Winograd F(2x2,3x3) (sr_backbone_utils.py:304-333 block halves,
  * iconvsr_ipb_par.py:144 conv_hr): act(gamma * (conv3x3(x; W) + bias) + Sum_j par_j * conv1x1_j(x)) + residual with
- * x (h,w,64).  wino_w_dev = pnp_wino_image_from_packed_f32 of the packed direct-conv image WITH the same gamma (the gain
- * lives in the transformed weights, the kernel scales the bias); wino_w1x1_dev = pnp_wino_par_image_from_packed_f32 of the
+ * x (h,w,64).  wino_w_dev = pnp_wino_image_from_packed_f32 of the packed direct-conv image WITH the same gamma: the gain of the conv
+ * term lives in the transformed weights, and gamma_dev HERE SCALES ONLY THE BIAS -- an image built without it (or with another one)
+ * gives gamma * bias + conv instead of gamma * (conv + bias), silently; the C ABI cannot tell (the Python op checks the pairing);
+ * wino_w1x1_dev = pnp_wino_par_image_from_packed_f32 of the
  * packed 1x1 images or NULL (then par_dev / par_flags_dev are ignored); par_flags_dev as pnp_par_tile_flags_f32 writes
  * them, or NULL.  fp32 arithmetic; differs from pnp_conv3x3_f32 by summation order (~1e-6 on unit-scale maps). */
 int64_t pnp_wino_image_floats(void);

@@ -339,6 +339,9 @@ def wino_image(packed, gamma=None):
     out = torch.empty(int(_native.lib().pnp_wino_image_floats()), device=packed.device, dtype=torch.float32)
     _native.check(_native.lib().pnp_wino_image_from_packed_f32(_ptr(packed), _ptr(_chk(gamma, 'gamma')) if gamma is not None else None,
                                                                _ptr(out), _stream()), 'pnp_wino_image_from_packed_f32')
+    # which gain the image carries: conv3x3_wino scales only the BIAS by its `gamma` argument (the conv term's gain lives in the image), so
+    # the two must be the same tensor -- checked there when the image still carries this tag
+    out._pnp_gamma = None if gamma is None else gamma.detach().clone()
     return out
 
 
@@ -389,6 +392,10 @@ def conv3x3_wino(x, wino_w, bias=None, gamma=None, wino_w1x1=None, par=None, par
     h, w, c = x.shape
     if c != 64:
         raise ValueError('x must be (h, w, 64)')
+    tag = getattr(wino_w, '_pnp_gamma', 'untagged')              # (set by wino_image; lost by views / copies: then nothing is checked)
+    if not isinstance(tag, str) and ((tag is None) != (gamma is None) or (gamma is not None and not torch.equal(tag, gamma))):
+        raise ValueError('conv3x3_wino: `gamma` scales only the bias -- the conv term carries the gain wino_image() folded into wino_w; '
+                         'pass the SAME gamma tensor to both (or none to both)')
     out = torch.empty_like(x)
     opt = lambda t, n: _ptr(_chk(t, n)) if t is not None else None   # noqa: E731
     if par_flags is not None and (par_flags.dtype != torch.int32 or not par_flags.is_cuda):

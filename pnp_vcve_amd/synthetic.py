@@ -218,8 +218,9 @@ def make_clip(seed, n=1, t=7, h=128, w=128, slices='IBBBP', qp_mode='qp', crf=25
     par_classes: 3 = SURVEY 8(d)'s U{0,1,2} (every block of a P/B frame carries a partition record; bench.py);
                  4 = a quarter of the blocks carry none (all-zero) -- the golden fixtures were drawn with this.
     """
-    assert h % block == 0 and w % block == 0
-    bh, bw = h // block, w // block
+    # (a frame that is not a multiple of the block size: the block grid starts at the origin and the frame cuts its last row / column --
+    #  what a decoder's cropping does to a coded picture, e.g. 180 rows out of 192)
+    bh, bw = (h + block - 1) // block, (w + block - 1) // block
     lq = uniform01(seed, 'lq', (n, t, 3, h, w))
     noise = normal(seed, 'gt_noise', (n, t, 3, h, w), std=0.02)
     gt = np.clip(lq + noise, 0.0, 1.0).astype(np.float32)
@@ -241,8 +242,8 @@ def make_clip(seed, n=1, t=7, h=128, w=128, slices='IBBBP', qp_mode='qp', crf=25
     is_i = (sl[:, :, 0, 0, 0] == 73)
     mv_blk[is_i] = 0.0
     par_blk[is_i] = 0.0
-    mvs = np.repeat(np.repeat(mv_blk, block, axis=3), block, axis=4)
-    par = np.repeat(np.repeat(par_blk, block, axis=3), block, axis=4)
+    mvs = np.repeat(np.repeat(mv_blk, block, axis=3), block, axis=4)[..., :h, :w]
+    par = np.repeat(np.repeat(par_blk, block, axis=3), block, axis=4)[..., :h, :w]
 
     if qp_mode == 'qp':
         qps = randint(seed, 'qp', (n, t), 20, 40).astype(np.float32) / np.float32(255.0)

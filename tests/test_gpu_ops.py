@@ -523,16 +523,19 @@ def test_par_tile_flags_vs_numpy():
             # bits 3..5 (r04): every value of plane j in the tile is 0 or exactly float32(1) / float32(255) -- the reference loader's value
             unit = np.float32(1.0) / np.float32(255.0)
             exp[ty, tx] |= sum(int(((blk[j] == 0) | (blk[j] == unit)).all()) << (3 + j) for j in range(3))
-            # bit 6 (r05): the tile lies inside the image and each of its 8x8 halves is all zero or has exactly ONE live plane that is
-            # constant on it (what conv_wino.hip folds into its weights)
-            ok = ty * 8 + 8 <= h and tx * 16 + 16 <= w
+            # bit 6 (r05; r06: any frame size): each of its 8x8 halves is, on its pixels INSIDE the image (`blk` is cropped to it), all
+            # zero or has exactly ONE live plane that is constant there (what conv_wino.hip folds into its weights); a half wholly
+            # outside counts as empty
+            ok = True
             for half in (blk[:, :, :8], blk[:, :, 8:]):
                 live = [j for j in range(3) if (half[j] != 0).any()]
                 ok = ok and (not live or (len(live) == 1 and (half[live[0]] == half[live[0]].flat[0]).all()))
             exp[ty, tx] |= int(ok) << 6
     assert np.array_equal(got, exp)
-    # (0,0): plane 0 constant on both halves; (1,1): plane 1 constant; (2,0): two planes live in one half; last tile: ragged; (5,5): empty
-    assert got[0, 0] == 1 | 56 | 64 and got[1, 1] == 2 | 8 | 32 | 64 and got[2, 0] == 6 | 8 and got[-1, -1] == 4 | 8 | 16 and got[5, 5] == 56 | 64
+    # (0,0): plane 0 constant on both halves; (1,1): plane 1 constant; (2,0): two planes live in one half; last tile: ragged (4 x 6 pixels
+    # inside, plane 2 constant on them; its right half lies outside); (11,8): plane 2 live on one row only; (5,5): empty
+    assert got[0, 0] == 1 | 56 | 64 and got[1, 1] == 2 | 8 | 32 | 64 and got[2, 0] == 6 | 8 and got[-1, -1] == 4 | 8 | 16 | 64 and got[5, 5] == 56 | 64
+    assert got[11, 8] == 4 | 8 | 16
 
 
 def test_torch_custom_ops_call_the_hip_kernels():

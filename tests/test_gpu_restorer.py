@@ -204,6 +204,8 @@ def test_bench_headline_line_is_short_and_the_secondary_workloads_go_to_a_side_f
     assert e2e['pngs_written'] == (e2e['clips'] + 1) * 7 and e2e['value'] > 0 and 20 < e2e['psnr'] < 60
     assert e2e['seconds_total'] >= e2e['seconds_generator_forward'] > 0
     for e in sec[:14]:
+        if e.get('skipped'):                  # an entry whose workspace does not fit the device's free memory (the 100-frame clip: 24.5 GB)
+            continue
         assert e['value'] > 0
         if not e['hip_graphs']:               # per-kernel events are not taken inside a graph replay
             rf = e['roofline']

@@ -340,6 +340,14 @@ def test_wino_op_refuses_what_it_cannot_do():
         ops.conv3x3_wino(torch.zeros(32, 32, 4, device=dev()), u)
     with pytest.raises(RuntimeError):
         ops.conv3x3_wino(x, u, wino_w1x1=torch.zeros(12288, device=dev()))      # branches without a partition map: PNP_ERR_BAD_ARG
+    # the op's gamma scales only the bias; the conv term's gain is whatever wino_image() folded into the image: they must agree
+    g = torch.rand(64, device=dev())
+    pw = ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev()))
+    with pytest.raises(ValueError):
+        ops.conv3x3_wino(x, ops.wino_image(pw), gamma=g)
+    with pytest.raises(ValueError):
+        ops.conv3x3_wino(x, ops.wino_image(pw, g))
+    ops.conv3x3_wino(x, ops.wino_image(pw, g), gamma=g)
 
 
 # ------------------------------------------------------------------------------------------------- whole generator
