@@ -54,7 +54,8 @@ constexpr int SLAB_B = NPX * 64;              // bytes per 16-channel slab of th
 constexpr int RING_B = 4 * 16384;             // four 16-KiB weight chunks
 constexpr int PV_B = RING_B + 4 * SLAB_B;      // [plane j][thread] float4: the partition values of the thread's 4 pixels, signed (PAR); 3 x 4 KiB
 constexpr int BG_B = PV_B + 256 * 48;         // 64 floats: bias * gamma
-constexpr int WINO_LDS = BG_B + 256;          // 161024
+constexpr int DUMP_B = BG_B + 256;            // 256 B per wave nobody reads: where the residual warm-up loads land (LDS-DMA: no destination register)
+constexpr int WINO_LDS = DUMP_B + 1024;       // 162048 of 163840
 constexpr unsigned OOBW = 0xFFFFFFF0u;
 #ifndef WINO_FOLD
 #define WINO_FOLD 1       // A/B switch: a wave-uniform partition plane folded into the B fragments instead of run as MFMAs
@@ -331,6 +332,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
             }
         }
     };
+    // ... inside the K loop as LDS-DMA loads (16 B per lane straight into the halo's place: lane-linear, like rgb_store's layout): with a
+    // destination register the two float4 had to live from the request in one chunk to the LDS write in the next, and at the register
+    // limit hipcc spilled them right behind the loads -- a wait for the memory latency in the middle of the K loop (r05).  The lanes past
+    // pixel 323 re-fetch that pixel and land in the unused rest of the partition-value rows.
+    auto rgb_dma = [&](int tq_, int y0, int x0) {
+        if constexpr (MS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int e = tq_ + 256 * i;
+                e = e < NPX ? e : NPX - 1;
+                const int ry = (e * 3641) >> 16, col = e - ry * HP, rx = col < 9 ? 2 * col : 2 * col - 17;
+                const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+                const bool inb = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                auto* dst = (__attribute__((address_space(3))) void*)(smem + PV_B + (tq_ >> 6) * 1024 + i * 4096);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rgb, dst, 16, (int)(inb ? (unsigned)(ry * W + rx) * 16u : OOBW), (int)((unsigned)(y0 * W + x0) * 16u), 0, 0);
+            }
+        }
+    };
     auto rgb_store = [&](int tq_) {
         if constexpr (MS) {
 #pragma unroll
@@ -401,7 +420,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         for (int n = 0; n < 4; ++n) bf[0][n] = lds4(bl + n * 1024);
     }
 
-    float warm0 = 0.f, warm1 = 0.f;
     unsigned long long dbg_t0 = 0, dbg_r0 = 0, dbg_k = 0, dbg_e = 0;
     if (a.dbg) {
         dbg_t0 = __builtin_amdgcn_s_memtime();
@@ -582,14 +600,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                     // MS, last source: the next tile's RGB halo, requested in step 1 and stored a chunk later (this tile's RGB patch was read
                     // before its first chunk)
                     // (every segment does it: the same pixels again, but no run-time branch in the chunk and no value that lives across one)
-                    if (MS && S == 1 && PG == 0 && g == 14 && (WINO_MS_FLAT || last_seg)) rgb_request(tqk, nty0, ntx0);
-                    if (MS && S == 1 && PG == 1 && g == 14 && (WINO_MS_FLAT || last_seg)) rgb_store(tqk);
-                    if (RES && S == 3 && PG == 0 && g == 16 && !(ty0 + 16 > H || tx0 + 16 > W)) {
+                    if (MS && S == 1 && PG == 0 && g == 14 && (WINO_MS_FLAT || last_seg)) rgb_dma(tqk, nty0, ntx0);
+                    if (RES && S == 3 && PG == 0 && g == 16) {
                         // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (8 rows x
-                        // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2
-                        const unsigned wo = (unsigned)((8 * (tq >> 7) + ((tq >> 4) & 3)) * W + 8 * ((tq >> 6) & 1)) * 256u + (unsigned)(tq & 15) * 128u;
-                        warm0 = bload1(r_res, wo, (unsigned)(ty0 * W + tx0) * 256u);
-                        warm1 = bload1(r_res, wo + (unsigned)W * 1024u, (unsigned)(ty0 * W + tx0) * 256u);
+                        // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2.  As LDS-DMA loads
+                        // into a dump area: a load with a destination REGISTER has to keep it until the data is back, and at the register
+                        // limit hipcc spilled the two values right behind the loads -- i.e. every wave waited out the HBM latency in the
+                        // middle of the K loop for the sake of a prefetch (r05; ~4 k cycles per tile, tools/trace_wino.py: 42.3 k against
+                        // conv_hr's 37.9 k).  (A ragged tile touches lines of other pixels or, beyond the map, nothing: the descriptor's range.)
+                        const unsigned wo = (unsigned)((8 * (tqk >> 7) + ((tqk >> 4) & 3)) * W + 8 * ((tqk >> 6) & 1)) * 256u + (unsigned)(tqk & 15) * 128u;
+                        auto* dump = (__attribute__((address_space(3))) void*)(smem + DUMP_B + (tqk >> 6) * 256);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_res, dump, 4, (int)wo, (int)((unsigned)(ty0 * W + tx0) * 256u), 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_res, dump, 4, (int)(wo + (unsigned)W * 1024u), (int)((unsigned)(ty0 * W + tx0) * 256u), 0, 0);
                     }
                     // rolling transform of row TR + the patch rows of step S + 1.  Branch kernels: the transform BEFORE this chunk's patch reads
                     // -- the rows it frees (chunk 0: the old rows 1 and 3) are dead by the time new ones arrive, at most three patch rows live
@@ -828,7 +850,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
                 if (PARTIAL) go[j] = (ty0 + row < H && tx0 + col < W) ? go[j] : OOBW;
             }
             f32x4 rs[4];
-            if (RES) asm volatile("" ::"v"(warm0), "v"(warm1));       // (keeps the warm-up loads alive; they are long done)
             if (RES) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rs[j] = bload4(r_res, go[j], so);
