@@ -124,27 +124,34 @@ def committed_pmc_traffic(tag):
 
 
 def _wino_flags(name):
-    """(PAR, RES, MS, FO) of a summarised `conv3x3_wino_kernel<...>` name, None for anything else"""
+    """(PAR, RES, MS, FO) of a summarised `conv3x3_wino_kernel<...>` name -- or, for `conv3x3_wino_gated_kernel<RES>` (round 6: a front
+    half behind the device-side gate as ONE launch, fold-only or branch body), (None, RES, False, None); None for anything else"""
     import re
     m = re.search(r'conv3x3_wino_kernel<\s*(true|false)\s*,\s*(true|false)\s*,\s*(true|false)\s*,\s*(true|false)\s*>', name)
-    return tuple(x == 'true' for x in m.groups()) if m else None
+    if m:
+        return tuple(x == 'true' for x in m.groups())
+    m = re.search(r'conv3x3_wino_gated_kernel<\s*(true|false)\s*>', name)
+    return (None, m.group(1) == 'true', False, None) if m else None
 
 
 def _launch_weighted_traffic(pmc, prefix, min_bytes=0.0):
     """launch-weighted mean HBM bytes per launch over the kernel variants whose summarised name starts with `prefix`.
 
     `conv3x3_wino_kernel<PAR,RES,MS,FO>` is several kernels under one symbol: the roofline of the block convs counts exactly the
-    single-source instantiations (MS = false: plain = conv_hr, RES = back halves, FO / PAR = front halves) -- the multi-source one
-    is the input conv -- and among those only launches that worked: a front half is launched twice behind a device-side gate and one
-    of the two returns after reading the frame's partition word (a few KB; `min_bytes` drops those variants)."""
+    single-source instantiations (MS = false: plain = conv_hr, RES = back halves, FO / PAR = front halves, + the gated front-half
+    kernels) -- the multi-source one is the input conv -- and among those only launches that worked: round 5 launched a front half
+    twice behind a device-side gate and one of the two returned after reading the frame's partition word (a few KB; `min_bytes` drops
+    those variants)."""
     ks = []
     for k, v in pmc.items():
-        if not (k.startswith(prefix) or '::' + prefix in k) or 'hbm_bytes_per_launch' not in v:
+        if 'hbm_bytes_per_launch' not in v:
             continue
         if prefix == 'conv3x3_wino_kernel':
             f = _wino_flags(k)
             if f is None or f[2]:
                 continue
+        elif not (k.startswith(prefix) or '::' + prefix in k):
+            continue
         if v['hbm_bytes_per_launch'] < min_bytes:
             continue
         ks.append(v)

@@ -127,9 +127,11 @@ struct WinoArgs {
 // as the branch kernel does it for such a wave (same FMAs, same MFMA order: bit-identical values).  The plane and its value come from
 // one pixel of the quadrant; its 1x1 fragments straight from L2.
 template <bool PAR, bool RES, bool MS, bool FO = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) {
+__device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
     static_assert(!MS || (!PAR && !RES), "the multi-source form is the input conv: no branches, no residual");
     static_assert(!FO || (!PAR && !MS), "fold-only is the plain structure");
+    // (declared HERE, not handed in by the kernel: as a pointer parameter the LDS base stops being the constant 0 for address folding,
+    //  and the K loop keeps four more base registers -- in scratch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m = lane & 15, kq = lane >> 4;
@@ -1080,6 +1082,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 // 8x8 pixels, the four waves splitting the output channels -- the arithmetic of the big kernel's tail units (bit for bit the same
 // values as a whole tile), as a kernel of its own: the 10x10x64 halo goes to LDS first, the B fragments come straight from L2 a step
 // ahead, 2.25x fewer matrix FLOPs than the direct form and four times as many blocks.
+template <bool PAR, bool RES, bool MS, bool FO = false>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) {
+    wino_tile_body<PAR, RES, MS, FO>(a);
+}
+
+#ifndef WINO_MS_TU
+// A front half behind the device-side gate as ONE launch: the frame's partition word (ConvArgs::par_any, bit 3 = every 8x8 quadrant of the
+// frame is all zero or carries one constant plane) picks the fold-only body or the branch body -- block-uniform, one scalar load.  Round 5
+// launched both kernels and let one return (112 launches of 5.2 us per 720p clip step = 0.7 %); the bodies are the standalone kernels'
+// (same registers, same LDS; only the taken one ever enters the instruction cache).
+template <bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_gated_kernel(const WinoArgs a) {
+    WinoArgs b = a;
+    b.gate = nullptr;
+    if (__builtin_nontemporal_load(a.gate) & 8) {
+        b.par_flags = nullptr;
+        wino_tile_body<false, RES, false, true>(b);
+    } else {
+        wino_tile_body<true, RES, false, false>(b);
+    }
+}
+#endif
+
 #ifndef WINO_MS_TU
 template <bool PAR, bool RES>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArgs a) {
@@ -1561,9 +1586,9 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
     int cus = 256;
     const hipError_t attr_err = once.run([](int dev, int& g) {
         hipError_t e = hipSuccess;
-        const void* fo = reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false, true>);
+        const void* fo = reinterpret_cast<const void*>(conv3x3_wino_gated_kernel<false>);
         e = hipFuncSetAttribute(fo, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
-        const void* fo_res = reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false, true>);
+        const void* fo_res = reinterpret_cast<const void*>(conv3x3_wino_gated_kernel<true>);
         if (e == hipSuccess) e = hipFuncSetAttribute(fo_res, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS);
         const void* fns[4] = {reinterpret_cast<const void*>(conv3x3_wino_kernel<false, false, false>),
                               reinterpret_cast<const void*>(conv3x3_wino_kernel<false, true, false>),
@@ -1620,22 +1645,12 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         w.Urgb = a.wwino_rgb;
         return launch_conv3x3_wino_ms_raw(&w, grid, a.wino_units ? 1 : 0, ntiles, stream);
     } else if (a.wpar && a.par_any) {
-        // Two launches behind a device-side gate on the frame's partition word (launch_par_frame_any), one of which returns at once:
-        // the fold-only kernel when EVERY 8x8 quadrant of the frame is all zero or carries one constant plane (one-hot maps on >= 8x8
-        // codec blocks, frames without records), the branch kernel otherwise.  Bit-identical results either way.
-        WinoArgs f = w;
-        f.par_flags = nullptr;
-        f.gate = w.gate = a.par_any;
-        f.gate_mask = w.gate_mask = 8;
-        f.gate_want = 1;
-        w.gate_want = 0;
-        if (a.residual) {        // channel-last blocks: branches + residual in one launch
-            hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, f);
-            hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-        } else {
-            hipLaunchKernelGGL((conv3x3_wino_kernel<false, false, false, true>), dim3(grid), dim3(256), WINO_LDS, stream, f);
-            hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
-        }
+        // ONE launch behind a device-side gate on the frame's partition word (launch_par_frame_any): the fold-only body when EVERY 8x8
+        // quadrant of the frame is all zero or carries one constant plane (one-hot maps on >= 8x8 codec blocks, frames without records),
+        // the branch body otherwise.  Bit-identical results either way.
+        w.gate = a.par_any;
+        if (a.residual) hipLaunchKernelGGL((conv3x3_wino_gated_kernel<true>), dim3(grid), dim3(256), WINO_LDS, stream, w);       // channel-last blocks
+        else hipLaunchKernelGGL((conv3x3_wino_gated_kernel<false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     } else if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<true, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_kernel<true, false, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);
     else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_kernel<false, true, false>), dim3(grid), dim3(256), WINO_LDS, stream, w);

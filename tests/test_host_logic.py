@@ -487,6 +487,10 @@ def test_roofline_traffic_counts_exactly_the_block_conv_launches_of_the_committe
     assert abs(alg / 1e6 - 591.6) < 0.1 and abs(t / alg - 1.318) < 0.002
     assert bench._wino_flags('conv3x3_wino_kernel<false, true, false, true>') == (False, True, False, True)
     assert bench._wino_flags('conv3x3_wino_quad_kernel<false,true>') is None
+    assert bench._wino_flags('conv3x3_wino_gated_kernel<true>') == (None, True, False, None)        # r06: one launch per gated front half
+    assert abs(bench._launch_weighted_traffic({'conv3x3_wino_gated_kernel<false>': {'hbm_bytes_per_launch': 5e8, 'launches': 3},
+                                               'conv3x3_wino_kernel<false,false,true,false>': {'hbm_bytes_per_launch': 9e8, 'launches': 1}},
+                                              'conv3x3_wino_kernel') - 5e8) < 1
     # without the floor the gated returns dilute the mean; the input conv never enters
     assert bench._launch_weighted_traffic(pmc, 'conv3x3_wino_kernel') < t
     assert 'traffic_ratio' in bench.ROOFLINE_KEEP and 'algorithmic_bytes_per_launch' in bench.ROOFLINE_KEEP

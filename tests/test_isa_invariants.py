@@ -89,14 +89,24 @@ def test_winograd_kernel_is_built_without_packed_fp32_valu_ops(tmp_path):
     text = _wino_asm(tmp_path, 'conv_wino.hip')
     kernels = {re.search(r'kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)E', fn.split('\n')[0]).groups(): fn
                for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_kernel' in fn.split('\n')[0]}
-    # {plain, residual, branches, branches + residual, fold-only (+ residual)}; the multi-source one lives in conv_wino_ms.hip
-    assert sorted(kernels) == sorted([('0', '0', '0', '0'), ('0', '1', '0', '0'), ('1', '0', '0', '0'), ('1', '1', '0', '0'),
-                                      ('0', '0', '0', '1'), ('0', '1', '0', '1')])
+    # {plain, residual, branches, branches + residual}; the fold-only bodies live in the two gated kernels (fold-only | branch body behind
+    # the frame's partition word), the multi-source one in conv_wino_ms.hip
+    assert sorted(kernels) == sorted([('0', '0', '0', '0'), ('0', '1', '0', '0'), ('1', '0', '0', '0'), ('1', '1', '0', '0')])
+    gated = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_gated_kernel' in fn.split('\n')[0]]
+    assert len(gated) == 2
+    for fn in gated:
+        assert fn.count('v_mfma_f32_16x16x4_f32') >= 1280 + 2240 and not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn)
+        # the fold-only body comes first: its K loop (the first 1024 MFMAs) stays clear of scratch traffic like the standalone kernels'
+        lines = fn.split('\n')
+        mf = [i for i, l in enumerate(lines) if 'v_mfma_f32_16x16x4_f32' in l]
+        assert sum(1 for l in lines[mf[0]:mf[1023]] if 'scratch_' in l) <= 4
+    gsizes = [int(v) for v in re.findall(r'conv3x3_wino_gated_kernel\w+\.private_seg_size, (\d+)', text)]
+    assert len(gsizes) == 2 and max(gsizes) <= 160, gsizes
     # the accumulators and the transformed patch live in REGISTERS: a source order hipcc does not like once put both arrays into scratch
     # memory (private_seg_size 1616: correct results, ten times slower).  Round 6 (patch rows read where they are
     # transformed): 40-52 B for the kernels of the default path (r05: 84-176), <= 128 B for the branch kernels (208-236)
     sizes = {tuple(k): int(v) for *k, v in re.findall(r'conv3x3_wino_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)E\w+\.private_seg_size, (\d+)', text)}
-    assert len(sizes) == 6
+    assert len(sizes) == 4
     for k, v in sizes.items():
         assert v <= (64 if k[0] == '0' else 160), (k, v)
     for k, fn in kernels.items():

@@ -7,7 +7,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ('conv3x3_wino_quad_ms_kernel', 'conv3x3_wino_quad_kernel', 'conv3x3_wino_kernel', 'conv3x3_persist_kernel', 'conv3x3_mfma_kernel', 'conv3x3_f16x3_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_f16_kernel', 'par_tile_flags_kernel', 'conv_last_valu_kernel', 'dcn_window_kernel',
+    for k in ('conv3x3_wino_quad_ms_kernel', 'conv3x3_wino_quad_kernel', 'conv3x3_wino_gated_kernel', 'conv3x3_wino_kernel', 'conv3x3_persist_kernel', 'conv3x3_mfma_kernel', 'conv3x3_f16x3_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_f16_kernel', 'par_tile_flags_kernel', 'conv_last_valu_kernel', 'dcn_window_kernel',
               'mv_warp_nhwc64_kernel', 'mv_warp_nhwc_kernel', 'psnr_sse_kernel', 'flow_warp_nchw_kernel', 'pack_weights_kernel',
               'pack_lr_kernel', 'caa_predict_kernel', 'mix_bias_kernel'):
         if k in name:
@@ -17,7 +17,7 @@ def short(name):
                 if not mm:
                     mm = re.search(r'conv3x3_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
                 return k + ('<%s,%s,%s,%s>' % mm.groups() if mm else '')
-            if k in ('conv3x3_wino_quad_kernel', 'conv3x3_wino_kernel', 'conv3x3_f16x3_kernel', 'conv3x3_f16_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_persist_kernel', 'dcn_window_kernel', 'mv_warp_nhwc_kernel', 'mv_warp_nhwc64_kernel'):     # keep the template arguments
+            if k in ('conv3x3_wino_quad_kernel', 'conv3x3_wino_gated_kernel', 'conv3x3_wino_kernel', 'conv3x3_f16x3_kernel', 'conv3x3_f16_kernel', 'conv3x3_f16_small_kernel', 'conv3x3_f16_multi_kernel', 'conv3x3_persist_kernel', 'dcn_window_kernel', 'mv_warp_nhwc_kernel', 'mv_warp_nhwc64_kernel'):     # keep the template arguments
                 import re
                 mm = re.search(k + r'<([^>]*)>', name)
                 if mm:
