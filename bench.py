@@ -989,7 +989,17 @@ def secondary_workloads(dev, T, no_cpu_baseline=False):
         out.append(e)
         del m, a
         torch.cuda.empty_cache()
-    out.append(pipeline_e2e(dev, T))
+    # the loop twice: a process's FIRST pass fills the caching allocators inside the timed window (pinned host staging buffers, the
+    # device tensors of the clips in flight, the second workspace context: hipHostMalloc / hipMalloc beside running kernels) -- 58.5
+    # frames/s against 66.6 for every later pass (tools/e2e_probe.py, r06); an evaluation run has hundreds of clips, so the entry's value
+    # is the steady pass and the first one is kept beside it
+    first = pipeline_e2e(dev, T)
+    torch.cuda.empty_cache()
+    e2e = pipeline_e2e(dev, T)
+    e2e['first_pass_of_the_process'] = {k: first[k] for k in ('value', 'seconds_total', 'seconds_generator_forward')}
+    e2e['note'] += ('; `value` is the SECOND pass of the loop in this process (allocators warm: the steady state of a long evaluation), '
+                    'first_pass_of_the_process the cold one')
+    out.append(e2e)
     torch.cuda.empty_cache()
     return out
 
