@@ -69,6 +69,12 @@ constexpr unsigned OOBW = 0xFFFFFFF0u;
 #ifndef WINO_MS_LAUNDER
 #define WINO_MS_LAUNDER 1 // A/B switch (MS): the thread id laundered per segment for the halo offsets (2: for every per-lane constant of the chunks)
 #endif
+#ifndef WINO_RING_DMA
+#define WINO_RING_DMA 1   // A/B switch (plain / residual / fold-only kernels): the weight chunks arrive in the ring as LDS-DMA loads too -- no staging
+#endif                    // registers (16), no ring write, ONE counted wait per chunk placed a chunk and a half behind the request
+#ifndef WINO_HALO_DMA
+#define WINO_HALO_DMA 1   // A/B switch: the next tile's halo slabs arrive as LDS-DMA loads (no staging registers, no ds_write, no wait for the data in
+#endif                    // the instruction stream) instead of load -> register -> ds_write a chunk later
 #ifndef WINO_QUAD
 #define WINO_QUAD 1      // A/B switch of the quadrant units (conv3x3_wino_kernel's tail)
 #endif
@@ -97,6 +103,13 @@ __device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) { return f32x4{a[0] + b[
 __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { return f32x4{a[0] - b[0], a[1] - b[1], a[2] - b[2], a[3] - b[3]}; }
 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the weight / halo requests kept in flight
 __device__ __forceinline__ void lds_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15: "do not wait")
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
 
 struct WinoArgs {
     const float* src;       // NHWC64
@@ -440,6 +453,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
         const unsigned nso = (unsigned)(nty0 * W + ntx0) * 256u;
         if constexpr (!MS) halo_offsets(tq, nty0, ntx0);
         unsigned tq16 = (unsigned)tq * 16u;
+        const int wave_s = __builtin_amdgcn_readfirstlane(tq >> 6);      // the wave's index as a scalar (LDS-DMA destinations go through M0)
         int tqk = tq;            // the thread id the chunks derive their per-lane constants from (MS: laundered once more per segment)
         // MS: per segment (= one 64-channel source): where its weight image starts, where the next segment's does, whether it is the
         // tile's last one (then the next chunks are the next tile's RGB chunks), and the tile origin of the slabs it refills
@@ -548,6 +562,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                 constexpr int NRING = NBR ? 3 : 4;
                 constexpr bool NEXT_IS_BR = PAR && PG == 3;      // the next chunk is a branch chunk: it reads its own fragments
                 constexpr int TR = PG == 0 ? 3 : PG - 1;         // the V row rewritten in this chunk (row 3 of step S, or row PG - 1 of S + 1)
+                constexpr bool RDMA = WINO_RING_DMA && WINO_HALO_DMA && !PAR && !MS;
                 // WINO_JIT_ROWS: V row TR = column transform of (patch row RA -/+ patch row RB): row 3 = d1 - d3 of step S (slab S is refilled from
                 // position chunk 1 of step S on: still this tile's here), rows 0 / 1 / 2 = d0 - d2 / d1 + d2 / d2 - d1 of step S + 1.  Both rows are
                 // read in this chunk and dead behind the transform: no patch row lives across a chunk, the epilogue or the tile seam
@@ -590,15 +605,40 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                             else if (!last_seg) breg[g - 4] = bload4(r_u, tq16, nx_base + (C - 13) * 16384 + (g - 4) * 4096);
                             else if (g == 4) breg[0] = bload4(r_urgb, tq16, (C - 13) * 4096);
                         }
-                    } else if (g >= 4 && g < 4 + NRING)
+                    } else if (RDMA && g >= 4 && g < 8) {
+                        // chunk C + 3 straight into its ring slot (the slot of chunk C - 1: every wave left it before the barrier at the top of
+                        // this chunk), piece g - 4 of wave w = 64 lanes x 16 B at byte (g - 4) * 4096 + 1024 w
+                        auto* dst = (__attribute__((address_space(3))) void*)(smem + (NC & 3) * 16384 + (g - 4) * 4096 + wave_s * 1024);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_u, dst, 16, (int)tq16, (NSTEP * 4 + NPG) * 16384 + (g - 4) * 4096, 0, 0);
+                    } else if (!RDMA && g >= 4 && g < 4 + NRING)
                         breg[g - 4] = NBR ? bload4(r_up, tq16, NSTEP * 12288 + (g - 4) * 4096) : bload4(r_u, tq16, (NSTEP * 4 + NPG) * 16384 + (g - 4) * 4096);
                     if (S == 0 && PG == 1 && g == 7) bgv = *reinterpret_cast<const f32x4*>(smem + BG_B + (tqk & 15) * 16);
-                    if ((PG == 1 || PG == 2) && g >= 8 && g < 11) {        // (before this chunk's own halo requests reuse the registers)
-                        int e = tqk + 256 * (g - 8 + 3 * (PG - 1));
-                        e = e < NPX * 4 ? e : NPX * 4 - 1;
-                        *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[g - 8];
+                    if constexpr (WINO_HALO_DMA) {
+                        // The next tile's slab S (1296 float4) as LDS-DMA loads: pieces 0-2 in position chunk 1, pieces 3, 4 in chunk 2 -- every
+                        // wave has read its last patch rows of slab S in chunk 0, the barrier at the top of chunk 1 is behind -- each straight to
+                        // its place (piece i of wave w: 64 lanes x 16 B at element 256 i + 64 w).  No staging registers (12), no ds_write, and no
+                        // wait for HBM data in the instruction stream: the loads retire in order in front of the weight requests the ring
+                        // writes wait for, and the slab's first reader is five chunks away.  The sixth piece is 16 elements (1280 .. 1295): a
+                        // DMA load would write 240 lanes past the slab, so it stays load -> register -> ds_write (chunk 2 -> chunk 3).
+                        if ((PG == 1 || PG == 2) && g >= 11 && g < (PG == 1 ? 14 : 13)) {
+                            const int i = g - 11 + 3 * (PG - 1);
+                            auto* dst = (__attribute__((address_space(3))) void*)(smem + RING_B + S * SLAB_B + i * 4096 + wave_s * 1024);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_src, dst, 16, (int)hoff[i], (int)(ref_so + S * 64), 0, 0);
+                        }
+                        if (PG == 2 && g == 13) hreg[0] = bload4(r_src, hoff[5], ref_so + S * 64);
+                        if (PG == 3 && g == 8) {
+                            int e = tqk + 256 * 5;
+                            e = e < NPX * 4 ? e : NPX * 4 - 1;
+                            *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[0];
+                        }
+                    } else {
+                        if ((PG == 1 || PG == 2) && g >= 8 && g < 11) {        // (before this chunk's own halo requests reuse the registers)
+                            int e = tqk + 256 * (g - 8 + 3 * (PG - 1));
+                            e = e < NPX * 4 ? e : NPX * 4 - 1;
+                            *reinterpret_cast<f32x4*>(smem + RING_B + S * SLAB_B + e * 16) = hreg[g - 8];
+                        }
+                        if ((PG == 0 || PG == 1) && g >= 11 && g < 14) hreg[g - 11] = bload4(r_src, hoff[g - 11 + 3 * PG], ref_so + S * 64);
                     }
-                    if ((PG == 0 || PG == 1) && g >= 11 && g < 14) hreg[g - 11] = bload4(r_src, hoff[g - 11 + 3 * PG], ref_so + S * 64);
                     // MS, last source: the next tile's RGB halo, requested in step 1 and stored a chunk later (this tile's RGB patch was read
                     // before its first chunk)
                     // (every segment does it: the same pixels again, but no run-time branch in the chunk and no value that lives across one)
@@ -698,8 +738,19 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                             }
                         }
                     }
-                    if (g >= 52 && g < 52 + NRING) {
+                    if (!RDMA && g >= 52 && g < 52 + NRING) {
                         if (WINO_MS_FLAT || !(MS && C >= 13 && last_seg && g > 52)) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
+                    }
+                    if (RDMA && g == 63) {
+                        // The ONE wait of a chunk: everything requested BEFORE this chunk has landed -- i.e. the weight chunk C + 2 (requested a
+                        // chunk ago, first read behind the barrier at the top of the next chunk) and every halo piece older than this chunk.
+                        // vmcnt retires in order, so "at most the requests of THIS chunk outstanding" says exactly that: 4 weight pieces + the
+                        // halo pieces (3 | 2 + the sixth piece's register load) + the residual warm-up (2) + the folded plane's fragments (4).
+                        // (The epilogue's stores in front of a tile's first chunk are not counted: that wait then covers them too, as the ring
+                        //  write's wait did.)
+                        constexpr int NVM = 4 + (WINO_HALO_DMA ? (PG == 1 ? 3 : (PG == 2 ? 3 : 0)) : ((PG == 0 || PG == 1) ? 3 : 0))
+                                          + ((RES && S == 3 && PG == 0) ? 2 : 0) + ((FO && PG == 0) ? 4 : 0);
+                        wait_vm<NVM>();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -900,6 +951,9 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
         ty0 = nty0;
         tx0 = ntx0;
     }
+    // (LDS-DMA loads of "the next tile's" first weight chunks may still be in flight behind the block's last tile: they must have landed
+    //  before the block ends and its LDS goes to the next one)
+    if constexpr (WINO_RING_DMA && WINO_HALO_DMA && !PAR && !MS) wait_vm<0>();
     // ---- quadrant unit (see the strip assignment): 8x8 pixels of tile qtile, wave w = output channels 16 w .. + 15.  Same arithmetic
     // in the same order as a whole tile -- per accumulator: branches, then the position's 4 k-steps, step by step; bias through the C
     // operand of position (1,1) -- so a pixel's value does not depend on which form computed it (bit for bit; tested).  Straight-line code:
