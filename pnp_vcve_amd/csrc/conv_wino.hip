@@ -150,6 +150,8 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
     const int m = lane & 15, kq = lane >> 4;
     const int H = a.H, W = a.W;
     const int tiles_x = (W + 15) >> 4, ntiles = tiles_x * ((H + 15) >> 4);
+    // MS with the ring as LDS-DMA loads: no run-time `last source?` branch inside a chunk (every chunk's wait counts its own requests)
+    constexpr bool MSF = WINO_MS_FLAT || (MS && WINO_RING_DMA && WINO_HALO_DMA);
     if (a.gate) {      // (block-uniform: a scalar load)
         const int gv = __builtin_nontemporal_load(a.gate);
         if (((gv & a.gate_mask) != 0) != (a.gate_want != 0)) return;
@@ -562,7 +564,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                 constexpr int NRING = NBR ? 3 : 4;
                 constexpr bool NEXT_IS_BR = PAR && PG == 3;      // the next chunk is a branch chunk: it reads its own fragments
                 constexpr int TR = PG == 0 ? 3 : PG - 1;         // the V row rewritten in this chunk (row 3 of step S, or row PG - 1 of S + 1)
-                constexpr bool RDMA = WINO_RING_DMA && WINO_HALO_DMA && !PAR && !MS;
+                constexpr bool RDMA = WINO_RING_DMA && WINO_HALO_DMA && !PAR;
                 // WINO_JIT_ROWS: V row TR = column transform of (patch row RA -/+ patch row RB): row 3 = d1 - d3 of step S (slab S is refilled from
                 // position chunk 1 of step S on: still this tile's here), rows 0 / 1 / 2 = d0 - d2 / d1 + d2 / d2 - d1 of step S + 1.  Both rows are
                 // read in this chunk and dead behind the transform: no patch row lives across a chunk, the epilogue or the tile seam
@@ -589,7 +591,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                     if ((g & 15) < 4 && !(pj == 3 && NEXT_IS_BR)) {
                         // (MS, the tile's last chunk: the next one is an RGB chunk of the next tile, which reads its own fragments -- the read
                         //  here is then of no use, and harmless; a run-time `if (last_seg)` per gap would cut the straight-line schedule)
-                        if (WINO_MS_FLAT || !(MS && C == 15 && pj == 3 && last_seg)) {
+                        if (MSF || !(MS && C == 15 && pj == 3 && last_seg)) {
                             const unsigned nb = pj < 3 ? (C & 3) * 16384 + (pj + 1) * 4096 : ((C + 1) & 3) * 16384;
                             bf[(pj + 1) & 1][g & 3] = lds4(nb + bl + (g & 3) * 1024);
                         }
@@ -599,9 +601,13 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                         // which are one 4-KiB piece each.  Branch-free: descriptor, base, chunk and piece stride of "the next segment" are
                         // per-segment scalars (last source: the RGB image with piece stride 0 -- its one piece is fetched four times and lands
                         // in all four quarters of the ring slot, of which an RGB chunk reads the first)
-                        if (g >= 4 && g < 8) {
+                        if (RDMA && g >= 4 && g < 8) {
+                            auto* dst = (__attribute__((address_space(3))) void*)(smem + (NC & 3) * 16384 + (g - 4) * 4096 + wave_s * 1024);
+                            if (C < 13) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_u, dst, 16, (int)tq16, (int)(u_so + (C + 3) * 16384 + (g - 4) * 4096), 0, 0);
+                            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r_nx, dst, 16, (int)tq16, (int)(nx_base + (C - 13) * nx_cs + (g - 4) * nx_ps), 0, 0);
+                        } else if (g >= 4 && g < 8) {
                             if (C < 13) breg[g - 4] = bload4(r_u, tq16, u_so + (C + 3) * 16384 + (g - 4) * 4096);
-                            else if (WINO_MS_FLAT) breg[g - 4] = bload4(r_nx, tq16, nx_base + (C - 13) * nx_cs + (g - 4) * nx_ps);
+                            else if (MSF) breg[g - 4] = bload4(r_nx, tq16, nx_base + (C - 13) * nx_cs + (g - 4) * nx_ps);
                             else if (!last_seg) breg[g - 4] = bload4(r_u, tq16, nx_base + (C - 13) * 16384 + (g - 4) * 4096);
                             else if (g == 4) breg[0] = bload4(r_urgb, tq16, (C - 13) * 4096);
                         }
@@ -642,7 +648,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                     // MS, last source: the next tile's RGB halo, requested in step 1 and stored a chunk later (this tile's RGB patch was read
                     // before its first chunk)
                     // (every segment does it: the same pixels again, but no run-time branch in the chunk and no value that lives across one)
-                    if (MS && S == 1 && PG == 0 && g == 14 && (WINO_MS_FLAT || last_seg)) rgb_dma(tqk, nty0, ntx0);
+                    if (MS && S == 1 && PG == 0 && g == 14 && (MSF || last_seg)) rgb_dma(tqk, nty0, ntx0);
                     if (RES && S == 3 && PG == 0 && g == 16) {
                         // The residual map was last touched a whole launch ago: its lines come from HBM.  Touch this wave's 128 lines (8 rows x
                         // 8 pixels x 256 B) now, four chunks ahead of the epilogue, so that its 16-B loads find them in L2.  As LDS-DMA loads
@@ -739,7 +745,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                         }
                     }
                     if (!RDMA && g >= 52 && g < 52 + NRING) {
-                        if (WINO_MS_FLAT || !(MS && C >= 13 && last_seg && g > 52)) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
+                        if (MSF || !(MS && C >= 13 && last_seg && g > 52)) *reinterpret_cast<f32x4*>(smem + (NC & 3) * 16384 + (g - 52) * 4096 + tq16) = breg[g - 52];
                     }
                     if (RDMA && g == 63) {
                         // The ONE wait of a chunk: everything requested BEFORE this chunk has landed -- i.e. the weight chunk C + 2 (requested a
@@ -748,8 +754,9 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                         // halo pieces (3 | 2 + the sixth piece's register load) + the residual warm-up (2) + the folded plane's fragments (4).
                         // (The epilogue's stores in front of a tile's first chunk are not counted: that wait then covers them too, as the ring
                         //  write's wait did.)
+                        // (MS: + the two pieces of the next tile's RGB halo)
                         constexpr int NVM = 4 + (WINO_HALO_DMA ? (PG == 1 ? 3 : (PG == 2 ? 3 : 0)) : ((PG == 0 || PG == 1) ? 3 : 0))
-                                          + ((RES && S == 3 && PG == 0) ? 2 : 0) + ((FO && PG == 0) ? 4 : 0);
+                                          + ((RES && S == 3 && PG == 0) ? 2 : 0) + ((FO && PG == 0) ? 4 : 0) + ((MS && S == 1 && PG == 0) ? 2 : 0);
                         wait_vm<NVM>();
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -811,7 +818,19 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
 #pragma unroll
                 for (int pj = 0; pj < 4; ++pj) br[pj] = lds4(PG * 16384 + (pj * 64 + (tq & 63)) * 16);
                 // three ahead: RGB chunk 3 (one piece), then the first source's chunks 0..2
-                if (PG == 0) breg[0] = bload4(r_urgb, tq16, 3 * 4096);
+                constexpr bool RD = WINO_RING_DMA && WINO_HALO_DMA;
+                if constexpr (RD) {
+                    // (the slot of the RGB chunk in front: every wave took its fragments out of it before the barrier above)
+                    auto* dst = (__attribute__((address_space(3))) void*)(smem + ((PG + 3) & 3) * 16384 + wave_s * 1024);
+                    if (PG == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_urgb, dst, 16, (int)tq16, 3 * 4096, 0, 0);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            auto* di = (__attribute__((address_space(3))) void*)(smem + ((PG + 3) & 3) * 16384 + i * 4096 + wave_s * 1024);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_u, di, 16, (int)tq16, (int)(a.u_off[0] + (PG - 1) * 16384 + i * 4096), 0, 0);
+                        }
+                    }
+                } else if (PG == 0) breg[0] = bload4(r_urgb, tq16, 3 * 4096);
                 else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) breg[i] = bload4(r_u, tq16, a.u_off[0] + (PG - 1) * 16384 + i * 4096);
@@ -828,8 +847,11 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
 #pragma unroll
                     for (int n = 0; n < 4; ++n) bf[0][n] = lds4(bl + n * 1024);
                 }
+                if constexpr (RD) wait_vm<(PG == 0 ? 1 : 4)>();       // what the chunks in front requested has landed (this chunk's own may fly)
+                else {
 #pragma unroll
-                for (int i = 0; i < (PG == 0 ? 1 : 4); ++i) *reinterpret_cast<f32x4*>(smem + ((PG + 3) & 3) * 16384 + i * 4096 + tq16) = breg[i];
+                    for (int i = 0; i < (PG == 0 ? 1 : 4); ++i) *reinterpret_cast<f32x4*>(smem + ((PG + 3) & 3) * 16384 + i * 4096 + tq16) = breg[i];
+                }
             };
             rgb_chunk(I<0>{});
             rgb_chunk(I<1>{});
@@ -840,10 +862,10 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
             for (int ks = 0; ks < nw; ++ks) {
                 last_seg = ks + 1 >= nw;
                 u_so = a.u_off[ks];
-                if (WINO_MS_FLAT) r_nx = rsrc_of(last_seg ? a.Urgb : a.ubase, last_seg ? 4u * 4096u : OOBW);
-                nx_base = (WINO_MS_FLAT && last_seg) ? 0u : a.u_off[last_seg ? 0 : ks + 1];
-                nx_cs = (WINO_MS_FLAT && last_seg) ? 4096u : 16384u;
-                nx_ps = (WINO_MS_FLAT && last_seg) ? 0u : 4096u;
+                if (MSF) r_nx = rsrc_of(last_seg ? a.Urgb : a.ubase, last_seg ? 4u * 4096u : OOBW);
+                nx_base = (MSF && last_seg) ? 0u : a.u_off[last_seg ? 0 : ks + 1];
+                nx_cs = (MSF && last_seg) ? 4096u : 16384u;
+                nx_ps = (MSF && last_seg) ? 0u : 4096u;
                 // the slabs this segment refills belong to the next source of this tile, or to the first source of the next tile
                 r_src = rsrc_of(reinterpret_cast<const char*>(a.srcs[last_seg ? 0 : ks + 1]) - ((long)W + 1) * 256, OOBW);
                 ref_so = last_seg ? nso : (unsigned)(ty0 * W + tx0) * 256u;
@@ -953,7 +975,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
     }
     // (LDS-DMA loads of "the next tile's" first weight chunks may still be in flight behind the block's last tile: they must have landed
     //  before the block ends and its LDS goes to the next one)
-    if constexpr (WINO_RING_DMA && WINO_HALO_DMA && !PAR && !MS) wait_vm<0>();
+    if constexpr (WINO_RING_DMA && WINO_HALO_DMA && !PAR) wait_vm<0>();
     // ---- quadrant unit (see the strip assignment): 8x8 pixels of tile qtile, wave w = output channels 16 w .. + 15.  Same arithmetic
     // in the same order as a whole tile -- per accumulator: branches, then the position's 4 k-steps, step by step; bias through the C
     // operand of position (1,1) -- so a pixel's value does not depend on which form computed it (bit for bit; tested).  Straight-line code:

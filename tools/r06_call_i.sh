@@ -1,15 +1,15 @@
 #!/bin/bash
 # round 6, GPU call I: halo slabs as LDS-DMA -- Winograd + generator tests, then A/B previous commit / current
-O=gpurun_out/r06i; mkdir -p $O
+O=gpurun_out/r06k; mkdir -p $O
 python -m pytest tests/test_gpu_wino.py tests/test_gpu_generator.py -m gpu -x -q > $O/gpu_tests.txt 2>&1; tail -3 $O/gpu_tests.txt
 AB=pnp_vcve_amd/lib/ab
 cp pnp_vcve_amd/lib/libpnpvcve_hip.so $AB/lib_cur.so
 for rep in 1 2; do
-  bash tools/try_libs.sh $O/ab_bench.txt $AB/lib_gated.so $AB/lib_halo.so $AB/lib_cur.so -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary
+  bash tools/try_libs.sh $O/ab_bench.txt $AB/lib_rdma.so $AB/lib_cur.so -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary
 done
 python - <<'PY'
 import json
-for l in open('gpurun_out/r06i/ab_bench.txt'):
+for l in open('gpurun_out/r06k/ab_bench.txt'):
     if l.startswith('==='): print(l.strip())
     elif l.startswith('{'):
         d=json.loads(l); r=d['roofline']
