@@ -69,6 +69,11 @@ constexpr unsigned OOBW = 0xFFFFFFF0u;
 #ifndef WINO_MS_LAUNDER
 #define WINO_MS_LAUNDER 1 // A/B switch (MS): the thread id laundered per segment for the halo offsets (2: for every per-lane constant of the chunks)
 #endif
+#ifndef WINO_SEAM_CUT
+#define WINO_SEAM_CUT 2   // A/B switch: the rolling input transform stops at the tile seam -- V rows 0-2 of the next tile's first step are made behind
+#endif                    // the epilogue instead of in the tile's last three chunks (48 registers do not live across it).  1 = every single-source
+                          // kernel: 86.1 -> 72.8 frames/s (r06; r05 found the same: the allocator answers with 144-264 B of scratch); 2 = the branch
+                          // kernels only (default: 120 -> 56 B of scratch there, front half 414 -> 407 us); 0 = nowhere
 #ifndef WINO_RING_DMA
 #define WINO_RING_DMA 1   // A/B switch (plain / residual / fold-only kernels): the weight chunks arrive in the ring as LDS-DMA loads too -- no staging
 #endif                    // registers (16), no ring write, ONE counted wait per chunk placed a chunk and a half behind the request
@@ -152,6 +157,8 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
     const int tiles_x = (W + 15) >> 4, ntiles = tiles_x * ((H + 15) >> 4);
     // MS with the ring as LDS-DMA loads: no run-time `last source?` branch inside a chunk (every chunk's wait counts its own requests)
     constexpr bool MSF = WINO_MS_FLAT || (MS && WINO_RING_DMA && WINO_HALO_DMA);
+    // the rolling input transform cut at the tile seam: 1 = every single-source kernel, 2 = the branch kernels only
+    constexpr bool SEAM = !MS && WINO_JIT_ROWS && (WINO_SEAM_CUT == 1 || (WINO_SEAM_CUT == 2 && PAR));
     if (a.gate) {      // (block-uniform: a scalar load)
         const int gv = __builtin_nontemporal_load(a.gate);
         if (((gv & a.gate_mask) != 0) != (a.gate_want != 0)) return;
@@ -565,6 +572,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                 constexpr bool NEXT_IS_BR = PAR && PG == 3;      // the next chunk is a branch chunk: it reads its own fragments
                 constexpr int TR = PG == 0 ? 3 : PG - 1;         // the V row rewritten in this chunk (row 3 of step S, or row PG - 1 of S + 1)
                 constexpr bool RDMA = WINO_RING_DMA && WINO_HALO_DMA && !PAR;
+                constexpr bool XF = !(SEAM && S == 3 && PG >= 1);      // this chunk transforms a V row at all
                 // WINO_JIT_ROWS: V row TR = column transform of (patch row RA -/+ patch row RB): row 3 = d1 - d3 of step S (slab S is refilled from
                 // position chunk 1 of step S on: still this tile's here), rows 0 / 1 / 2 = d0 - d2 / d1 + d2 / d2 - d1 of step S + 1.  Both rows are
                 // read in this chunk and dead behind the transform: no patch row lives across a chunk, the epilogue or the tile seam
@@ -672,18 +680,18 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                     // cycles of matrix time before the 4 per instruction (tools/ubench/ub_valu_gap.hip; front half 427 -> 423 us).  The
                     // plain kernels keep one float4 per gap: lumped, the residual kernel spills 22 instead of 13 registers (+3 %).
                     if constexpr (PAR) {
-                        if (WINO_JIT_ROWS && g >= 8 && g < 16) {   // (beside the halo pieces: LDS reads cost the matrix pipe nothing)
+                        if (XF && WINO_JIT_ROWS && g >= 8 && g < 16) {   // (beside the halo pieces: LDS reads cost the matrix pipe nothing)
                             const int c = g & 3;
                             if (g < 12) da[c] = patch(SR{}, RA, c);
                             else db[c] = patch(SR{}, RB, c);
                         }
-                        if (g == 16) {
+                        if (XF && g == 16) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
                                 tt[c] = WINO_JIT_ROWS ? (TR == 1 ? da[c] + db[c] : da[c] - db[c])
                                                       : TR == 0 ? d0[c] - d2[c] : (TR == 1 ? d1[c] + d2[c] : (TR == 2 ? d2[c] - d1[c] : d1[c] - d3[c]));
                         }
-                        if (g == 17) {
+                        if (XF && g == 17) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 V[4 * TR + c] = c == 0 ? tt[0] - tt[2] : (c == 1 ? tt[1] + tt[2] : (c == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
@@ -698,7 +706,7 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                             if (PG == 2 && g < 32) d3[c] = patch(SN{}, 3, c);
                         }
                     } else {
-                        if (WINO_JIT_ROWS && g >= 20 && g < 28) {
+                        if (XF && WINO_JIT_ROWS && g >= 20 && g < 28) {
                             const int c = (g - 20) & 3;
                             if (g < 24) da[c] = patch(SR{}, RA, c);
                             else db[c] = patch(SR{}, RB, c);
@@ -710,12 +718,12 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                             if (PG == 1 && g < 24) d1[c] = patch(SN{}, 1, c);
                             if (PG == 2 && g < 24) d3[c] = patch(SN{}, 3, c);
                         }
-                        if (g >= 36 && g < 40) {                 // first the row combination ...
+                        if (XF && g >= 36 && g < 40) {           // first the row combination ...
                             const int c = g - 36;
                             tt[c] = WINO_JIT_ROWS ? (TR == 1 ? add4(da[c], db[c]) : sub4(da[c], db[c]))
                                                   : TR == 0 ? sub4(d0[c], d2[c]) : (TR == 1 ? add4(d1[c], d2[c]) : (TR == 2 ? sub4(d2[c], d1[c]) : sub4(d1[c], d3[c])));
                         }
-                        if (g >= 40 && g < 44) {                 // ... then the column combination
+                        if (XF && g >= 40 && g < 44) {           // ... then the column combination
                             const int c = g - 40;
                             V[4 * TR + c] = c == 0 ? sub4(tt[0], tt[2]) : (c == 1 ? add4(tt[1], tt[2]) : (c == 2 ? sub4(tt[2], tt[1]) : sub4(tt[1], tt[3])));
                         }
@@ -972,6 +980,38 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
         tile = ntile;
         ty0 = nty0;
         tx0 = ntx0;
+        if constexpr (SEAM) {
+            // V rows 0-2 of the next tile's first step (its slab 0 has been in place since this tile's step 1): twelve patch reads and 24
+            // float4 sums with no MFMA beside them -- the vector ALU is the matrix pipe, so only the LDS latency (a few hundred cycles per
+            // tile) is new -- in exchange for 48 registers that no longer live across the epilogue
+            f32x4 e0[4], e1[4], e2[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                e0[c] = patch(I<0>{}, 0, c);
+                e1[c] = patch(I<0>{}, 1, c);
+                e2[c] = patch(I<0>{}, 2, c);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f32x4 tr[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if constexpr (PAR) tr[c] = i == 0 ? e0[c] - e2[c] : (i == 1 ? e1[c] + e2[c] : e2[c] - e1[c]);
+                    else tr[c] = i == 0 ? sub4(e0[c], e2[c]) : (i == 1 ? add4(e1[c], e2[c]) : sub4(e2[c], e1[c]));
+                }
+                if constexpr (PAR) {
+                    V[4 * i + 0] = tr[0] - tr[2];
+                    V[4 * i + 1] = tr[1] + tr[2];
+                    V[4 * i + 2] = tr[2] - tr[1];
+                    V[4 * i + 3] = tr[1] - tr[3];
+                } else {
+                    V[4 * i + 0] = sub4(tr[0], tr[2]);
+                    V[4 * i + 1] = add4(tr[1], tr[2]);
+                    V[4 * i + 2] = sub4(tr[2], tr[1]);
+                    V[4 * i + 3] = sub4(tr[1], tr[3]);
+                }
+            }
+        }
     }
     // (LDS-DMA loads of "the next tile's" first weight chunks may still be in flight behind the block's last tile: they must have landed
     //  before the block ends and its LDS goes to the next one)
