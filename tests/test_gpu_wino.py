@@ -95,6 +95,32 @@ def test_wino_conv_identity_and_shift_weights_localise_layout_bugs():
         assert torch.equal(nchw(out).double(), ref), (ky, kx)
 
 
+def test_shipped_library_does_not_show_the_packed_fp32_signature():
+    """tools/repro/wino_packed_f32_hazard.py's pattern on the SHIPPED library: identity weights on a 32x32 random map.  The
+    builds with hipcc-generated v_pk_{add,mul}_f32 in conv_wino.hip returned 1/256 of these values wrong, in fixed (lane, register)
+    slots (profiles/r05_wino_packed_f32_hazard.txt); the shipped build is compiled with the packed-fp32 target feature off (CPU test:
+    tests/test_isa_invariants.py) and must be clean here -- tile kernel, unit kernel, with a residual, and the multi-source kernel"""
+    from pnp_vcve_amd import ops
+    h, w = 32, 32
+    g = torch.Generator(device=dev()).manual_seed(32)
+    x = torch.randn(h, w, 64, device=dev(), generator=g)
+    r = torch.randn(h, w, 64, device=dev(), generator=g)
+    wt = torch.zeros(64, 64, 3, 3, device=dev())
+    wt[torch.arange(64), torch.arange(64), 1, 1] = 1.0
+    u = ops.wino_image(ops.pack_conv3x3(wt))
+    # (random values: the +-1 transforms round, so a right result is within ~1e-6 of x; the signature's wrong values were off by up to 3.4)
+    for units in (False, True):
+        assert float((ops.conv3x3_wino(x, u, units=units) - x).abs().max()) < 1e-5
+        assert float((ops.conv3x3_wino(x, u, residual=r, units=units) - (x + r)).abs().max()) < 1e-5
+    wt2 = torch.zeros(64, 67, 3, 3, device=dev())
+    wt2[torch.arange(64), 3 + torch.arange(64), 1, 1] = 1.0
+    lr4 = torch.zeros(h, w, 4, device=dev())
+    urgb = ops.wino_rgb_image(ops.pack_conv3x3(wt2, cbase=0, csrc=3))
+    img = torch.empty(1, 65536, device=dev())
+    img[0] = ops.wino_image(ops.pack_conv3x3(wt2, cbase=3, csrc=64))
+    assert float((ops.conv3x3_wino_ms([lr4, x], [urgb, img[0]]) - x).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize('hw', [(64, 64), (40, 72), (48, 50)])
 @pytest.mark.parametrize('scale', [1.0 / 255.0, 1.0])
 def test_wino_front_half_with_partition_branches(hw, scale):
