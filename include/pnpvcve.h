@@ -226,7 +226,8 @@ int pnp_pixel_shuffle_conv_f32(const float* x_dev, const float* packed_dev, int 
  * gives gamma * bias + conv instead of gamma * (conv + bias), silently; the C ABI cannot tell (the Python op checks the pairing);
  * wino_w1x1_dev = pnp_wino_par_image_from_packed_f32 of the
  * packed 1x1 images or NULL (then par_dev / par_flags_dev are ignored); par_flags_dev as pnp_par_tile_flags_f32 writes
- * them, or NULL.  fp32 arithmetic; differs from pnp_conv3x3_f32 by summation order (~1e-6 on unit-scale maps). */
+ * them, or NULL.  fp32 arithmetic; differs from pnp_conv3x3_f32 by summation order (~1e-6 on unit-scale maps).  With residual_dev the
+ * tile form takes act = 0 only (what the reference's blocks do; PNP_ERR_UNSUPPORTED otherwise), the unit form any act. */
 int64_t pnp_wino_image_floats(void);
 int64_t pnp_wino_par_image_floats(void);
 int pnp_wino_image_from_packed_f32(const float* packed_w_dev, const float* gamma_dev, float* dst_dev, void* stream);

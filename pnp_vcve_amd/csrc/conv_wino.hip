@@ -961,7 +961,10 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                 for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const f32x4*>(tr + rbase + j * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = __builtin_elementwise_max(o[j], act_lo * o[j]);       // none: max(v, 1 v) | relu: max(v, 0 v) | leaky-relu: max(v, 0.1 v)
+                    // none: max(v, 1 v) | relu: max(v, 0 v) | leaky-relu: max(v, 0.1 v).  The residual bodies take no activation (the
+                    // reference adds the residual to a bare conv, sr_backbone_utils.py:313,329; launch_conv3x3_wino refuses anything else):
+                    // 128 vector-ALU instructions per tile less where the matrix pipe stands idle
+                    if constexpr (!RES) o[j] = __builtin_elementwise_max(o[j], act_lo * o[j]);
                     if (RES) {
                         o[j] += rs[j];
                         if (n < 3) rs[j] = bload4(r_res, go[j], so + (n + 1) * 64);       // requested one N tile ahead
@@ -1742,6 +1745,7 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
         else hipLaunchKernelGGL((conv3x3_wino_quad_kernel<false, false>), gq, bq, 0, stream, w);
         return (int)hipGetLastError();
     }
+    if (a.residual && a.act != 0) return PNP_ERR_UNSUPPORTED;      // (tile kernels: residual bodies have no activation; the unit kernels above do)
     int grid = ntiles < cus ? ntiles : cus;                 // one resident block per CU
     if (grid >= 8) grid -= grid % 8;
     if (conv_wino_ms_eligible(a, CONV_CFG_BIG, 1) && !a.wwino) {

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6, GPU call N: fold-only body's plane fragments as shared LDS-DMA -- Winograd + generator tests, A/B vs the previous commit
-O=gpurun_out/r06n; mkdir -p $O
+# round 6, GPU call N: residual bodies without the activation instructions -- Winograd + generator tests, A/B vs the previous commit
+O=gpurun_out/r06o; mkdir -p $O
 python -m pytest tests/test_gpu_wino.py tests/test_gpu_generator.py -m gpu -x -q > $O/gpu_tests.txt 2>&1; tail -3 $O/gpu_tests.txt
 AB=pnp_vcve_amd/lib/ab
 cp pnp_vcve_amd/lib/libpnpvcve_hip.so $AB/lib_cur.so
@@ -9,7 +9,7 @@ for rep in 1 2; do
 done
 python - <<'PY'
 import json
-for l in open('gpurun_out/r06n/ab_bench.txt'):
+for l in open('gpurun_out/r06o/ab_bench.txt'):
     if l.startswith('==='): print(l.strip())
     elif l.startswith('{'):
         d=json.loads(l); r=d['roofline']
