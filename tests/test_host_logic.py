@@ -487,6 +487,12 @@ def test_roofline_traffic_counts_exactly_the_block_conv_launches_of_the_committe
     assert abs(alg / 1e6 - 591.6) < 0.1 and abs(t / alg - 1.318) < 0.002
     assert bench._wino_flags('conv3x3_wino_kernel<false, true, false, true>') == (False, True, False, True)
     assert bench._wino_flags('conv3x3_wino_quad_kernel<false,true>') is None
+    # round 6's committed passes (front halves are conv3x3_wino_gated_kernel launches there): 677 MB = 1.14x -- the spill traffic is gone
+    with open(os.path.join(ROOT, 'profiles', 'r06_pmc.json')) as fh:
+        p6 = json.load(fh)
+    t6 = bench._launch_weighted_traffic(p6, 'conv3x3_wino_kernel', min_bytes=0.01 * 512 * 720 * 1280)
+    assert sum(v['launches'] for k, v in p6.items() if bench._wino_flags(k) and not bench._wino_flags(k)[2]) == 693
+    assert 1.10 < t6 / alg < 1.18 and bench.committed_pmc_traffic('')[1] >= 'profiles/r06_pmc.json'
     assert bench._wino_flags('conv3x3_wino_gated_kernel<true>') == (None, True, False, None)        # r06: one launch per gated front half
     assert abs(bench._launch_weighted_traffic({'conv3x3_wino_gated_kernel<false>': {'hbm_bytes_per_launch': 5e8, 'launches': 3},
                                                'conv3x3_wino_kernel<false,false,true,false>': {'hbm_bytes_per_launch': 9e8, 'launches': 1}},
