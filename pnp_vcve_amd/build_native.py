@@ -27,14 +27,16 @@ EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize'],
                #   spill slots in the residual kernels)
                'conv_wino.hip': None, 'conv_wino_ms.hip': None}
 _WINO = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops', '-mllvm', '-pragma-unroll-threshold=1000000']
-# conv_wino.hip (r06): the straight-line tile kernels keep all 64 accumulator quads in AGPRs only if the allocator does not park some of
-# them in arch VGPRs between uses: with LLVM's default local assignment order a tile's K loop holds ~100 v_accvgpr_read + ~70
-# v_accvgpr_write (each one a vector-ALU instruction in an MFMA gap, the reads behind an s_nop); -greedy-reverse-local-assignment leaves
-# ~30 reads and no write (tools/isa_chunks.py; block convs 333 -> 329 us).  The multi-source instantiation (conv_wino_ms.hip = the same
-# source, WINO_MS_TU) carries its accumulators around a run-time loop over the sources and LOSES with that flag (more spill slots,
-# 79.1 -> 77.3 frames/s when everything was built with it): hence two translation units.
+# conv_wino.hip (r06): the tile kernels keep all 64 accumulator quads in AGPRs only if the allocator does not park some of them in arch
+# VGPRs between uses: with LLVM's default local assignment order a tile's K loop holds ~100 v_accvgpr_read + ~70 v_accvgpr_write (each
+# one a vector-ALU instruction in an MFMA gap, the reads behind an s_nop); -greedy-reverse-local-assignment leaves ~30 reads and no
+# write (tools/isa_chunks.py; block convs 333 -> 329 us).  The multi-source instantiation (conv_wino_ms.hip = the same source,
+# WINO_MS_TU; a run-time loop over the sources with the accumulators carried around it) is its own translation unit because it LOST
+# with that flag while its ring / halo still went through registers (316 B of scratch; 79.1 -> 77.3 frames/s when everything was built
+# with it).  Since the LDS-DMA ring (28 staging registers gone) the flag is right for it too: 228 + 228 accumulator moves per source
+# segment -> 0, 20 B of scratch.  The unit stays separate: its flags have diverged once.
 EXTRA_FLAGS['conv_wino.hip'] = _WINO + ['-mllvm', '-greedy-reverse-local-assignment']
-EXTRA_FLAGS['conv_wino_ms.hip'] = list(_WINO)
+EXTRA_FLAGS['conv_wino_ms.hip'] = _WINO + ['-mllvm', '-greedy-reverse-local-assignment']
 # sources a translation unit #includes (beyond the headers)
 INCLUDES = {'conv_wino_ms.hip': ['conv_wino.hip']}
 
