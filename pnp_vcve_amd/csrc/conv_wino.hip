@@ -74,6 +74,9 @@ constexpr unsigned OOBW = 0xFFFFFFF0u;
 #endif                    // the epilogue instead of in the tile's last three chunks (48 registers do not live across it).  1 = every single-source
                           // kernel: 86.1 -> 72.8 frames/s (r06; r05 found the same: the allocator answers with 144-264 B of scratch); 2 = the branch
                           // kernels only (default: 120 -> 56 B of scratch there, front half 414 -> 407 us); 0 = nowhere
+#ifndef WINO_LUMP
+#define WINO_LUMP 1       // A/B switch (non-branch kernels): the 8 float4 sums of a chunk's input transform in this many MFMA gaps.  8 = one sum per gap
+#endif                    // (round 5: lumped, the residual kernel spilled); r06, registers to spare: 8 / 4 / 2 / 1 gaps = 88.2 / 88.8 / 88.9 / 89.2 frames/s
 #ifndef WINO_RING_DMA
 #define WINO_RING_DMA 1   // A/B switch (plain / residual / fold-only kernels): the weight chunks arrive in the ring as LDS-DMA loads too -- no staging
 #endif                    // registers (16), no ring write, ONE counted wait per chunk placed a chunk and a half behind the request
@@ -718,15 +721,18 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                             if (PG == 1 && g < 24) d1[c] = patch(SN{}, 1, c);
                             if (PG == 2 && g < 24) d3[c] = patch(SN{}, 3, c);
                         }
-                        if (XF && g >= 36 && g < 40) {           // first the row combination ...
-                            const int c = g - 36;
-                            tt[c] = WINO_JIT_ROWS ? (TR == 1 ? add4(da[c], db[c]) : sub4(da[c], db[c]))
-                                                  : TR == 0 ? sub4(d0[c], d2[c]) : (TR == 1 ? add4(d1[c], d2[c]) : (TR == 2 ? sub4(d2[c], d1[c]) : sub4(d1[c], d3[c])));
-                        }
-                        if (XF && g >= 40 && g < 44) {           // ... then the column combination
-                            const int c = g - 40;
-                            V[4 * TR + c] = c == 0 ? sub4(tt[0], tt[2]) : (c == 1 ? add4(tt[1], tt[2]) : (c == 2 ? sub4(tt[2], tt[1]) : sub4(tt[1], tt[3])));
-                        }
+                        // first the row combination, then the column combination: WINO_LUMP gaps in all (a gap that holds any vector-ALU
+                        // instruction costs ~9 cycles of matrix time before the 4 per instruction: 8 gaps 200 cycles per chunk, 2 gaps 146)
+                        constexpr int LPG = 8 / WINO_LUMP;       // float4 sums per gap
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (XF && g == 36 + c / LPG)
+                                tt[c] = WINO_JIT_ROWS ? (TR == 1 ? add4(da[c], db[c]) : sub4(da[c], db[c]))
+                                                      : TR == 0 ? sub4(d0[c], d2[c]) : (TR == 1 ? add4(d1[c], d2[c]) : (TR == 2 ? sub4(d2[c], d1[c]) : sub4(d1[c], d3[c])));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (XF && g == 36 + (4 + c) / LPG)
+                                V[4 * TR + c] = c == 0 ? sub4(tt[0], tt[2]) : (c == 1 ? add4(tt[1], tt[2]) : (c == 2 ? sub4(tt[2], tt[1]) : sub4(tt[1], tt[3])));
                     }
                     if constexpr (FO) {
                         // the plane's 1x1 fragments of this step: requested in position row 0, parked (N tiles 0-2) / kept (3) in row 1
