@@ -147,3 +147,45 @@ def test_winograd_multi_source_unit_is_its_own_translation_unit(tmp_path):
     seg = lines[mf[64]:mf[-1]]                      # behind the 64 MFMAs of the frame's RGB chunks: one source's 16 chunks
     assert sum(1 for l in seg if 'scratch_' in l) <= 2, sum(1 for l in seg if 'scratch_' in l)
     assert sum(1 for l in seg if 'v_accvgpr_' in l) <= 32, sum(1 for l in seg if 'v_accvgpr_' in l)
+
+
+def test_winograd_lds_dma_loads_have_landed_before_the_barrier_that_publishes_them(tmp_path):
+    """The tile kernels' weight ring and halo slabs arrive as LDS-DMA loads (`buffer_load_dwordx4 ... lds`: no destination register, so no
+    compiler-made wait ever covers them) and are published to the other waves by the chunk barriers.  The pipeline's contract
+    (conv_wino.hip, the counted `s_waitcnt vmcnt(N)` at the end of every chunk): a DMA load issued in chunk c has landed before the
+    barrier at the top of chunk c + 2 -- the ring chunk requested in chunk c is first read behind that barrier.  vmcnt retires in order,
+    so `vmcnt(N)` completes everything but the last N vector-memory instructions issued.  Checked on the compiler's own output by
+    replaying the instruction stream of one tile's K loop for the plain, the residual and the multi-source kernel and for the fold-only
+    body inside the gated kernel: at every barrier, every LDS-DMA load issued before the PREVIOUS barrier must be complete."""
+    vm = re.compile(r'^\s+(buffer_(load|store|atomic)|global_(load|store)|scratch_(load|store))')
+    checked = 0
+    for src, pat in (('conv_wino.hip', r'conv3x3_wino_kernelILb0ELb0ELb0ELb0E'), ('conv_wino.hip', r'conv3x3_wino_kernelILb0ELb1ELb0ELb0E'),
+                     ('conv_wino.hip', r'conv3x3_wino_gated_kernelILb0E'), ('conv_wino_ms.hip', r'conv3x3_wino_kernelILb0ELb0ELb1ELb0E')):
+        text = _wino_asm(tmp_path, src)
+        fn = [f for f in re.split(r'\n(?=_Z\w+:\s)', text) if re.search(pat, f.split('\n')[0])][0]
+        lines = fn.split('\n')
+        mf = [i for i, l in enumerate(lines) if 'v_mfma_f32_16x16x4_f32' in l]
+        first = 64 if 'Lb1ELb0EEEv' in lines[0] and 'kernelILb0ELb0ELb1' in lines[0] else 0       # (multi-source: behind the RGB chunks)
+        loop = lines[mf[first]:mf[first + 1023]]
+        issued = 0                       # vector-memory instructions issued so far
+        done = 0                         # ... of which known complete (in-order retirement)
+        dma = []                         # issue indices of LDS-DMA loads
+        barriers = []                    # value of `issued` at each barrier
+        ndma = 0
+        for l in loop:
+            if vm.match(l):
+                issued += 1
+                if l.rstrip().endswith(' lds'):
+                    dma.append(issued)
+                    ndma += 1
+            m = re.search(r's_waitcnt.*vmcnt\((\d+)\)', l)
+            if m:
+                done = max(done, issued - int(m.group(1)))
+            if 's_barrier' in l:
+                if len(barriers) >= 1:
+                    must = [d for d in dma if d <= barriers[-1]]             # issued before the previous barrier
+                    assert all(d <= done for d in must), (lines[0][:80], len(barriers), done, must[-1])
+                barriers.append(issued)
+        assert len(barriers) >= 15 and ndma >= 16 * 4, (lines[0][:80], len(barriers), ndma)    # 16 chunks, 4 ring pieces each (+ halo pieces)
+        checked += 1
+    assert checked == 4
