@@ -366,6 +366,14 @@ def test_wino_op_refuses_what_it_cannot_do():
         ops.conv3x3_wino(torch.zeros(32, 32, 4, device=dev()), u)
     with pytest.raises(RuntimeError):
         ops.conv3x3_wino(x, u, wino_w1x1=torch.zeros(12288, device=dev()))      # branches without a partition map: PNP_ERR_BAD_ARG
+    # residual bodies of the tile kernels carry no activation (the reference adds the residual to a bare conv, sr_backbone_utils.py:313,329):
+    # refused there (PNP_ERR_UNSUPPORTED), computed by the unit kernels -- act(conv) + residual
+    r = torch.randn(32, 32, 64, device=dev())
+    uu = ops.wino_image(ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev()) * 0.05))
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_wino(x + 1.0, uu, residual=r, act=1)
+    y = ops.conv3x3_wino(x + 1.0, uu, residual=r, act=1, units=True)
+    assert torch.equal(y, torch.relu(ops.conv3x3_wino(x + 1.0, uu, units=True)) + r)
     # the op's gamma scales only the bias; the conv term's gain is whatever wino_image() folded into the image: they must agree
     g = torch.rand(64, device=dev())
     pw = ops.pack_conv3x3(torch.randn(64, 64, 3, 3, device=dev()))
