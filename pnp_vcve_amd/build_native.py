@@ -1,25 +1,30 @@
-"""Builds libpnpvcve_hip.so (gfx950) in-tree with hipcc.  No torch involved."""
+"""Builds libpnpvcve_hip.so (gfx950) in-tree with hipcc.  No torch involved.
+
+Every translation unit goes device code -> assembly listing -> isa_hazards.patch_listing -> assembler -> code object -> bundle, and the
+host pass embeds that bundle (the steps `hipcc -c` runs itself, with one edit of the listing in between): gfx950 needs a wait state
+between a 16-byte store and a vector-ALU write of its data registers that LLVM does not insert for the store form the Winograd
+epilogue uses, and a source-level fence costs that kernel its register allocation (isa_hazards.py)."""
 import os
 import subprocess
 import sys
+
+from . import isa_hazards
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libpnpvcve_hip.so')
 SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_wino.hip', 'conv_wino_ms.hip', 'conv_f16.hip', 'conv_f16x3.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
-# per-source extras.  dcn.hip: hipcc's SLP vectoriser packs the scalar coordinate / weight arithmetic of the deformable gather into
-# v_pk_*_f32 pairs; every build with that packing gave wrong, run-to-run varying samples in the fp16 instantiation under some
-# timing (the round-2 code shape rarely, others always), every build without it is correct under every perturbation tried
-# (tools/repro/dcn_f16_hazard.py, profiles/r03_dcn_hazard_report.txt).
+# per-source extras.  Rounds 3-5 met one signature three times -- wrong values in fixed (lane, register) slots whenever hipcc packed fp32
+# arithmetic into v_pk_*_f32 (dcn.hip r03, conv_f16x3.hip r04, conv_wino.hip r05; tools/repro/*_hazard.py, profiles/r0[345]_*hazard*)
+# -- and fenced it off per file with the flags below.  Round 6 found the cause: a 16-byte store followed at once by a vector-ALU write
+# of its data registers (isa_hazards.py; a packed op writes two of them per instruction and hits the window ten times as often).  The
+# build now pads that in every unit's listing, and the all-packed Winograd build passes every test -- but runs 20 % slower (the
+# allocator spills in the tile loop), so the flags stay as they are: measured-good code shapes, no longer fences.
 EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize'],
-               # conv_f16x3.hip (r04): an intermediate build of the general partition re-split (float-vector code inside a cut-up chunk)
-               # showed the same signature; the committed structure is bit-stable with or without the flag
-               # (tools/repro/f16x3_resplit_hazard.py) -- kept as the conservative form, scalar code + this flag
                'conv_f16x3.hip': ['-fno-slp-vectorize'],
-               # conv_wino.hip (r05): the same signature a third time -- with v_pk_{add,mul}_f32 in the epilogue / the input transform, a few
-               # fixed (lane, register) slots of the output came out wrong, deterministically, and moved when unrelated code moved
-               # (tools/repro/wino_packed_f32_hazard.py; profiles/r05_wino_packed_f32_hazard.txt).  The kernel is built without packed fp32 VALU ops at all
+               # conv_wino.hip: built without packed fp32 VALU ops (profiles/r06_wino_ab.txt: 89.3 frames/s; all packed 71.7; packed sums
+               # only: +0.6 % with every product written element by element -- not taken)
                #   -pragma-unroll-threshold: the K loop of a tile is ~1200 MFMAs unrolled from `#pragma unroll` loops; past LLVM's default
                #   limit of 16384 (estimated) instructions a loop silently stays rolled, the accumulator array gets indexed dynamically
                #   and lands in scratch MEMORY (private_segment 1616 B, results right, ten times slower).  That is what "source orders
@@ -48,6 +53,44 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > mt for d in deps)
 
 
+def _run(cmd, verbose):
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def compile_unit(src, obj, flags, verbose=False, hipcc=None):
+    """src (.hip) -> obj: the device listing is padded against the store hazard before it is assembled; -> number of stores padded"""
+    hipcc = hipcc or os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    llvm = isa_hazards.LLVM
+    stem = obj[:-2] if obj.endswith('.o') else obj
+    lst, dev_o, dev_co, fb = stem + '.gfx950.s', stem + '.gfx950.o', stem + '.gfx950.co', stem + '.hipfb'
+    _run([hipcc] + flags + ['-Wno-unused-command-line-argument', '--cuda-device-only', '-S', '-o', lst, src], verbose)
+    with open(lst) as f:
+        text, padded = isa_hazards.patch_listing(f.read())
+    with open(lst, 'w') as f:
+        f.write(text)
+    if verbose and padded:
+        print(f'   {os.path.basename(src)}: s_nop behind {padded} store(s) whose data registers the next instruction writes', flush=True)
+    _run([f'{llvm}/clang', '-cc1as', '-triple', 'amdgcn-amd-amdhsa', '-filetype', 'obj', '-target-cpu', 'gfx950', '-mrelocation-model', 'pic',
+          '-o', dev_o, lst], verbose)
+    _run([f'{llvm}/lld', '-flavor', 'gnu', '-m', 'elf64_amdgpu', '--no-undefined', '-shared', '-o', dev_co, dev_o], verbose)
+    _run([f'{llvm}/clang-offload-bundler', '-type=o', '-bundle-align=4096', '-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950',
+          '-input=/dev/null', f'-input={dev_co}', f'-output={fb}'], verbose)
+    host, skip = [], 0
+    for i, f in enumerate(flags):                                  # (device-only target features mean nothing to the host pass)
+        if skip:
+            skip -= 1
+        elif f == '-Xclang' and flags[i + 1:i + 2] == ['-target-feature']:
+            skip = 3
+        else:
+            host.append(f)
+    _run([hipcc] + host + ['-Wno-unused-command-line-argument', '--cuda-host-only', '-Xclang', '-fcuda-include-gpubinary', '-Xclang', fb, '-c', src, '-o', obj], verbose)
+    for tmp in (lst, dev_o, dev_co, fb):
+        os.remove(tmp)
+    return padded
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -60,18 +103,34 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _stale(o, [s, os.path.abspath(__file__)] + headers + [os.path.join(CSRC, i) for i in INCLUDES.get(src, [])]):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+        deps = [s, os.path.abspath(__file__), os.path.join(HERE, 'isa_hazards.py')] + headers + [os.path.join(CSRC, i) for i in INCLUDES.get(src, [])]
+        if force or _stale(o, deps):
+            compile_unit(s, o, FLAGS + EXTRA_FLAGS.get(src, []), verbose, hipcc)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        _run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, verbose)
     return LIB
 
 
+def build_variant(name, extra, verbose=False):
+    """lib/ab/lib_<name>.so: the current library with conv_wino.hip and conv_wino_ms.hip recompiled with `extra` flags added
+    (tools/build_wino_variants.sh; run in turn with tools/try_libs.sh)"""
+    build(verbose=False)
+    ab = os.path.join(HERE, 'lib', 'ab')
+    os.makedirs(ab, exist_ok=True)
+    objdir = os.path.join(HERE, 'lib', 'obj')
+    objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES if not s.startswith('conv_wino')]
+    for src in ('conv_wino.hip', 'conv_wino_ms.hip'):
+        o = os.path.join(ab, src.replace('.hip', f'_{name}.o'))
+        compile_unit(os.path.join(CSRC, src), o, [f for f in FLAGS if f != '-Wall'] + ['-w'] + EXTRA_FLAGS[src] + extra, verbose)
+        objs.append(o)
+    out = os.path.join(ab, f'lib_{name}.so')
+    _run([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, verbose)
+    return out
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--variant' in sys.argv:
+        i = sys.argv.index('--variant')
+        print('built', build_variant(sys.argv[i + 1], sys.argv[i + 2].split(), verbose='-v' in sys.argv))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True))
