@@ -15,12 +15,13 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'lib', 'libpnpvcve_hip.so')
 SOURCES = ['conv_mfma.hip', 'conv_persist.hip', 'conv_wino.hip', 'conv_wino_ms.hip', 'conv_f16.hip', 'conv_f16x3.hip', 'conv_last.hip', 'warp.hip', 'prep.hip', 'metrics.hip', 'raster.hip', 'dcn.hip', 'generator.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
-# per-source extras.  Rounds 3-5 met one signature three times -- wrong values in fixed (lane, register) slots whenever hipcc packed fp32
-# arithmetic into v_pk_*_f32 (dcn.hip r03, conv_f16x3.hip r04, conv_wino.hip r05; tools/repro/*_hazard.py, profiles/r0[345]_*hazard*)
-# -- and fenced it off per file with the flags below.  Round 6 found the cause: a 16-byte store followed at once by a vector-ALU write
-# of its data registers (isa_hazards.py; a packed op writes two of them per instruction and hits the window ten times as often).  The
-# build now pads that in every unit's listing, and the all-packed Winograd build passes every test -- but runs 20 % slower (the
-# allocator spills in the tile loop), so the flags stay as they are: measured-good code shapes, no longer fences.
+# per-source extras.  Rounds 3-5 met a signature three times -- wrong values whenever hipcc packed fp32 arithmetic into v_pk_*_f32
+# (dcn.hip r03, conv_f16x3.hip r04, conv_wino.hip r05; tools/repro/*_hazard.py, profiles/r0[345]_*hazard*) -- and fenced it off per
+# file with the flags below.  Round 6 found the cause of the Winograd case: a 16-byte store followed at once by a vector-ALU write of
+# its data registers (isa_hazards.py; a packed op writes two of them per instruction and hits the window ten times as often).  The
+# build pads that in every unit's listing, and the all-packed Winograd build passes every test -- but runs 20 % slower (the allocator
+# spills in the tile loop), so its flag stays as a measured-good code shape.  dcn.hip and conv_f16x3.hip have no such site in their
+# listings with or without SLP packing: their failures are NOT explained by it and -fno-slp-vectorize stays a fence there.
 EXTRA_FLAGS = {'dcn.hip': ['-fno-slp-vectorize'],
                'conv_f16x3.hip': ['-fno-slp-vectorize'],
                # conv_wino.hip: built without packed fp32 VALU ops (profiles/r06_wino_ab.txt: 89.3 frames/s; all packed 71.7; packed sums

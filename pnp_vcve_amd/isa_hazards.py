@@ -5,14 +5,16 @@
                                                                         data registers
 
 On MI355X the store then writes the NEW value in lanes 12-15 of every row of 16 (tools/repro/store_x4_then_wide_valu.hip,
-profiles/r06_store_x4_hazard_probe.txt: 2 % of the stores behind a 32-bit VALU op, 23 % behind a packed one; LDS stores are not
-affected).  LLVM's hazard recogniser knows the rule -- 2 wait states on gfx940+ -- but exempts MUBUF stores whose soffset operand is
+profiles/r06_store_x4_hazard_probe.txt: 2 % of the stores behind a 32-bit VALU op, 23 % behind a packed one; buffer, global and
+scratch stores alike; stores of 64 bits or less and LDS stores are not affected).  LLVM's hazard recogniser knows the rule -- 2 wait states on gfx940+ -- but exempts MUBUF stores whose soffset operand is
 an SGPR (GCNHazardRecognizer::createsVALUHazard), the form the Winograd tile kernels' epilogue uses (tile offset in the scalar
 operand, so that a lane's offset can be the out-of-range marker).  One wait state is enough for that form.  This was the root cause
-of the "packed fp32" wrong values of rounds 3-5: a packed op writes two data registers at once and hits the window ten times as often,
-but a scalar build is exposed just the same whenever the scheduler puts the producer of the next N tile's element right behind the
-store -- round 6's verified build had 12 such sites (all tests green, 420 soak forwards bit-identical: with one wave per SIMD the
-timing happened to be benign).
+of the "packed fp32" wrong values of round 5's Winograd kernel (profiles/r06_wino_pk_add_probe.txt): a packed op writes two data
+registers at once and hits the window ten times as often, but a scalar build is exposed just the same whenever the scheduler puts the
+producer of the next N tile's element right behind the store -- round 6's verified build had 12 such sites (all tests green, 420 soak
+forwards bit-identical: with one wave per SIMD the timing happened to be benign).  NOT explained by it: the similar-looking failures
+of dcn.hip's fp16 instantiation (r03) and of an intermediate conv_f16x3.hip (r04) with SLP-packed arithmetic -- their listings hold no
+such site with or without the packing, so their -fno-slp-vectorize stays a fence.
 
 A source-level fence (an s_nop statement, or a store form LLVM does pad) moves the register allocation of the 1200-MFMA tile loop off
 its optimum (36 -> 400 B of scratch, 88 -> 73 frames/s), so the fix is applied where it costs nothing: build_native.py compiles

@@ -80,8 +80,8 @@ def _tile_loop(fn, tail_mfmas):
 
 def test_winograd_kernel_is_built_without_packed_fp32_valu_ops(tmp_path):
     """Both Winograd translation units are compiled with the packed-fp32 target feature off.  Through round 5 that was a fence: builds
-    with v_pk_{add,mul}_f32 gave wrong values in fixed (lane, register) slots (profiles/r05_wino_packed_f32_hazard.txt; DCN r03,
-    split-fp16 r04).  Round 6 found the cause -- a 16-byte store followed at once by a write of its data registers, which a packed op
+    with v_pk_{add,mul}_f32 gave wrong values in fixed (lane, register) slots (profiles/r05_wino_packed_f32_hazard.txt).  Round 6 found
+    the cause -- a 16-byte store followed at once by a write of its data registers, which a packed op
     hits ten times as often (pnp_vcve_amd/isa_hazards.py; padded in the build, checked below) -- and with it padded the all-packed
     build is correct but 20 % slower (the allocator spills in the tile loop: 71.7 vs 89.3 frames/s, profiles/r06_wino_ab.txt), so the
     flag stays, as a performance choice.  Also bounded here, on the compiler's own output: the spill slots of every instantiation and

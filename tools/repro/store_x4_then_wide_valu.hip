@@ -1,7 +1,7 @@
 // Does a 16-byte vector-memory store still read its data registers when the NEXT vector-ALU instruction overwrites them?
 //
-// Round 6 found the wrong values of the packed-fp32 builds (profiles/r03_dcn_hazard_report.txt, r04_f16x3_resplit_hazard_report.txt,
-// r05_wino_packed_f32_hazard.txt, r06_wino_pk_add_probe.txt) in one place of the Winograd epilogue's code object:
+// Round 6 found the wrong values of the packed-fp32 Winograd builds (profiles/r05_wino_packed_f32_hazard.txt,
+// r06_wino_pk_add_probe.txt) in one place of the Winograd epilogue's code object:
 //       buffer_store_dwordx4 v[34:37], v55, s[24:27], s8 offen
 //       v_pk_add_f32 v[34:35], v[230:231], v[198:199]          <- the next tile's output transform, into the store's data registers
 // and the wrong output values are exactly the HIGH half of the overwritten pair (element 1 of the float4), in lanes 12-15 of each row
@@ -155,6 +155,61 @@ ALLW_DS(ds_mov64_23, ST_DS128, C_MOV64_23)
 ALLW_DS(d2_pk23, ST_DS64X2, C_PK23)
 ALLW_DS(d2_s3, ST_DS64X2, C_S3)
 
+// ... and for stores to scratch (what a register spill is): scratch_store_dword / x2 / x4 of v[100:103] to the lane's private
+// memory, the overwriting instruction, then the value read back
+#define ST_SCR1 "scratch_store_dword %[pa], v100, off\n\t"
+#define ST_SCR2 "scratch_store_dwordx2 %[pa], v[100:101], off\n\t"
+#define ST_SCR4 "scratch_store_dwordx4 %[pa], v[100:103], off\n\t"
+#define PROBE_SCR(NAME, STORE, WAIT, CLOB)                                                                                       \
+    __global__ __launch_bounds__(256, 1) void NAME(unsigned* buf, unsigned long long bytes, int iters) {                          \
+        volatile unsigned priv[8];                                                                                                \
+        priv[threadIdx.x & 7] = 0;                                                                                                \
+        const unsigned gt = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;                                               \
+        const unsigned long long pa64 = (unsigned long long)buf;                                                                  \
+        i32x4 rs = {(int)(unsigned)pa64, (int)(unsigned)(pa64 >> 32), (int)(unsigned)bytes, 0x00020000};                          \
+        rs[0] = __builtin_amdgcn_readfirstlane(rs[0]);                                                                            \
+        rs[1] = __builtin_amdgcn_readfirstlane(rs[1]);                                                                            \
+        rs[2] = __builtin_amdgcn_readfirstlane(rs[2]);                                                                            \
+        rs[3] = __builtin_amdgcn_readfirstlane(rs[3]);                                                                            \
+        const unsigned pa = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(5))) char*)(&priv[0]);                      \
+        for (int it = 0; it < iters; ++it) {                                                                                      \
+            const unsigned slot = (unsigned)it * nthr + gt, off = slot * 16u;                                                     \
+            const unsigned d0 = slot * 4u + 0x10000000u, d1 = d0 + 1u, d2 = d0 + 2u, d3 = d0 + 3u, poison = 0x7fc0deadu;          \
+            asm volatile("v_mov_b32 v100, %[d0]\n\tv_mov_b32 v101, %[d1]\n\tv_mov_b32 v102, %[d2]\n\tv_mov_b32 v103, %[d3]\n\t"    \
+                         "v_mov_b32 v104, %[po]\n\tv_mov_b32 v105, %[po]\n\tv_mov_b32 v106, 0\n\tv_mov_b32 v107, 0\n\t"            \
+                         "v_mov_b32 v108, %[d0]\n\tv_mov_b32 v109, %[d1]\n\tv_mov_b32 v110, %[d2]\n\tv_mov_b32 v111, %[d3]\n\t"    \
+                         "v_accvgpr_write_b32 a0, %[po]\n\ts_nop 15\n\t" STORE WAIT CLOB "s_nop 15\n\ts_waitcnt vmcnt(0)\n\t"      \
+                         "scratch_load_dwordx4 v[108:111], %[pa], off\n\ts_waitcnt vmcnt(0)\n\t"                                  \
+                         "buffer_store_dwordx4 v[108:111], %[v], %[r], 0 offen\n\ts_nop 15\n\t"                                   \
+                         :                                                                                                        \
+                         : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [po] "v"(poison), [v] "v"(off), [r] "s"(rs),     \
+                           [pa] "v"(pa)                                                                                            \
+                         : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "a0",  \
+                           "memory");                                                                                             \
+        }                                                                                                                         \
+        if (priv[3] == 0x12345u) buf[0] = 1;                                                                                      \
+    }
+#define ALLW_SCR(BASE, STORE, CLOB)            \
+    PROBE_SCR(BASE##_w0, STORE, W0, CLOB)      \
+    PROBE_SCR(BASE##_w1, STORE, W1, CLOB)      \
+    PROBE_SCR(BASE##_w2, STORE, W2, CLOB)      \
+    PROBE_SCR(BASE##_w3, STORE, W3, CLOB)
+ALLW_SCR(sc1_s0, ST_SCR1, C_S0)
+ALLW_SCR(sc1_pk01, ST_SCR1, C_PK01)
+ALLW_SCR(sc2_s0, ST_SCR2, C_S0)
+ALLW_SCR(sc2_s1, ST_SCR2, C_S1)
+ALLW_SCR(sc2_pk01, ST_SCR2, C_PK01)
+ALLW_SCR(sc2_mov64, ST_SCR2, C_MOV64_01)
+ALLW_SCR(sc4_pk23, ST_SCR4, C_PK23)
+ALLW_SCR(sc4_s3, ST_SCR4, C_S3)
+// 8-byte and 4-byte global / buffer stores behind a packed op (LLVM pads nothing at or below 64 bits)
+#define ST_BUF1_S "buffer_store_dword v100, %[v], %[r], %[s] offen\n\t"
+#define ST_GLB2 "global_store_dwordx2 %[p], v[100:101], off\n\t"
+ALLW(b1_s0, BUSY0, ST_BUF1_S, C_S0)
+ALLW(b1_pk01, BUSY0, ST_BUF1_S, C_PK01)
+ALLW(g2_pk01, BUSY0, ST_GLB2, C_PK01)
+ALLW(q2_pk01, BUSY4, ST_BUF2_S, C_PK01)
+
 typedef void (*kern_t)(unsigned*, unsigned long long, int);
 struct Case { const char* name; const char* what; int elems; kern_t k[4]; };
 #define CASE(BASE, WHAT, ELEMS) {#BASE, WHAT, ELEMS, {BASE##_w0, BASE##_w1, BASE##_w2, BASE##_w3}}
@@ -197,6 +252,18 @@ int main() {
         CASE(qs_s3210, "4 stores queued ; buffer_store_dwordx4 (SGPR soffset) ; v_mov_b32 v103..v100", 4),
         CASE(q0_pk01, "4 stores queued ; buffer_store_dwordx4 (soffset 0) ; v_pk_add_f32 v[100:101]", 4),
         CASE(q0_s3, "4 stores queued ; buffer_store_dwordx4 (soffset 0) ; v_mov_b32 v103", 4),
+        CASE(b1_s0, "buffer_store_dword (SGPR soffset) ; v_mov_b32 v100", 1),
+        CASE(b1_pk01, "buffer_store_dword (SGPR soffset) ; v_pk_add_f32 v[100:101]", 1),
+        CASE(g2_pk01, "global_store_dwordx2 ; v_pk_add_f32 v[100:101]", 2),
+        CASE(q2_pk01, "4 stores queued ; buffer_store_dwordx2 (SGPR soffset) ; v_pk_add_f32 v[100:101]", 2),
+        CASE(sc1_s0, "scratch_store_dword ; v_mov_b32 v100   (value read back from scratch)", 1),
+        CASE(sc1_pk01, "scratch_store_dword ; v_pk_add_f32 v[100:101]", 1),
+        CASE(sc2_s0, "scratch_store_dwordx2 ; v_mov_b32 v100", 2),
+        CASE(sc2_s1, "scratch_store_dwordx2 ; v_mov_b32 v101", 2),
+        CASE(sc2_pk01, "scratch_store_dwordx2 ; v_pk_add_f32 v[100:101]", 2),
+        CASE(sc2_mov64, "scratch_store_dwordx2 ; v_mov_b64 v[100:101]", 2),
+        CASE(sc4_pk23, "scratch_store_dwordx4 ; v_pk_add_f32 v[102:103]", 4),
+        CASE(sc4_s3, "scratch_store_dwordx4 ; v_mov_b32 v103", 4),
         CASE(ds_pk01, "ds_write_b128 ; v_pk_add_f32 v[100:101]   (value read back from LDS)", 4),
         CASE(ds_pk23, "ds_write_b128 ; v_pk_add_f32 v[102:103]", 4),
         CASE(ds_s0, "ds_write_b128 ; v_mov_b32 v100", 4),
