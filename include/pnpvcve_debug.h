@@ -30,6 +30,10 @@ int pnp_conv3x3_f32_ex(int nsrc, const float* const* srcs_dev, const int* src_ch
 int pnp_conv3x3_wino_f32_ex(const float* src_dev, const float* wino_w_dev, const float* bias_dev, const float* gamma_dev,
                             const float* wino_w1x1_dev, const float* par_dev, const int* par_flags_dev,
                             const float* residual_dev, int act, float* out_dev, int h, int w, void* trace_dev, void* stream);
+/* The frame's partition word (pnp_generator_forward computes it per frame: bit 3 = every 8x8 quadrant is all zero or one constant
+ * plane) for the NEXT pnp_conv3x3_wino_f32_ex calls with branches: they then take the one gated launch the generator uses (fold-only
+ * body when bit 3 is set).  A device int; NULL = back to the ungated branch kernel.  Process-wide, not thread-safe: a tracing hook. */
+int pnp_debug_wino_gate_word(const int* gate_word_dev);
 
 /* The fp16-operand conv of pnpvcve.h with an optional timeline buffer (16 u64 per 4-wave group). */
 int pnp_conv3x3_f16_ex(int nsrc, const float* const* srcs_dev, const int* src_channels,

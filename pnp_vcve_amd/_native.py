@@ -109,6 +109,7 @@ DEBUG_SIGNATURES['pnp_dcn_nhwc_f32_ex'] = (c_int, [c_void_p, c_void_p, c_void_p,
                                                    c_int, c_void_p, c_void_p])
 
 DEBUG_SIGNATURES['pnp_dcn_trace_u64s'] = (c_int, [])
+DEBUG_SIGNATURES['pnp_debug_wino_gate_word'] = (c_int, [c_void_p])
 DEBUG_SIGNATURES['pnp_conv3x3_wino_f32_ex'] = (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p])
 DEBUG_SIGNATURES['pnp_conv3x3_f16_maps'] = (c_int, [c_int, POINTER(c_void_p), POINTER(c_int), c_int, POINTER(c_void_p), c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,

@@ -1361,6 +1361,12 @@ int pnp_conv3x3_wino_units_f32(const float* src, const float* wino_w, const floa
                                    (void*)&pnp_conv3x3_wino_units_f32, st);
 }
 
+static const int* g_debug_wino_gate_word = nullptr;
+int pnp_debug_wino_gate_word(const int* gate_word_dev) {
+    g_debug_wino_gate_word = gate_word_dev;
+    return 0;
+}
+
 int pnp_conv3x3_wino_f32_ex(const float* src, const float* wino_w, const float* bias, const float* gamma, const float* wino_w1x1,
                             const float* par, const int* par_flags, const float* residual, int act, float* out, int h, int w,
                             void* trace, void* st) {
@@ -1376,6 +1382,7 @@ int pnp_conv3x3_wino_f32_ex(const float* src, const float* wino_w, const float* 
     a.wpar = wino_w1x1;              // "has branches"; the direct-form image itself is not read on this path
     a.par = wino_w1x1 ? par : nullptr;
     a.par_flags = wino_w1x1 ? par_flags : nullptr;
+    a.par_any = (wino_w1x1 && par_flags) ? g_debug_wino_gate_word : nullptr;
     a.par_plane = (long)h * w;
     a.bias = bias;
     a.gamma = gamma;

@@ -1,6 +1,7 @@
 """Per-tile cycle split of the Winograd conv (csrc/conv_wino.hip) from its timeline buffer: K loop vs epilogue, in-kernel clock,
 block lifetimes.    python tools/trace_wino.py [--h 720 --w 1280] [--kind back|hr|front|front_dense]"""
 import argparse
+import ctypes
 import os
 import sys
 
@@ -32,14 +33,29 @@ def main():
     pw, p1 = ops.pack_conv3x3(wt), ops.pack_conv1x1(w1)
     u, ug, up = ops.wino_image(pw), ops.wino_image(pw, gamma), ops.wino_par_image(p1)
     flags = ops.par_tile_flags(par)
+    from pnp_vcve_amd import _native
+    words = {v: torch.tensor([v], dtype=torch.int32, device=dev) for v in (0, 8)}
+
+    def gated(word, fn):
+        _native.lib().pnp_debug_wino_gate_word(ctypes.c_void_p(words[word].data_ptr()))
+        try:
+            return fn()
+        finally:
+            _native.lib().pnp_debug_wino_gate_word(None)
     kinds = {
         'hr': lambda tr: ops.conv3x3_wino(x, u, bias=b, act=2, trace=tr),
         'back': lambda tr: ops.conv3x3_wino(x, u, bias=b, residual=res, trace=tr),
         'front': lambda tr: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, par_flags=flags, act=1, trace=tr),
+        # the generator's one gated launch, fold-only body (every 8x8 block of `par` is one constant plane)
+        'front_fold': lambda tr: gated(8, lambda: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, par_flags=flags, act=1, trace=tr)),
+        'front_gated_branch': lambda tr: gated(0, lambda: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, par_flags=flags, act=1, trace=tr)),
         'front_dense': lambda tr: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par, act=1, trace=tr),
         # no partition record anywhere (an I frame): the branch chunks hold no MFMA -- what the PAR structure costs by itself
         'front_zero': lambda tr: ops.conv3x3_wino(x, ug, bias=b, gamma=gamma, wino_w1x1=up, par=par * 0, par_flags=flags, act=1, trace=tr),
     }
+    if args.kind == 'all':
+        tr0 = torch.zeros(256 * 16, dtype=torch.int64, device=dev)
+        print('front_fold == front (branch kernel), bit for bit:', bool(torch.equal(kinds['front_fold'](tr0), kinds['front'](tr0))), flush=True)
     for name, fn in kinds.items():
         if args.kind not in ('all', name):
             continue
