@@ -77,6 +77,9 @@ constexpr unsigned OOBW = 0xFFFFFFF0u;
 #ifndef WINO_LUMP
 #define WINO_LUMP 1       // A/B switch (non-branch kernels): the 8 float4 sums of a chunk's input transform in this many MFMA gaps.  8 = one sum per gap
 #endif                    // (round 5: lumped, the residual kernel spilled); r06, registers to spare: 8 / 4 / 2 / 1 gaps = 88.2 / 88.8 / 88.9 / 89.2 frames/s
+#ifndef WINO_QUAD_AHEAD
+#define WINO_QUAD_AHEAD 2   // A/B switch (conv3x3_wino_quad_kernel): B fragments requested this many steps ahead.  1 / 2 / 3 = 2076 / 2130 / 2040
+#endif                      // frames/s on 7x3x128x128 clips (3: the fourth fragment set lives in AGPRs, moved back and forth)
 #ifndef WINO_RING_DMA
 #define WINO_RING_DMA 1   // A/B switch (plain / residual / fold-only kernels): the weight chunks arrive in the ring as LDS-DMA loads too -- no staging
 #endif                    // registers (16), no ring write, ONE counted wait per chunk placed a chunk and a half behind the request
@@ -1268,12 +1271,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
     }
     const int tyq = m >> 2, txq = m & 3;
     const unsigned wq16 = (unsigned)lane * 16u + (unsigned)wave * 1024u;
-    f32x4 Bq[2][16], Bp[2][3];
+    // B fragments of step s4 live in set s4 % QB, requested QA steps ahead (QA = 2: the first two steps' fragments are requested before
+    // the halo has landed)
+    constexpr int QA = WINO_QUAD_AHEAD, QB = QA + 1;
+    f32x4 Bq[QB][16], Bp[QB][3];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) Bq[0][p] = bload4(r_u, wq16, (unsigned)((p >> 2) * 16384 + (p & 3) * 4096));
-    if constexpr (PAR) {
+    for (int s0 = 0; s0 < QA; ++s0) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) Bp[0][j] = bload4(r_up, wq16, (unsigned)(j * 4096));
+        for (int p = 0; p < 16; ++p) Bq[s0][p] = bload4(r_u, wq16, (unsigned)((s0 * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
+        if constexpr (PAR) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Bp[s0][j] = bload4(r_up, wq16, (unsigned)(s0 * 12288 + j * 4096));
+        }
     }
     // partition values of the lane's tile, signed as the output transform wants them (positions (0,3), (3,0) negated), and the branches
     // the unit needs at all (a plane that is zero on all 64 pixels adds exact zeros)
@@ -1328,12 +1337,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
     lds_bar();
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-        if (s4 < 3) {
+        if (s4 + QA < 4) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) Bq[(s4 + 1) & 1][p] = bload4(r_u, wq16, (unsigned)(((s4 + 1) * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
+            for (int p = 0; p < 16; ++p) Bq[(s4 + QA) % QB][p] = bload4(r_u, wq16, (unsigned)(((s4 + QA) * 4 + (p >> 2)) * 16384 + (p & 3) * 4096));
             if constexpr (PAR) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) Bp[(s4 + 1) & 1][j] = bload4(r_up, wq16, (unsigned)((s4 + 1) * 12288 + j * 4096));
+                for (int j = 0; j < 3; ++j) Bp[(s4 + QA) % QB][j] = bload4(r_up, wq16, (unsigned)((s4 + QA) * 12288 + j * 4096));
             }
         }
         f32x4 dq[4][4], tq4[4];
@@ -1370,19 +1379,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4& ac = q == 0 ? acc[0] : (q == 1 ? acc[3] : (q == 2 ? acc[12] : acc[15]));
-                        ac = mfma16(ax[q][k], Bp[s4 & 1][J][k], ac);
+                        ac = mfma16(ax[q][k], Bp[s4 % QB][J][k], ac);
                     }
             };
             if (needq & 1) qbranch(I<0>{});
             if (needq & 2) qbranch(I<1>{});
             if (needq & 4) qbranch(I<2>{});
             if (foldq >= 0) {
-                const f32x4 wq = foldq == 0 ? Bp[s4 & 1][0] : (foldq == 1 ? Bp[s4 & 1][1] : Bp[s4 & 1][2]);
+                const f32x4 wq = foldq == 0 ? Bp[s4 % QB][0] : (foldq == 1 ? Bp[s4 % QB][1] : Bp[s4 % QB][2]);
                 const f32x4 cp = {foldcq, foldcq, foldcq, foldcq}, cm = {-foldcq, -foldcq, -foldcq, -foldcq};
-                Bq[s4 & 1][5] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][5]);
-                Bq[s4 & 1][6] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][6]);
-                Bq[s4 & 1][9] = __builtin_elementwise_fma(cm, wq, Bq[s4 & 1][9]);
-                Bq[s4 & 1][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 & 1][10]);
+                Bq[s4 % QB][5] = __builtin_elementwise_fma(cp, wq, Bq[s4 % QB][5]);
+                Bq[s4 % QB][6] = __builtin_elementwise_fma(cm, wq, Bq[s4 % QB][6]);
+                Bq[s4 % QB][9] = __builtin_elementwise_fma(cm, wq, Bq[s4 % QB][9]);
+                Bq[s4 % QB][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 % QB][10]);
             }
         }
 #pragma unroll
@@ -1394,7 +1403,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
                     const int p = pr * 4 + pc;
                     const bool fresh = s4 == 0 && k == 0 && !(PAR && (p == 0 || p == 3 || p == 12 || p == 15));
                     const f32x4 c0 = p == 5 ? f32x4{bgq, bgq, bgq, bgq} : f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc[p] = mfma16(V[p][k], Bq[s4 & 1][p][k], fresh ? c0 : acc[p]);
+                    acc[p] = mfma16(V[p][k], Bq[s4 % QB][p][k], fresh ? c0 : acc[p]);
                 }
     }
     f32x4 w0[4], w1[4], yq[4];
