@@ -1254,8 +1254,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
     const __amdgpu_buffer_rsrc_t r_out = rsrc_of(a.out, map_bytes);
     const __amdgpu_buffer_rsrc_t r_res = rsrc_of(RES ? a.residual : a.src, RES ? map_bytes : 0u);
     const float act_lo = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
+    const int tyq = m >> 2, txq = m & 3;
+    // Every request of the unit's prologue goes out before the first wait (a launch of these is one latency chain): halo, the lane's
+    // partition values, then (below) the B fragments of the first steps; the halo's LDS writes wait for the halo only (in-order vmcnt)
+    float praw[3][4];
+    f32x4 hv[7];
     {
-        f32x4 hv[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             const int e = t + 256 * i, pe = e >> 4, ry = pe / 10, rx = pe - ry * 10, gy = qy0 - 1 + ry, gx = qx0 - 1 + rx;
@@ -1263,13 +1267,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             if (e < 1600 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
                 hv[i] = *reinterpret_cast<const f32x4*>(a.src + ((long)gy * W + gx) * 64 + (e & 15) * 4);
         }
+        if constexpr (PAR) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int e = t + 256 * i;
-            if (e < 1600) *reinterpret_cast<f32x4*>(smem + (e >> 4) * QSTR + (e & 15) * 16) = hv[i];
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gy = min(qy0 + 2 * tyq + (q >> 1), H - 1), gx = min(qx0 + 2 * txq + (q & 1), W - 1);      // (clamped: see pv_request)
+                    praw[j][q] = a.par[(long)j * a.par_plane + (long)gy * W + gx];
+                }
         }
     }
-    const int tyq = m >> 2, txq = m & 3;
     const unsigned wq16 = (unsigned)lane * 16u + (unsigned)wave * 1024u;
     // B fragments of step s4 live in set s4 % QB, requested QA steps ahead (QA = 2: the first two steps' fragments are requested before
     // the halo has landed)
@@ -1284,6 +1291,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             for (int j = 0; j < 3; ++j) Bp[s0][j] = bload4(r_up, wq16, (unsigned)(s0 * 12288 + j * 4096));
         }
     }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int e = t + 256 * i;
+        if (e < 1600) *reinterpret_cast<f32x4*>(smem + (e >> 4) * QSTR + (e & 15) * 16) = hv[i];
+    }
     // partition values of the lane's tile, signed as the output transform wants them (positions (0,3), (3,0) negated), and the branches
     // the unit needs at all (a plane that is zero on all 64 pixels adds exact zeros)
     float pq[3][4];
@@ -1296,8 +1308,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             bool nz = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int gy = min(qy0 + 2 * tyq + (q >> 1), H - 1), gx = min(qx0 + 2 * txq + (q & 1), W - 1);      // (clamped: see pv_request)
-                const float v = a.par[(long)j * a.par_plane + (long)gy * W + gx];
+                const float v = praw[j][q];
                 nz = nz || v != 0.f;
                 pq[j][q] = (q == 1 || q == 2) ? -v : v;
             }
