@@ -88,6 +88,56 @@ ALLW(f16q_b0, f32x4, F1, 4.f, Q2_F32, M_16x16x4_F32, C_B0)
 ALLW(f32_a0, f32x16, F1, 2.f, Q0, M_32x32x2_F32, C_A0)
 ALLW(f32_b0, f32x16, F1, 2.f, Q0, M_32x32x2_F32, C_B0)
 
+// The shape found in the fp16 DCN kernel (round 6, tools/repro/dcn_f16_listing_bisect.py: an s_nop behind every MFMA makes that kernel
+// right): two MFMAs sharing SrcA, the second one waiting for its SrcB from LDS, then the next A fragment is converted INTO SrcA,
+// last register first.
+#define C_CVT4 "v_cvt_pk_f16_f32 v103, v116, v117\n\tv_cvt_pk_f16_f32 v102, v116, v117\n\tv_cvt_pk_f16_f32 v101, v116, v117\n\tv_cvt_pk_f16_f32 v100, v116, v117\n\t"
+#define C_CVT1 "v_cvt_pk_f16_f32 v103, v116, v117\n\t"
+#define PROBE_DCN(NAME, WAIT, CLOB, CHAIN)                                                                                       \
+    __global__ __launch_bounds__(256, 2) void NAME(unsigned* out, int iters) {                                                    \
+        __shared__ unsigned lds[4096];                                                                                            \
+        for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = H1;                                                                \
+        __syncthreads();                                                                                                          \
+        const unsigned la = (unsigned)(unsigned long long)(&lds[0]) + threadIdx.x * 16u;                                          \
+        unsigned bad = 0;                                                                                                         \
+        for (int it = 0; it < iters; ++it) {                                                                                      \
+            f32x16 d0, d1;                                                                                                        \
+            const unsigned one = H1, nan = 0x7fc00000u;                                                                           \
+            asm volatile(".irp r,100,101,102,103,104,105,106,107,108,109,110,111,112,113,114,115\n\tv_mov_b32 v\\r, %[one]\n\t.endr\n\t"  \
+                         "v_mov_b32 v116, %[nan]\n\tv_mov_b32 v117, %[nan]\n\t"                                                   \
+                         ".irp r,120,121,122,123,124,125,126,127,128,129,130,131,132,133,134,135,136,137,138,139,140,141,142,143,144,145,146,147,148,149,150,151\n\tv_mov_b32 v\\r, 0\n\t.endr\n\t" \
+                         "s_nop 15\n\t"                                                                                           \
+                         ".if " #CHAIN "\n\tv_mfma_f32_32x32x16_f16 v[120:135], v[112:115], v[112:115], v[120:135]\n\tv_mfma_f32_32x32x16_f16 v[136:151], v[112:115], v[112:115], v[136:151]\n\t.endif\n\t" \
+                         "ds_read_b128 v[104:107], %[la]\n\tds_read_b128 v[108:111], %[la] offset:4096\n\t"                        \
+                         "s_waitcnt lgkmcnt(1)\n\t"                                                                               \
+                         "v_mfma_f32_32x32x16_f16 v[120:135], v[100:103], v[104:107], v[120:135]\n\t"                             \
+                         "s_waitcnt lgkmcnt(0)\n\t"                                                                               \
+                         "v_mfma_f32_32x32x16_f16 v[136:151], v[100:103], v[108:111], v[136:151]\n\t" WAIT CLOB                    \
+                         "s_nop 15\n\ts_nop 15\n\t"                                                                               \
+                         ".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\t.endr\n\t"                                              \
+                         "v_mov_b32 %[a], v120\n\tv_mov_b32 %[b], v135\n\tv_mov_b32 %[c], v136\n\tv_mov_b32 %[e], v151\n\t"        \
+                         : [a] "=&v"(d0[0]), [b] "=&v"(d0[1]), [c] "=&v"(d1[0]), [e] "=&v"(d1[1])                                  \
+                         : [one] "v"(one), [nan] "v"(nan), [la] "v"(la)                                                           \
+                         : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+                           "v114", "v115", "v116", "v117", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", \
+                           "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", \
+                           "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "memory");                             \
+            const float want = CHAIN ? 32.f : 16.f;                                                                               \
+            bad += !(d0[0] == want && d0[1] == want && d1[0] == want && d1[1] == want);                                           \
+        }                                                                                                                         \
+        out[blockIdx.x * 256 + threadIdx.x] = bad;                                                                                \
+    }
+#define ALLW_DCN(BASE, CLOB, CHAIN)            \
+    PROBE_DCN(BASE##_w0, W0, CLOB, CHAIN)      \
+    PROBE_DCN(BASE##_w1, W1, CLOB, CHAIN)      \
+    PROBE_DCN(BASE##_w2, W2, CLOB, CHAIN)      \
+    PROBE_DCN(BASE##_w3, W3, CLOB, CHAIN)
+ALLW_DCN(dcn_cvt4, C_CVT4, 0)
+ALLW_DCN(dcn_cvt1, C_CVT1, 0)
+ALLW_DCN(dcn_mov3, C_A3, 0)
+ALLW_DCN(dcnq_cvt4, C_CVT4, 1)
+ALLW_DCN(dcnq_mov3, C_A3, 1)
+
 typedef void (*kern_t)(unsigned*, int);
 struct Case { const char* what; kern_t k[4]; };
 #define CASE(BASE, WHAT) {WHAT, {BASE##_w0, BASE##_w1, BASE##_w2, BASE##_w3}}
@@ -124,6 +174,11 @@ int main() {
         CASE(f16q_b0, "2 MFMAs queued ; v_mfma_f32_16x16x4_f32 ; v_mov_b32 v104"),
         CASE(f32_a0, "v_mfma_f32_32x32x2_f32 ; v_mov_b32 v100"),
         CASE(f32_b0, "v_mfma_f32_32x32x2_f32 ; v_mov_b32 v104"),
+        CASE(dcn_cvt4, "2 x 32x32x16_f16 sharing A, B from LDS (waitcnt) ; v_cvt_pk_f16_f32 v103, v102, v101, v100"),
+        CASE(dcn_cvt1, "2 x 32x32x16_f16 sharing A, B from LDS (waitcnt) ; v_cvt_pk_f16_f32 v103"),
+        CASE(dcn_mov3, "2 x 32x32x16_f16 sharing A, B from LDS (waitcnt) ; v_mov_b32 v103"),
+        CASE(dcnq_cvt4, "2 MFMAs queued into the same accumulators ; the same ; v_cvt_pk_f16_f32 v103 .. v100"),
+        CASE(dcnq_mov3, "2 MFMAs queued into the same accumulators ; the same ; v_mov_b32 v103"),
     };
     printf("%d threads x %d MFMAs per probe (two blocks of four waves per CU); wrong = lanes whose outputs are not all exactly K\n", blocks * 256, iters);
     printf("%-92s %12s %12s %12s %12s\n", "MFMA ; next vector-ALU instruction", "0 wait", "1 (s_nop 0)", "2 (s_nop 1)", "3 (s_nop 2)");
