@@ -80,6 +80,9 @@ constexpr unsigned OOBW = 0xFFFFFFF0u;
 #ifndef WINO_QUAD_AHEAD
 #define WINO_QUAD_AHEAD 2   // A/B switch (conv3x3_wino_quad_kernel): B fragments requested this many steps ahead.  1 / 2 / 3 = 2076 / 2130 / 2040
 #endif                      // frames/s on 7x3x128x128 clips (3: the fourth fragment set lives in AGPRs, moved back and forth)
+#ifndef WINO_PK_FOLD
+#define WINO_PK_FOLD 0     // A/B switch (tile bodies): the folded plane's FMAs on the B fragments as v_pk_fma_f32 (8 instead of 16 per gap):
+#endif                    // bit-identical, 88.55 -> 88.15 frames/s (r06: fewer VALU cycles, denser MFMA issue, lower clock -- DESIGN.md 3.1)
 #ifndef WINO_RING_DMA
 #define WINO_RING_DMA 1   // A/B switch (plain / residual / fold-only kernels): the weight chunks arrive in the ring as LDS-DMA loads too -- no staging
 #endif                    // registers (16), no ring write, ONE counted wait per chunk placed a chunk and a half behind the request
@@ -108,6 +111,17 @@ __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+// b + c * w as two v_pk_fma_f32 (the same fused multiply-add per element as __builtin_elementwise_fma: bit-identical).  The unit is
+// compiled without packed fp32 ops (build_native.py), so this is inline asm: the compile step passes it through to the listing and the
+// assembler step of the build knows the instruction.  Half the vector-ALU instructions of the folded plane (WINO_PK_FOLD).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_fma4(f32x2 c, f32x4 w, f32x4 b) {
+    f32x2 b01 = {b[0], b[1]}, b23 = {b[2], b[3]};
+    const f32x2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(b01) : "v"(c), "v"(w01));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(b23) : "v"(c), "v"(w23));
+    return f32x4{b01[0], b01[1], b23[0], b23[1]};
 }
 // Float4 sums written element by element.  As `a - b` on the vector type the four lanes stay one 128-bit value and the register
 // allocator needs an aligned quad for every intermediate of the rolling input transform; as four scalar ops they are independent
@@ -757,10 +771,17 @@ __device__ __forceinline__ void wino_tile_body(const WinoArgs& a) {
                             {
                                 const int pjn = (g + 1) >> 4;
                                 const float cs = ((PG == 1) == (pjn == 1)) ? foldc : -foldc;
+#if WINO_PK_FOLD
+                                const f32x2 c2 = {cs, cs};
+#pragma unroll
+                                for (int n = 0; n < 3; ++n) bf[pjn & 1][n] = pk_fma4(c2, wjt[n], bf[pjn & 1][n]);
+                                bf[pjn & 1][3] = pk_fma4(c2, wj3, bf[pjn & 1][3]);
+#else
                                 const f32x4 c4 = {cs, cs, cs, cs};
 #pragma unroll
                                 for (int n = 0; n < 3; ++n) bf[pjn & 1][n] = __builtin_elementwise_fma(c4, wjt[n], bf[pjn & 1][n]);
                                 bf[pjn & 1][3] = __builtin_elementwise_fma(c4, wj3, bf[pjn & 1][3]);
+#endif
                             }
                         }
                     }
