@@ -1258,8 +1258,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_gated_kernel(const WinoAr
 #endif
 
 #ifndef WINO_MS_TU
-template <bool PAR, bool RES>
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArgs a) {
+// FO ("fold only", as in the tile kernels): the frame passed the gate -- every 8x8 quadrant is all zero or carries one constant
+// partition plane -- so the unit reads its plane and factor from its first pixel and folds it into the B fragments: no per-lane
+// partition values, no branch code, one 1x1 fragment per step instead of three.  Same values as the PAR body bit for bit (the same
+// FMAs on the same fragments; accumulators started from an inline zero either way).
+template <bool PAR, bool RES, bool FO>
+__device__ __forceinline__ void wino_quad_body(const WinoArgs& a) {
+    static_assert(!(PAR && FO), "the fold-only body has no branch code");
     constexpr int QSTR = 272;                                // bytes per halo pixel in LDS (64 channels + 16: patch reads spread over banks)
     __shared__ __attribute__((aligned(16))) char smem[100 * QSTR];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1271,7 +1276,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
     if (qy0 >= H || qx0 >= W) return;
     const unsigned map_bytes = (unsigned)H * (unsigned)W * 256u;
     const __amdgpu_buffer_rsrc_t r_u = rsrc_of(a.U, 16u * 16384u);
-    const __amdgpu_buffer_rsrc_t r_up = rsrc_of(PAR ? a.Upar : a.U, 4u * 12288u);
+    const __amdgpu_buffer_rsrc_t r_up = rsrc_of((PAR || FO) ? a.Upar : a.U, 4u * 12288u);
     const __amdgpu_buffer_rsrc_t r_out = rsrc_of(a.out, map_bytes);
     const __amdgpu_buffer_rsrc_t r_res = rsrc_of(RES ? a.residual : a.src, RES ? map_bytes : 0u);
     const float act_lo = a.act == 0 ? 1.f : (a.act == 1 ? 0.f : 0.1f);
@@ -1297,12 +1302,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
                     praw[j][q] = a.par[(long)j * a.par_plane + (long)gy * W + gx];
                 }
         }
+        if constexpr (FO) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) praw[j][0] = a.par[(long)j * a.par_plane + (long)qy0 * W + qx0];      // (block-uniform)
+        }
     }
     const unsigned wq16 = (unsigned)lane * 16u + (unsigned)wave * 1024u;
     // B fragments of step s4 live in set s4 % QB, requested QA steps ahead (QA = 2: the first two steps' fragments are requested before
     // the halo has landed)
     constexpr int QA = WINO_QUAD_AHEAD, QB = QA + 1;
-    f32x4 Bq[QB][16], Bp[QB][3];
+    f32x4 Bq[QB][16], Bp[QB][FO ? 1 : 3];
 #pragma unroll
     for (int s0 = 0; s0 < QA; ++s0) {
 #pragma unroll
@@ -1312,6 +1321,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             for (int j = 0; j < 3; ++j) Bp[s0][j] = bload4(r_up, wq16, (unsigned)(s0 * 12288 + j * 4096));
         }
     }
+    int needq = 7, foldq = -1;
+    float foldcq = 0.f;
+    if constexpr (FO) {
+        // (the 1x1 fragments wait for the plane index: one dependent request, behind everything else of the prologue)
+        needq = 0;
+#pragma unroll
+        for (int j = 2; j >= 0; --j) {
+            const float uv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, praw[j][0])));
+            if (uv != 0.f) {
+                foldq = j;
+                foldcq = 0.25f * uv;
+            }
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < QA; ++s0) Bp[s0][0] = bload4(r_up, wq16, (unsigned)(s0 * 12288 + (foldq < 0 ? 0 : foldq) * 4096));
+    }
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int e = t + 256 * i;
@@ -1320,8 +1345,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
     // partition values of the lane's tile, signed as the output transform wants them (positions (0,3), (3,0) negated), and the branches
     // the unit needs at all (a plane that is zero on all 64 pixels adds exact zeros)
     float pq[3][4];
-    int needq = 7, foldq = -1;
-    float foldcq = 0.f;
     if constexpr (PAR) {
         int nz_any = 0;
 #pragma unroll
@@ -1376,6 +1399,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
 #pragma unroll
                 for (int j = 0; j < 3; ++j) Bp[(s4 + QA) % QB][j] = bload4(r_up, wq16, (unsigned)((s4 + QA) * 12288 + j * 4096));
             }
+            if constexpr (FO) Bp[(s4 + QA) % QB][0] = bload4(r_up, wq16, (unsigned)((s4 + QA) * 12288 + (foldq < 0 ? 0 : foldq) * 4096));
         }
         f32x4 dq[4][4], tq4[4];
 #pragma unroll
@@ -1426,6 +1450,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
                 Bq[s4 % QB][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 % QB][10]);
             }
         }
+        if constexpr (FO) {
+            if (foldq >= 0) {
+                const f32x4 wq = Bp[s4 % QB][0];
+                const f32x4 cp = {foldcq, foldcq, foldcq, foldcq}, cm = {-foldcq, -foldcq, -foldcq, -foldcq};
+                Bq[s4 % QB][5] = __builtin_elementwise_fma(cp, wq, Bq[s4 % QB][5]);
+                Bq[s4 % QB][6] = __builtin_elementwise_fma(cm, wq, Bq[s4 % QB][6]);
+                Bq[s4 % QB][9] = __builtin_elementwise_fma(cm, wq, Bq[s4 % QB][9]);
+                Bq[s4 % QB][10] = __builtin_elementwise_fma(cp, wq, Bq[s4 % QB][10]);
+            }
+        }
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
@@ -1459,6 +1493,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArg
             bstore1(r_out, inq ? qo : OOBW, (unsigned)((q >> 1) * W + 2 * r + (q & 1)) * 256u, v);
         }
     }
+}
+
+template <bool PAR, bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_kernel(const WinoArgs a) {
+    wino_quad_body<PAR, RES, false>(a);
+}
+// A small frame's front half behind the device-side gate as ONE launch, like conv3x3_wino_gated_kernel: bit 3 of the frame's partition
+// word picks the fold-only body, the branch body otherwise (block-uniform: a scalar load)
+template <bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_quad_gated_kernel(const WinoArgs a) {
+    if (__builtin_nontemporal_load(a.gate) & 8) wino_quad_body<false, RES, true>(a);
+    else wino_quad_body<true, RES, false>(a);
 }
 #endif      // !WINO_MS_TU
 #ifdef WINO_MS_TU
@@ -1789,7 +1835,11 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t stream) {
     const int ntiles = ((a.W + 15) / 16) * ((a.H + 15) / 16);
     if (a.wino_units && a.wwino) {                          // small frames: one block per quadrant unit
         const dim3 gq(4 * ntiles), bq(256);
-        if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_quad_kernel<true, true>), gq, bq, 0, stream, w);
+        if (a.wpar && a.par_any) {
+            w.gate = a.par_any;
+            if (a.residual) hipLaunchKernelGGL((conv3x3_wino_quad_gated_kernel<true>), gq, bq, 0, stream, w);
+            else hipLaunchKernelGGL((conv3x3_wino_quad_gated_kernel<false>), gq, bq, 0, stream, w);
+        } else if (a.wpar && a.residual) hipLaunchKernelGGL((conv3x3_wino_quad_kernel<true, true>), gq, bq, 0, stream, w);
         else if (a.wpar) hipLaunchKernelGGL((conv3x3_wino_quad_kernel<true, false>), gq, bq, 0, stream, w);
         else if (a.residual) hipLaunchKernelGGL((conv3x3_wino_quad_kernel<false, true>), gq, bq, 0, stream, w);
         else hipLaunchKernelGGL((conv3x3_wino_quad_kernel<false, false>), gq, bq, 0, stream, w);

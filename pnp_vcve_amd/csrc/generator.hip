@@ -726,7 +726,7 @@ int forward_sample(const pnp_generator* g, const float* flat, const float* packe
             for (int s = 1; s < q.nsrc; ++s) a.wwino_src[s] = q.wsrc_wino_[s];
         }
         a.wino_units = (q.wino_ || a.wwino_rgb) ? q.units_ : 0;
-        a.par_any = (q.wino_ && q.wpar_ && !a.wino_units) ? q.par_any_ : nullptr;
+        a.par_any = (q.wino_ && q.wpar_) ? q.par_any_ : nullptr;       // (tile kernels and quadrant-unit kernels alike: one gated launch)
         a.wpar_h = twin(q.wpar_);
         a.wpar_h_scaled = (g->prec == PNP_PREC_F16X3 && a.wpar_h) ? 1 : 0;     // the packed buffer holds 3 + 3 branch images (build_layout)
         a.par = q.par_;

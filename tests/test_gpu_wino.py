@@ -451,11 +451,14 @@ def test_generator_i_frame_front_halves_behind_the_device_side_gate():
     # quadrants 4 pixels high; 148x216: ragged in both directions and a flag tile whose right half lies outside.  A quadrant cut by the
     # frame's edge counts with the pixels it has -- in par_tile_flags' bit 6, in the fold-only kernel and in the branch kernel's own
     # per-wave decision (pixels outside take the nearest inside value) alike, so the gate stays bit-neutral
-    for extra, (h, w) in (({}, (192, 256)), ({'channel_first': False}, (192, 256)), ({}, (180, 320)), ({'channel_first': False}, (148, 216))):
+    # 128x128 and 100x132 (63 tiles, ragged both ways): the quadrant-unit kernels of small frames behind the same gate
+    # (conv3x3_wino_quad_gated_kernel: fold-only unit body | branch unit body)
+    for extra, (h, w) in (({}, (192, 256)), ({'channel_first': False}, (192, 256)), ({}, (180, 320)), ({'channel_first': False}, (148, 216)),
+                          ({}, (128, 128)), ({'channel_first': False}, (128, 128)), ({}, (100, 132)), ({'channel_first': False}, (100, 132))):
         cfg = dict(syn.DEFAULT_GENERATOR_CFG)
         cfg.update(extra)
         sd = syn.make_state_dict(cfg, seed=2025)
-        clip = syn.make_clip(seed=99, n=1, t=4, h=h, w=w, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)    # > 128 tiles: tile kernels
+        clip = syn.make_clip(seed=99, n=1, t=4, h=h, w=w, slices='IBBBP', qp_mode='qp', crf=25, block=8, par_classes=3)
         assert float(np.abs(clip['partitions'][0, 0]).max()) == 0.0 and float(np.abs(clip['partitions'][0, 1]).max()) > 0.0
         m = build(cfg, sd, 1)
         for with_records in (False, True, 'straddling'):

@@ -125,7 +125,7 @@ def test_winograd_kernel_is_built_without_packed_fp32_valu_ops(tmp_path):
     # the quadrant-unit kernels of small frames: straight-line code, no spill slot at all, no packed fp32 either
     units = [fn for fn in re.split(r'\n(?=_Z\w+:\s)', text) if 'conv3x3_wino_quad' in fn.split('\n')[0]]
     usizes = [int(v) for v in re.findall(r'conv3x3_wino_quad\w+\.private_seg_size, (\d+)', text)]
-    assert len(units) == 4 and len(usizes) == 4 and max(usizes) == 0, usizes
+    assert len(units) == 6 and len(usizes) == 6 and max(usizes) == 0, usizes      # {plain, RES, PAR, PAR+RES} + the two gated ones (fold-only | branch body)
     for fn in units:
         assert fn.count('v_mfma_f32_16x16x4_f32') >= 256 and not re.search(r'\bv_pk_(add|mul|fma)_f32\b', fn)
 
